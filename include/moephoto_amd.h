@@ -1,0 +1,139 @@
+/* moephoto_amd.h -- C ABI of libmoephoto_amd.so: the MI355X (gfx950) engine behind MoePhoto's
+ * tiled SR / denoise hot path.  Plain pointers and sizes only; no torch types.
+ *
+ * Every entry point replaces one piece of the reference's Python/PyTorch path (paths relative to
+ * the MoePhoto repo; see INTEGRATION.md for the ctypes stub a maintainer adds):
+ *
+ *   moe_net_create        the model constructors of the plugin tables' "constructor slot":
+ *                         Net2x/Net3x/Net4x/NetDN/SEDN (python/models.py:125-223) and
+ *                         MoeNet_lite2.Net(upscale) (python/MoeNet_lite2.py:22-37), as selected by
+ *                         runSR.mode_switch (python/runSR.py:10-24) / runDN.mode_switch (runDN.py:10-21)
+ *   moe_net_set_param     nn.Module.load_state_dict, one call per state-dict entry
+ *                         (python/imageProcess.py:319-328: model.load_state_dict(weights))
+ *   moe_net_finalize      castModel / model.to(dtype, device) (python/imageProcess.py:309-317)
+ *   moe_net_forward       modelCached(x): the torch.nn forward invoked from Option.__call__
+ *                         (python/imageProcess.py:391-395) inside doCrop's tile loop (:164-166)
+ *   moe_plan_*            the tile planner prepare/getAnchors (python/imageProcess.py:19-35,73-118)
+ *   moe_stitch            the blend + slice-assign part of doCrop (python/imageProcess.py:120-131,167-170)
+ *   moe_run_plan          doCrop as a whole (python/imageProcess.py:157-172): tile gather -> net -> stitch,
+ *                         device resident, batched over same-shaped tiles
+ *   moe_to_float/_output  toTorch / toOutput (python/imageProcess.py:245-263)
+ *
+ * All functions return 0 on success or a negative MOE_E* code; moe_last_error() returns a
+ * thread-local description (the Python wrapper raises RuntimeError / MemoryError from it, matching
+ * worker.enhance's error envelope, python/worker.py:52-74).  Device work is enqueued on the caller's
+ * hipStream_t (passed as void*) and never synchronised here: the reference runs on torch's current
+ * stream in one thread (python/worker.py:89-93), so must we.
+ */
+#ifndef MOEPHOTO_AMD_H
+#define MOEPHOTO_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOE_ABI_VERSION 1
+
+/* error codes */
+#define MOE_OK 0
+#define MOE_EINVAL (-1)   /* bad argument / unknown parameter name / shape mismatch */
+#define MOE_ENOMEM (-2)   /* host or device allocation failed, or a tile does not fit (-> MemoryError) */
+#define MOE_EHIP (-3)     /* a HIP runtime call failed (no device, launch failure, ...) */
+#define MOE_ESTATE (-4)   /* call order violated (forward before finalize, missing parameters) */
+
+/* architectures: the constructor slot of the plugin tables */
+#define MOE_ARCH_NET2X 0  /* models.Net2x  : a2/p2 */
+#define MOE_ARCH_NET3X 1  /* models.Net3x  : a3/p3 */
+#define MOE_ARCH_NET4X 2  /* models.Net4x  : a4/p4 */
+#define MOE_ARCH_NETDN 3  /* models.NetDN  : dn_lite5/10/15 */
+#define MOE_ARCH_SEDN 4   /* models.SEDN   : l15/l25/l50 */
+#define MOE_ARCH_LITE 5   /* MoeNet_lite2.Net(upscale = `scale` in {2,4,8}) */
+
+/* element types of caller-visible buffers */
+#define MOE_F32 0
+#define MOE_F16 1
+#define MOE_U8 2
+#define MOE_U16 3
+
+/* arithmetic of the MFMA convolutions (weights/activations as operands; accumulate is always fp32,
+ * the 1-channel stem and the final branch sum are always fp32) */
+#define MOE_PREC_FP16 0        /* fp16 operands, one MFMA pass: the reference's GPU fp16 mode (config.fp16) */
+#define MOE_PREC_FP16X3 1      /* hi/lo split operands, three MFMA passes: ~fp32 products */
+#define MOE_PREC_DEBUG_DIRECT 2 /* slow scalar device convolution, fp32 accumulate; kernel debugging only */
+
+typedef struct moe_net moe_net;
+typedef struct moe_plan moe_plan;
+
+const char* moe_last_error(void);
+int moe_abi_version(void);
+/* number of visible HIP devices (0 when none); never fails */
+int moe_device_count(void);
+
+/* ---- model ------------------------------------------------------------------------------------ */
+int moe_net_create(int arch, int scale, moe_net** out);
+void moe_net_destroy(moe_net* net);
+/* scale factor per side (1 for denoisers) */
+int moe_net_scale(const moe_net* net);
+/* number of state-dict entries this architecture expects, and the i-th name/shape
+ * (shape receives up to 4 dims, *ndim their count) */
+int moe_net_num_params(const moe_net* net);
+int moe_net_param_info(const moe_net* net, int index, const char** name, int64_t shape[4], int* ndim);
+/* one load_state_dict entry: fp32, C-contiguous, host memory; copied */
+int moe_net_set_param(moe_net* net, const char* name, const float* data, const int64_t* shape, int ndim);
+/* pack + upload weights to HIP device `device`; strict like load_state_dict (every parameter set).
+ * May be called again to move / change precision. */
+int moe_net_finalize(moe_net* net, int device, int precision);
+/* device bytes of scratch a forward of B planes of h x w needs (allocated lazily, grow-only, owned by the net) */
+int64_t moe_net_workspace_bytes(const moe_net* net, int B, int h, int w);
+/* y[b] = Net(x[b]),  x: B planes of h x w (h, w >= 1), element (b,i,j) at x + x_off[b] + i*sH + j*sW
+ * (strides in elements; x_off == NULL means b*sB), dtype MOE_F32/MOE_F16.  y: B contiguous planes of
+ * (scale*h) x (scale*w), plane b at y + (y_off ? y_off[b] : b*scale*h*scale*w), dtype MOE_F32/MOE_F16.
+ * x_off / y_off are HOST arrays of B element offsets.  Asynchronous on `stream`. */
+int moe_net_forward(moe_net* net, const void* x, int x_dtype, int B, int h, int w,
+                    int64_t sB, int64_t sH, int64_t sW, const int64_t* x_off,
+                    void* y, int y_dtype, const int64_t* y_off, void* stream);
+/* keep fp32 copies of named intermediates during forwards (slow; debugging / layer-by-layer parity only) */
+int moe_net_set_debug(moe_net* net, int enable);
+/* copy a named intermediate of the LAST forward to host as fp32 NCHW (debug / layer-by-layer parity);
+ * synchronises the stream.  Returns the element count written (<= capacity) or a negative error. */
+int64_t moe_net_debug_tap(moe_net* net, const char* tap, float* host, int64_t capacity, int64_t shape[4], void* stream);
+
+/* ---- tile planner (host only, no device needed) ------------------------------------------------ */
+/* shape = (C, H, W) of the image as handed to doCrop (before planes-as-batch); ram / ram_coef as in
+ * Option.ramCoef & config.calcFreeMem(); cropsize 0 = unlimited */
+int moe_plan_create(const int64_t shape[3], double ram, double ram_coef, int pad, int scale, int align,
+                    int cropsize, moe_plan** out);
+void moe_plan_destroy(moe_plan* plan);
+/* info[0..11] = n_tiles, step_h, step_w, out_h, out_w, pad_h_to, pad_w_to, pad_sc, tile_h, tile_w, clip_h, clip_w */
+int moe_plan_info(const moe_plan* plan, int64_t info[12]);
+/* tiles[k*8 .. k*8+7] = (top, bottom, left, right, topT, leftT, bsc, rsc) in raster order */
+int moe_plan_tiles(const moe_plan* plan, int32_t* tiles);
+/* blend ramp b[k] = sigmoid(9*(k/padSc - .5)), k < padSc, fp32 */
+int moe_plan_ramp(const moe_plan* plan, float* ramp);
+
+/* ---- device-side stitch / whole-image run ------------------------------------------------------ */
+/* Fold the per-tile results into the canvas exactly as doCrop's sequential blend does.
+ * tiles_dev: device buffer holding every tile's result as C contiguous fp32 planes of
+ * ((bottom-top)*scale) x ((right-left)*scale); tile k starts at element tile_off[k] (HOST array).
+ * out: (C, out_h, out_w) contiguous, dtype MOE_F32/MOE_F16. */
+int moe_stitch(const moe_plan* plan, int device, const float* tiles_dev, const int64_t* tile_off, int C,
+               void* out, int out_dtype, void* stream);
+/* doCrop on device: img = (C, Hp, Wp) planes (already padded per moe_plan_info's pad_*_to, see
+ * python wrapper), element (c,i,j) at img + c*sC + i*sH + j*sW; out as in moe_stitch.
+ * max_tiles_per_batch <= 0 picks a default. */
+int moe_run_plan(moe_net* net, const moe_plan* plan, const void* img, int img_dtype, int64_t sC, int64_t sH, int64_t sW,
+                 void* out, int out_dtype, int max_tiles_per_batch, void* stream);
+
+/* ---- image I/O edges ---------------------------------------------------------------------------- */
+/* src: H x W x C interleaved MOE_U8 (v/255) or MOE_U16 (v/2^bits); dst: C planes H x W, MOE_F32/MOE_F16 */
+int moe_to_float(const void* src, int src_dtype, int bits, int H, int W, int C, void* dst, int dst_dtype, int device, void* stream);
+/* src: C planes H x W (MOE_F32/MOE_F16); dst: H x W x C interleaved, v*2^bits clamped to [0, 2^bits-1], truncated */
+int moe_to_output(const void* src, int src_dtype, int H, int W, int C, int bits, void* dst, int dst_dtype, int device, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOEPHOTO_AMD_H */

@@ -1,0 +1,52 @@
+"""Builds libmoephoto_amd.so (HIP kernels + engine + C ABI) in-tree with hipcc for gfx950.
+
+    python -m moephoto_amd.build [--force]
+
+The .so is git-ignored but travels to the GPU box with the working tree (gpurun snapshot)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+SOURCES = ['conv_mfma.hip', 'misc_kernels.hip', 'engine.cpp', 'planner.cpp']
+HEADERS = ['common.h', 'engine.h', os.path.join('..', '..', 'include', 'moephoto_amd.h')]
+LIB = os.path.join(HERE, 'libmoephoto_amd.so')
+ARCH = 'gfx950'
+
+
+def hipcc():
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return 'hipcc'
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build_lib(force=False, verbose=False):
+    if not force and not stale():
+        return LIB
+    objs = []
+    os.makedirs(os.path.join(HERE, '_obj'), exist_ok=True)
+    for src in SOURCES:
+        obj = os.path.join(HERE, '_obj', os.path.splitext(src)[0] + '.o')
+        cmd = [hipcc(), '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-x', 'hip', '-c', os.path.join(CSRC, src), '-o', obj]
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build_lib(force='--force' in sys.argv, verbose=True))

@@ -1,0 +1,126 @@
+// common.h -- shared types between the gfx950 kernels and the host engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 half2_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 half4_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 half8_t;
+typedef __attribute__((ext_vector_type(4))) float float4_t;
+typedef __attribute__((ext_vector_type(16))) float float16_t;
+
+// Activation tensors live in HBM as NHWC fp16 with a channel stride that is a multiple of 64
+// (48-channel nets are zero-padded to 64): one pixel of a 64-channel tensor is exactly one 128-byte line.
+constexpr int kCB = 64;          // channel block
+constexpr int kTileW = 32;       // output pixels per patch row  (= MFMA N)
+constexpr int kTileH = 8;        // output rows per patch
+constexpr int kFragBytes = 1024; // one MFMA 32x32x16 f16 operand fragment: 64 lanes x 16 B
+
+// ---------------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution (conv_mfma.hip)
+// ---------------------------------------------------------------------------------------------------
+struct ConvArgs {
+    const half_t* in;     // [B][H][W][in_cs]
+    half_t* out;          // [B][H*r][W*r][out_cs]
+    const half_t* res;    // optional residual, same indexing as out (may alias out)
+    const half_t* wpk;    // packed weight fragments [wbatch][chunk][frag][lane][8]
+    const float* bias;    // [nchunks*64] in packed output-channel order, or nullptr
+    const half_t* zero;   // >= 256 B of zeros (out-of-image taps are redirected here)
+    // FP16X3 (hi/lo split operands): partial products are combined through an fp32 side buffer
+    half_t* out_lo;       // low part of the output activation ((v - hi) * 2^11), or nullptr
+    const half_t* res_lo; // low part of the residual, or nullptr
+    float* acc32;         // [B][H][W][nchunks*64] fp32 partial sums (pre-shuffle coordinates)
+    int acc_mode;         // 0: none, 1: store acc, 2: acc32 += acc, 3: acc += acc32 * 2^-11 then epilogue
+    long long w_batch_stride;  // halfs between per-plane weight sets (0: shared)
+    int B, H, W;
+    int in_cs, out_cs;    // channel strides of in / out, in halfs
+    int r;                // pixel-shuffle factor folded into the store (1: none)
+    int nchunks;          // 64-output-channel chunks
+    int G;                // persistent workgroups per chunk
+    int px, py;           // patches along x / y
+    float slope;          // PReLU / LeakyReLU slope (1: identity)
+    float scale;          // multiplier applied before the activation (ARSB ScaleLayer); 1: none
+};
+
+void launch_conv_mfma(const ConvArgs& a, int taps, int nseg, hipStream_t s);
+int conv_mfma_max_groups();  // persistent workgroups the device holds (1 per CU)
+hipError_t conv_mfma_init(); // raise dynamic-LDS limits once per process
+
+struct DirectConvArgs {
+    const half_t* in; half_t* out; const half_t* res;
+    const float* w;       // plain fp32 OIHW weights [cout][cin][k][k] (original channel counts)
+    const float* bias;    // [cout] original order or nullptr
+    long long w_batch_stride;
+    int B, H, W, in_cs, out_cs, cin, cout, k, r;
+    float slope, scale;
+};
+void launch_conv_direct(const DirectConvArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------------
+// HBM-bound kernels (misc_kernels.hip)
+// ---------------------------------------------------------------------------------------------------
+struct StemArgs {
+    const void* x; int x_dtype;      // MOE_F32 / MOE_F16
+    const long long* x_off;          // device [B] element offsets, or nullptr: b * sB
+    long long sB, sH, sW;
+    const float* w;                  // [taps][64] fp32 (padded channels zero)
+    float slope;
+    half_t* out;                     // [B][H][W][64]
+    half_t* out_lo;                  // FP16X3 low part or nullptr
+    int B, H, W, taps;
+};
+void launch_stem(const StemArgs& a, hipStream_t s);
+
+struct TailArgs {
+    const half_t* in0; const half_t* in1;  // [B][H][W][64]; in1 may be nullptr
+    const half_t* w0; const half_t* w1;    // [taps][64] fp16
+    const half_t* in0_lo; const half_t* in1_lo;  // FP16X3 low parts (all four or none)
+    const half_t* w0_lo; const half_t* w1_lo;
+    const void* skip; int skip_dtype;      // optional 1-channel skip (SEDN: + x), strided like the stem input
+    const long long* skip_off; long long skip_sB, skip_sH, skip_sW;   // skip_off nullptr: b * skip_sB
+    void* y; int y_dtype;                  // MOE_F32 / MOE_F16
+    const long long* y_off;                // device [B] element offsets of each output plane, or nullptr: b*H*W
+    int B, H, W, taps;
+};
+void launch_tail(const TailArgs& a, hipStream_t s);
+
+// per-plane channel sums: in [B][HW][C] fp16 -> partial [B][nslab][C] fp32
+void launch_pool_partial(const half_t* in, const half_t* in_lo, float* partial, int B, long long HW, int C, int nslab, hipStream_t s);
+
+struct SednSeArgs {   // _Conv_Block squeeze-excite (models.py:198-213) + per-plane scaling of the 1x1 `trans` weights
+    const float* partial; int nslab; long long HW;
+    const float* w_down;  // [16][256]
+    const float* w_up;    // [256][16]
+    const float* trans_pk32;  // trans weights in packed fragment order, fp32 [nfrag*512]
+    half_t* trans_out;        // [B][nfrag*512] fp16: trans * sigmoid-gate[cin]
+    half_t* trans_out_lo;     // low parts or nullptr
+    int B, nfrag;
+};
+void launch_sedn_se(const SednSeArgs& a, hipStream_t s);
+
+struct FrmArgs {     // FRM gate (models.py:270-287) then out = t*gate + x   (MoeNet_lite2.py:16-20)
+    const float* partial; int nslab; long long HW;
+    const float* w0; const float* b0;   // [3][64], [3]
+    const float* w2; const float* b2;   // [64][3], [64]
+    const half_t* t; const half_t* x; half_t* out;  // [B][HW][64]
+    const half_t* t_lo; const half_t* x_lo; half_t* out_lo;  // FP16X3 low parts or nullptr
+    float* gate;                         // [B][64] scratch
+    int B;
+};
+void launch_frm(const FrmArgs& a, hipStream_t s);
+
+struct StitchArgs {
+    const float* tiles; const long long* tile_off;   // device
+    const int* row_first; const int* row_cnt;        // device [out_h]: first covering tile row, count
+    const int* col_first; const int* col_cnt;        // device [out_w]
+    const int* row_tab; const int* col_tab;          // device [step][4] = (first, solid, origin, extent)
+    const float* ramp;                               // device [pad_sc]
+    void* out; int out_dtype;
+    int C, out_h, out_w, step_w;
+};
+void launch_stitch(const StitchArgs& a, hipStream_t s);
+
+void launch_to_float(const void* src, int src_dtype, float inv_or_div, bool divide, int H, int W, int C, void* dst, int dst_dtype, hipStream_t s);
+void launch_to_output(const void* src, int src_dtype, int H, int W, int C, float quant, void* dst, int dst_dtype, hipStream_t s);
+void launch_nhwc_to_nchw_f32(const half_t* in, const half_t* in_lo, float* out, int B, int H, int W, int cs, int C, hipStream_t s);

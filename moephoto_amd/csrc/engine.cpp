@@ -1,0 +1,986 @@
+// engine.cpp -- host side of libmoephoto_amd.so: model objects, weight packing, the per-architecture kernel
+// sequences, the device-resident doCrop (tile gather -> net -> stitch) and the extern "C" boundary.
+//
+// Reference for every sequence: python/models.py:108-223 (MyNet, Net2x/3x/4x, NetDN, SEDN/_Conv_Block),
+// python/MoeNet_lite2.py:22-54 (Net), python/imageProcess.py:157-172 (doCrop).  See include/moephoto_amd.h.
+#include "engine.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+using namespace moe;
+
+// =====================================================================================================
+// errors
+// =====================================================================================================
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                    \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? MOE_ENOMEM : MOE_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// =====================================================================================================
+// model
+// =====================================================================================================
+namespace {
+
+struct Param {
+    std::string name;
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+    bool set = false;
+    int64_t numel() const { int64_t n = 1; for (auto d : shape) n *= d; return n; }
+};
+
+struct ConvLayer {               // one MFMA convolution
+    int taps = 9, nseg = 1, nchunks = 1, r = 1;
+    int cin = 64, cout = 64, k = 3;
+    float slope = 1.f, scale = 1.f;
+    bool per_plane = false;      // SEDN trans: weights rebuilt per plane by the SE kernel
+    size_t w_hi = 0, w_lo = 0, bias = 0, w_plain = 0, bias_plain = 0, w_pk32 = 0;   // offsets into the device blob
+    bool has_bias = false;
+    int nfrag() const { return nseg * taps * 8; }
+};
+
+struct Act { half_t* hi = nullptr; half_t* lo = nullptr; };
+
+struct Arena {                   // bump allocator over the net's workspace (dry run when base == nullptr)
+    char* base = nullptr;
+    size_t off = 0;
+    void* take(size_t bytes)
+    {
+        const size_t a = (off + 255) & ~(size_t)255;
+        off = a + bytes;
+        return base ? base + a : nullptr;
+    }
+};
+
+}  // namespace
+
+struct moe_net {
+    int arch = 0, scale = 1;
+    int C = 64;                  // real channel count (48 for NetDN / lite); tensors are padded to 64
+    int stages = 1, r = 2;       // upsampler stages and their shuffle factor
+    std::vector<Param> params;
+    std::map<std::string, int> index;
+    bool finalized = false;
+    int device = -1, precision = MOE_PREC_FP16;
+    // device weights
+    char* blob = nullptr;
+    size_t blob_bytes = 0;
+    std::vector<ConvLayer> convs;
+    std::map<std::string, int> conv_index;
+    std::map<std::string, size_t> small;     // name -> blob offset of small fp32 / fp16 tables
+    std::map<std::string, float> scalars;
+    // workspace
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    int max_groups = 256;
+    // debug taps
+    bool debug = false;
+    struct Tap { float* dev = nullptr; int64_t shape[4] = {0, 0, 0, 0}; };
+    std::map<std::string, Tap> taps;
+
+    const Param* get(const std::string& n) const
+    {
+        auto it = index.find(n);
+        return it == index.end() ? nullptr : &params[it->second];
+    }
+    void add(const std::string& n, std::vector<int64_t> shape)
+    {
+        index[n] = (int)params.size();
+        Param p; p.name = n; p.shape = std::move(shape);
+        params.push_back(std::move(p));
+    }
+};
+
+static void declare_params(moe_net& n)
+{
+    const int C = n.C;
+    auto arsb = [&](const std::string& p) {
+        n.add(p + "conv_1.weight", {C, C, 3, 3});
+        n.add(p + "relu.weight", {1});
+        n.add(p + "conv_2.weight", {C, C, 3, 3});
+        n.add(p + "scale.scale", {1});
+    };
+    if (n.arch == MOE_ARCH_NET2X || n.arch == MOE_ARCH_NET3X || n.arch == MOE_ARCH_NET4X) {
+        n.add("conv_input.weight", {64, 1, 3, 3});
+        n.add("conv_input2.weight", {64, 64, 3, 3});
+        n.add("relu.weight", {1});
+        for (const char* br : {"u", "convt_R1"}) {
+            for (int s = 0; s < n.stages; ++s) {
+                const std::string p = std::string(br) + "." + std::to_string(s) + ".";
+                n.add(p + "0.weight", {64 * n.r * n.r, 64, 3, 3});
+                n.add(p + "0.bias", {64 * n.r * n.r});
+                n.add(p + "2.weight", {1});
+            }
+            n.add(std::string(br) + "." + std::to_string(n.stages) + ".weight", {1, 64, 3, 3});
+        }
+        for (int i = 1; i <= 6; ++i) arsb("convt_F" + std::to_string(i) + ".0.");
+    } else if (n.arch == MOE_ARCH_NETDN) {
+        n.add("conv_input.weight", {48, 1, 3, 3});
+        n.add("conv_input2.weight", {48, 48, 3, 3});
+        n.add("relu.weight", {1});
+        n.add("u.weight", {1, 48, 3, 3});
+        n.add("convt_R1.weight", {1, 48, 3, 3});
+        for (int i = 1; i <= 6; ++i) arsb("convt_F" + std::to_string(i) + ".0.");
+    } else if (n.arch == MOE_ARCH_SEDN) {
+        n.add("conv_input.weight", {64, 1, 3, 3});
+        n.add("convt_R1.weight", {1, 64, 3, 3});
+        for (int b = 0; b < 16; ++b) {
+            const std::string p = "convt_F1." + std::to_string(b) + ".";
+            n.add(p + "rblock.0.weight", {64, 64, 3, 3});
+            n.add(p + "rblock.2.weight", {64, 64, 3, 3});
+            n.add(p + "rblock.4.weight", {256, 64, 3, 3});
+            n.add(p + "trans.0.weight", {64, 256, 1, 1});
+            n.add(p + "conv_down.weight", {16, 256, 1, 1});
+            n.add(p + "conv_up.weight", {256, 16, 1, 1});
+        }
+    } else {   // MOE_ARCH_LITE
+        n.add("conv_input.weight", {48, 1, 1, 1});
+        n.add("conv_input2.weight", {48, 48, 1, 1});
+        n.add("relu.weight", {1});
+        for (const char* br : {"ures", "uim"})
+            for (int s = 0; s < n.stages; ++s) {
+                const std::string p = std::string(br) + "." + std::to_string(s) + ".";
+                n.add(p + "0.weight", {192, 48, 1, 1});
+                n.add(p + "0.bias", {192});
+                n.add(p + "2.weight", {1});
+            }
+        n.add("convt_R1.weight", {1, 48, 1, 1});
+        n.add("convt_I1.weight", {1, 48, 1, 1});
+        for (int k = 1; k <= 3; ++k) {
+            const std::string p = "convt_F1" + std::to_string(k) + ".";
+            n.add(p + "conv_1.weight", {48, 48, 3, 3});
+            n.add(p + "conv_2.weight", {48, 48, 3, 3});
+            n.add(p + "relu.weight", {1});
+            n.add(p + "se.conv_du.0.weight", {3, 48, 1, 1});
+            n.add(p + "se.conv_du.0.bias", {3});
+            n.add(p + "se.conv_du.2.weight", {48, 3, 1, 1});
+            n.add(p + "se.conv_du.2.bias", {48});
+        }
+    }
+}
+
+// =====================================================================================================
+// weight packing
+// =====================================================================================================
+namespace {
+
+struct BlobBuilder {
+    std::vector<char> data;
+    size_t take(size_t bytes)
+    {
+        const size_t a = (data.size() + 255) & ~(size_t)255;
+        data.resize(a + bytes, 0);
+        return a;
+    }
+    template <typename T> T* at(size_t off) { return (T*)(data.data() + off); }
+};
+
+// packed output channel n' = chunk*64 + cl  ->  original output channel, or -1 (padding).
+// r > 1: chunk = sub-pixel (i*r + j), cl = channel c of the shuffled output: original = c*r*r + i*r + j
+inline int orig_cout(int np, int cout, int r)
+{
+    const int chunk = np / 64, cl = np % 64;
+    if (r > 1) {
+        const int cs = cout / (r * r);
+        return cl < cs ? cl * r * r + chunk : -1;
+    }
+    return np < cout ? np : -1;
+}
+
+// A-operand fragments of v_mfma_f32_32x32x16_f16 for D[cout][pixel]: fragment f = ((seg*taps + tap)*4 + ks)*2 + nblk,
+// lane l holds W[cout = chunk*64 + nblk*32 + (l&31)][cin = seg*64 + ks*16 + 8*(l>>5) + e][tap], e = 0..7
+void pack_conv(const Param& W, const Param* bias, int r, ConvLayer& L, BlobBuilder& bb, bool want_lo, bool want_plain, bool want_pk32)
+{
+    const int cout = (int)W.shape[0], cin = (int)W.shape[1], k = (int)W.shape[2];
+    L.cout = cout; L.cin = cin; L.k = k; L.r = r;
+    L.taps = k * k;
+    L.nseg = (cin + 63) / 64;
+    L.nchunks = r > 1 ? r * r : (cout + 63) / 64;
+    const int nfrag = L.nfrag();
+    const size_t nel = (size_t)L.nchunks * nfrag * 512;
+    L.w_hi = bb.take(nel * 2);
+    if (want_lo) L.w_lo = bb.take(nel * 2);
+    if (want_pk32) L.w_pk32 = bb.take(nel * 4);
+    for (int chunk = 0; chunk < L.nchunks; ++chunk)
+        for (int f = 0; f < nfrag; ++f) {
+            const int nblk = f & 1, ks = (f >> 1) & 3, st = f >> 3;
+            const int tap = st % L.taps, seg = st / L.taps;
+            for (int l = 0; l < 64; ++l)
+                for (int e = 0; e < 8; ++e) {
+                    const int np = chunk * 64 + nblk * 32 + (l & 31);
+                    const int ci = seg * 64 + ks * 16 + 8 * (l >> 5) + e;
+                    const int oc = orig_cout(np, cout, r);
+                    float v = 0.f;
+                    if (oc >= 0 && ci < cin) v = W.data[((size_t)oc * cin + ci) * L.taps + tap];
+                    const size_t idx = ((size_t)(chunk * nfrag + f) * 64 + l) * 8 + e;
+                    const half_t hv = (half_t)v;
+                    bb.at<half_t>(L.w_hi)[idx] = hv;
+                    if (want_lo) bb.at<half_t>(L.w_lo)[idx] = (half_t)((v - (float)hv) * 2048.f);
+                    if (want_pk32) bb.at<float>(L.w_pk32)[idx] = v;
+                }
+        }
+    L.has_bias = bias != nullptr;
+    if (bias) {
+        L.bias = bb.take((size_t)L.nchunks * 64 * 4);
+        for (int np = 0; np < L.nchunks * 64; ++np) {
+            const int oc = orig_cout(np, cout, r);
+            bb.at<float>(L.bias)[np] = oc >= 0 ? bias->data[oc] : 0.f;
+        }
+    }
+    if (want_plain) {
+        L.w_plain = bb.take(W.data.size() * 4);
+        memcpy(bb.at<float>(L.w_plain), W.data.data(), W.data.size() * 4);
+        if (bias) {
+            L.bias_plain = bb.take(bias->data.size() * 4);
+            memcpy(bb.at<float>(L.bias_plain), bias->data.data(), bias->data.size() * 4);
+        }
+    }
+}
+
+}  // namespace
+
+static float scalar_of(const moe_net& n, const std::string& name) { return n.get(name)->data[0]; }
+
+static int build_device_weights(moe_net& n, int precision)
+{
+    BlobBuilder bb;
+    n.convs.clear(); n.conv_index.clear(); n.small.clear(); n.scalars.clear();
+    const bool lo = precision == MOE_PREC_FP16X3, plain = precision == MOE_PREC_DEBUG_DIRECT;
+    auto conv = [&](const std::string& key, const std::string& wname, const char* bname, int r, float slope, float scale,
+                    bool per_plane = false) {
+        ConvLayer L;
+        const Param* b = bname ? n.get(bname) : nullptr;
+        pack_conv(*n.get(wname), b, r, L, bb, lo, plain, per_plane);
+        L.slope = slope; L.scale = scale; L.per_plane = per_plane;
+        n.conv_index[key] = (int)n.convs.size();
+        n.convs.push_back(L);
+    };
+    auto f32table = [&](const std::string& key, const std::vector<float>& v) {
+        const size_t o = bb.take(v.size() * 4);
+        memcpy(bb.at<float>(o), v.data(), v.size() * 4);
+        n.small[key] = o;
+    };
+    auto stem = [&](const std::string& wname) {   // [tap][64] fp32
+        const Param& W = *n.get(wname);
+        const int C = (int)W.shape[0], taps = (int)(W.shape[2] * W.shape[3]);
+        std::vector<float> t((size_t)taps * 64, 0.f);
+        for (int c = 0; c < C; ++c) for (int k = 0; k < taps; ++k) t[(size_t)k * 64 + c] = W.data[(size_t)c * taps + k];
+        f32table("stem", t);
+        n.scalars["stem_taps"] = (float)taps;
+    };
+    auto tail = [&](const std::string& key, const std::string& wname) {   // [tap][64] fp16 (+lo)
+        const Param& W = *n.get(wname);
+        const int C = (int)W.shape[1], taps = (int)(W.shape[2] * W.shape[3]);
+        const size_t o = bb.take((size_t)taps * 64 * 2), ol = bb.take((size_t)taps * 64 * 2);
+        for (int c = 0; c < C; ++c)
+            for (int k = 0; k < taps; ++k) {
+                const float v = W.data[(size_t)c * taps + k];
+                const half_t hv = (half_t)v;
+                bb.at<half_t>(o)[(size_t)k * 64 + c] = hv;
+                bb.at<half_t>(ol)[(size_t)k * 64 + c] = (half_t)((v - (float)hv) * 2048.f);
+            }
+        n.small[key] = o; n.small[key + ".lo"] = ol;
+        n.scalars["tail_taps"] = (float)taps;
+    };
+    n.small["zero"] = bb.take(1024);
+
+    if (n.arch == MOE_ARCH_NET2X || n.arch == MOE_ARCH_NET3X || n.arch == MOE_ARCH_NET4X || n.arch == MOE_ARCH_NETDN) {
+        stem("conv_input.weight");
+        n.scalars["stem_slope"] = scalar_of(n, "relu.weight");
+        conv("input2", "conv_input2.weight", nullptr, 1, 1.f, 1.f);
+        for (int i = 1; i <= 6; ++i) {
+            const std::string p = "convt_F" + std::to_string(i) + ".0.";
+            conv("c1_" + std::to_string(i), p + "conv_1.weight", nullptr, 1, scalar_of(n, p + "relu.weight"), 1.f);
+            conv("c2_" + std::to_string(i), p + "conv_2.weight", nullptr, 1, 1.f, scalar_of(n, p + "scale.scale"));
+        }
+        if (n.arch == MOE_ARCH_NETDN) {
+            tail("tail_r", "convt_R1.weight");
+            tail("tail_u", "u.weight");
+        } else {
+            for (const char* br : {"u", "convt_R1"}) {
+                for (int s = 0; s < n.stages; ++s) {
+                    const std::string p = std::string(br) + "." + std::to_string(s) + ".";
+                    conv(std::string(br) + ".up" + std::to_string(s), p + "0.weight", (p + "0.bias").c_str(), n.r,
+                         scalar_of(n, p + "2.weight"), 1.f);
+                }
+            }
+            tail("tail_r", "convt_R1." + std::to_string(n.stages) + ".weight");
+            tail("tail_u", "u." + std::to_string(n.stages) + ".weight");
+        }
+    } else if (n.arch == MOE_ARCH_SEDN) {
+        stem("conv_input.weight");
+        n.scalars["stem_slope"] = 0.2f;
+        for (int b = 0; b < 16; ++b) {
+            const std::string p = "convt_F1." + std::to_string(b) + ".", k = "b" + std::to_string(b);
+            conv(k + ".rb0", p + "rblock.0.weight", nullptr, 1, 0.2f, 1.f);
+            conv(k + ".rb2", p + "rblock.2.weight", nullptr, 1, 0.2f, 1.f);
+            conv(k + ".rb4", p + "rblock.4.weight", nullptr, 1, 1.f, 1.f);
+            conv(k + ".trans", p + "trans.0.weight", nullptr, 1, 0.2f, 1.f, true);
+            f32table(k + ".down", n.get(p + "conv_down.weight")->data);
+            f32table(k + ".up", n.get(p + "conv_up.weight")->data);
+        }
+        tail("tail_r", "convt_R1.weight");
+    } else {
+        stem("conv_input.weight");
+        n.scalars["stem_slope"] = scalar_of(n, "relu.weight");
+        conv("input2", "conv_input2.weight", nullptr, 1, 1.f, 1.f);
+        for (int k = 1; k <= 3; ++k) {
+            const std::string p = "convt_F1" + std::to_string(k) + ".", key = "lb" + std::to_string(k);
+            conv(key + ".c1", p + "conv_1.weight", nullptr, 1, scalar_of(n, p + "relu.weight"), 1.f);
+            conv(key + ".c2", p + "conv_2.weight", nullptr, 1, 1.f, 1.f);
+            // FRM tables padded to 64 channels: w0 [3][64], b0 [3], w2 [64][3], b2 [64]
+            std::vector<float> w0(3 * 64, 0.f), w2(64 * 3, 0.f), b2(64, 0.f);
+            const Param& W0 = *n.get(p + "se.conv_du.0.weight");
+            const Param& W2 = *n.get(p + "se.conv_du.2.weight");
+            for (int j = 0; j < 3; ++j) for (int c = 0; c < 48; ++c) w0[j * 64 + c] = W0.data[j * 48 + c];
+            for (int c = 0; c < 48; ++c) { for (int j = 0; j < 3; ++j) w2[c * 3 + j] = W2.data[c * 3 + j]; b2[c] = n.get(p + "se.conv_du.2.bias")->data[c]; }
+            f32table(key + ".w0", w0);
+            f32table(key + ".b0", n.get(p + "se.conv_du.0.bias")->data);
+            f32table(key + ".w2", w2);
+            f32table(key + ".b2", b2);
+        }
+        for (const char* br : {"ures", "uim"})
+            for (int s = 0; s < n.stages; ++s) {
+                const std::string p = std::string(br) + "." + std::to_string(s) + ".";
+                conv(std::string(br) + ".up" + std::to_string(s), p + "0.weight", (p + "0.bias").c_str(), 2, scalar_of(n, p + "2.weight"), 1.f);
+            }
+        tail("tail_r", "convt_R1.weight");
+        tail("tail_u", "convt_I1.weight");
+    }
+
+    if (n.blob) { (void)hipFree(n.blob); n.blob = nullptr; }
+    HIP_TRY(hipMalloc((void**)&n.blob, bb.data.size()));
+    n.blob_bytes = bb.data.size();
+    HIP_TRY(hipMemcpy(n.blob, bb.data.data(), bb.data.size(), hipMemcpyHostToDevice));
+    return MOE_OK;
+}
+
+// =====================================================================================================
+// forward
+// =====================================================================================================
+namespace {
+
+struct Fwd {
+    moe_net& n;
+    hipStream_t s;
+    int B, h, w;
+    Arena ar;
+    bool x3, direct;
+    float* acc32 = nullptr;
+    size_t acc32_elems = 0;
+    bool dry() const { return ar.base == nullptr; }
+
+    Act act(long long pixels, int ch = 64)
+    {
+        Act a;
+        a.hi = (half_t*)ar.take((size_t)pixels * ch * 2);
+        if (x3) a.lo = (half_t*)ar.take((size_t)pixels * ch * 2);
+        return a;
+    }
+    template <typename T> T* blob(size_t off) const { return (T*)(n.blob + off); }
+    template <typename T> T* small(const std::string& k) const { return (T*)(n.blob + n.small.at(k)); }
+
+    void tap(const std::string& name, const Act& a, int H, int W, int cs, int C)
+    {
+        if (!n.debug || dry()) return;
+        auto& t = n.taps[name];
+        if (t.dev) { (void)hipFree(t.dev); t.dev = nullptr; }
+        const size_t nel = (size_t)B * C * H * W;
+        if (hipMalloc((void**)&t.dev, nel * 4) != hipSuccess) return;
+        t.shape[0] = B; t.shape[1] = C; t.shape[2] = H; t.shape[3] = W;
+        launch_nhwc_to_nchw_f32(a.hi, a.lo, t.dev, B, H, W, cs, C, s);
+    }
+
+    // one convolution layer: in [B][H][W][64*nseg] -> out [B][H*r][W*r][r>1 ? 64 : 64*nchunks]
+    void conv(const std::string& key, const Act& in, const Act& out, const Act* res, int H, int W, const half_t* plane_w = nullptr,
+              const half_t* plane_w_lo = nullptr)
+    {
+        if (dry()) return;
+        const ConvLayer& L = n.convs[n.conv_index.at(key)];
+        const int out_cs = L.r > 1 ? 64 : 64 * L.nchunks;
+        if (direct) {
+            DirectConvArgs d{};
+            d.in = in.hi; d.out = out.hi; d.res = res ? res->hi : nullptr;
+            d.w = blob<float>(L.w_plain);
+            d.bias = L.has_bias ? blob<float>(L.bias_plain) : nullptr;
+            d.w_batch_stride = 0;
+            d.B = B; d.H = H; d.W = W; d.in_cs = 64 * L.nseg; d.out_cs = out_cs; d.cin = L.cin; d.cout = L.cout; d.k = L.k; d.r = L.r;
+            d.slope = L.slope; d.scale = L.scale;
+            if (L.per_plane) { d.w = (const float*)plane_w; d.w_batch_stride = (long long)L.cout * L.cin; }
+            launch_conv_direct(d, s);
+            return;
+        }
+        ConvArgs a{};
+        a.in = in.hi; a.out = out.hi; a.res = res ? res->hi : nullptr;
+        a.wpk = L.per_plane ? plane_w : blob<half_t>(L.w_hi);
+        a.bias = L.has_bias ? blob<float>(L.bias) : nullptr;
+        a.zero = small<half_t>("zero");
+        a.w_batch_stride = L.per_plane ? (long long)L.nchunks * L.nfrag() * 512 : 0;
+        a.B = B; a.H = H; a.W = W; a.in_cs = 64 * L.nseg; a.out_cs = out_cs; a.r = L.r; a.nchunks = L.nchunks;
+        a.px = (W + kTileW - 1) / kTileW; a.py = (H + kTileH - 1) / kTileH;
+        const long long items = (long long)B * a.px * a.py;
+        int G = n.max_groups / L.nchunks;
+        if (G < 1) G = 1;
+        if (G > items) G = (int)items;
+        a.G = G;
+        a.slope = L.slope; a.scale = L.scale;
+        if (!x3) { launch_conv_mfma(a, L.taps, L.nseg, s); return; }
+        // hi/lo split: (w_lo * a_hi) -> acc32,  += (w_hi * a_lo),  then (w_hi * a_hi) + acc32/2048 and the epilogue
+        a.acc32 = acc32;
+        ConvArgs p1 = a; p1.wpk = L.per_plane ? plane_w_lo : blob<half_t>(L.w_lo); p1.acc_mode = 1; p1.res = nullptr; p1.bias = nullptr;
+        launch_conv_mfma(p1, L.taps, L.nseg, s);
+        ConvArgs p2 = a; p2.in = in.lo; p2.acc_mode = 2; p2.res = nullptr; p2.bias = nullptr;
+        launch_conv_mfma(p2, L.taps, L.nseg, s);
+        ConvArgs p3 = a; p3.acc_mode = 3; p3.out_lo = out.lo; p3.res_lo = res ? res->lo : nullptr;
+        launch_conv_mfma(p3, L.taps, L.nseg, s);
+    }
+};
+
+size_t acc32_need(const moe_net& n, int B, int h, int w)
+{
+    // largest [B][H][W][nchunks*64] fp32 any conv of this net produces (pre-shuffle coordinates)
+    size_t best = 0;
+    long long HW = (long long)h * w;
+    if (n.arch == MOE_ARCH_SEDN) return (size_t)B * (size_t)HW * 256;
+    int rr = 1;
+    best = (size_t)B * (size_t)HW * 64;
+    for (int s = 0; s < n.stages; ++s) {
+        best = std::max<size_t>(best, (size_t)B * (size_t)HW * rr * rr * 64 * n.r * n.r);
+        rr *= n.r;
+    }
+    return best;
+}
+
+int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, long long sH, long long sW, const long long* x_off_dev,
+                void* y, int y_dtype, const long long* y_off_dev)
+{
+    const int B = f.B, h = f.h, w = f.w;
+    const long long P = (long long)B * h * w;
+    hipStream_t s = f.s;
+    if (f.x3) { f.acc32_elems = acc32_need(n, B, h, w); f.acc32 = (float*)f.ar.take(f.acc32_elems * 4); }
+
+    auto stem = [&](const Act& out) {
+        if (f.dry()) return;
+        StemArgs a{};
+        a.x = x; a.x_dtype = x_dtype; a.x_off = x_off_dev; a.sB = sB; a.sH = sH; a.sW = sW;
+        a.w = f.small<float>("stem"); a.slope = n.scalars.at("stem_slope");
+        a.out = out.hi; a.out_lo = out.lo; a.B = B; a.H = h; a.W = w; a.taps = (int)n.scalars.at("stem_taps");
+        launch_stem(a, s);
+    };
+    auto tail = [&](const Act* r, const Act* u, int H, int W, bool skip) {
+        if (f.dry()) return;
+        TailArgs a{};
+        a.in0 = r->hi; a.w0 = f.small<half_t>("tail_r");
+        if (u) { a.in1 = u->hi; a.w1 = f.small<half_t>("tail_u"); }
+        if (f.x3) {
+            a.in0_lo = r->lo; a.w0_lo = f.small<half_t>("tail_r.lo");
+            if (u) { a.in1_lo = u->lo; a.w1_lo = f.small<half_t>("tail_u.lo"); }
+        }
+        if (skip) { a.skip = x; a.skip_dtype = x_dtype; a.skip_off = x_off_dev; a.skip_sB = sB; a.skip_sH = sH; a.skip_sW = sW; }
+        a.y = y; a.y_dtype = y_dtype; a.y_off = y_off_dev; a.B = B; a.H = H; a.W = W; a.taps = (int)n.scalars.at("tail_taps");
+        launch_tail(a, s);
+    };
+
+    if (n.arch == MOE_ARCH_NET2X || n.arch == MOE_ARCH_NET3X || n.arch == MOE_ARCH_NET4X || n.arch == MOE_ARCH_NETDN) {
+        Act A = f.act(P), Bb = f.act(P), Cc = f.act(P);
+        stem(A);
+        f.tap("stem", A, h, w, 64, n.C);
+        f.conv("input2", A, Bb, nullptr, h, w);
+        f.tap("input2", Bb, h, w, 64, n.C);
+        for (int i = 1; i <= 6; ++i) {
+            f.conv("c1_" + std::to_string(i), Bb, Cc, nullptr, h, w);
+            f.conv("c2_" + std::to_string(i), Cc, Bb, &Bb, h, w);
+            f.tap("arsb" + std::to_string(i), Bb, h, w, 64, n.C);
+        }
+        if (n.arch == MOE_ARCH_NETDN) { tail(&Bb, &A, h, w, false); return MOE_OK; }
+        // two upsampler branches: R on the trunk output, U on the stem output (models.py:117-123)
+        Act fin[2];
+        int H = h, W = w;
+        for (int br = 0; br < 2; ++br) {
+            Act cur = br == 0 ? Bb : A;
+            H = h; W = w;
+            for (int st = 0; st < n.stages; ++st) {
+                Act nxt = f.act((long long)B * H * n.r * W * n.r);
+                f.conv(std::string(br == 0 ? "convt_R1" : "u") + ".up" + std::to_string(st), cur, nxt, nullptr, H, W);
+                H *= n.r; W *= n.r;
+                f.tap(std::string(br == 0 ? "r" : "u") + ".up" + std::to_string(st), nxt, H, W, 64, 64);
+                cur = nxt;
+            }
+            fin[br] = cur;
+        }
+        tail(&fin[0], &fin[1], H, W, false);
+        return MOE_OK;
+    }
+    if (n.arch == MOE_ARCH_SEDN) {
+        Act A = f.act(P), Cc = f.act(P), Dd = f.act(P), T = f.act(P, 256);
+        const int nslab = (int)std::min<long long>(64, std::max<long long>(1, ((long long)h * w) / 256));
+        float* partial = (float*)f.ar.take((size_t)B * nslab * 256 * 4);
+        const ConvLayer& Lt = n.convs[n.conv_index.at("b0.trans")];
+        const size_t wel = (size_t)Lt.nchunks * Lt.nfrag() * 512;
+        half_t* wplane = (half_t*)f.ar.take(f.direct ? (size_t)B * 64 * 256 * 4 : (size_t)B * wel * 2);
+        half_t* wplane_lo = f.x3 ? (half_t*)f.ar.take((size_t)B * wel * 2) : nullptr;
+        stem(A);
+        f.tap("stem", A, h, w, 64, 64);
+        for (int b = 0; b < 16; ++b) {
+            const std::string k = "b" + std::to_string(b);
+            f.conv(k + ".rb0", A, Cc, nullptr, h, w);
+            f.conv(k + ".rb2", Cc, Dd, nullptr, h, w);
+            f.conv(k + ".rb4", Dd, T, nullptr, h, w);
+            if (!f.dry()) {
+                launch_pool_partial(T.hi, T.lo, partial, B, (long long)h * w, 256, nslab, s);
+                const ConvLayer& L = n.convs[n.conv_index.at(k + ".trans")];
+                SednSeArgs a{};
+                a.partial = partial; a.nslab = nslab; a.HW = (long long)h * w;
+                a.w_down = f.small<float>(k + ".down"); a.w_up = f.small<float>(k + ".up");
+                a.B = B;
+                if (f.direct) {
+                    // plain fp32 OIHW weights [64][256]: element i -> cin = i % 256; reuse the SE kernel with a
+                    // "fragment" view of 1 element per cin is not possible, so the debug path scales on the host-side layout:
+                    a.trans_pk32 = f.blob<float>(L.w_plain); a.nfrag = -(64 * 256);   // negative: plain layout marker
+                    a.trans_out = wplane;
+                } else {
+                    a.trans_pk32 = f.blob<float>(L.w_pk32); a.nfrag = L.nfrag() * L.nchunks;
+                    a.trans_out = wplane; a.trans_out_lo = wplane_lo;
+                }
+                launch_sedn_se(a, s);
+            }
+            f.conv(k + ".trans", T, A, &A, h, w, wplane, wplane_lo);
+            f.tap("block" + std::to_string(b), A, h, w, 64, 64);
+        }
+        tail(&A, nullptr, h, w, true);
+        return MOE_OK;
+    }
+    // MOE_ARCH_LITE
+    {
+        Act A = f.act(P), Bb = f.act(P), Cc = f.act(P), Dd = f.act(P);
+        const int nslab = (int)std::min<long long>(64, std::max<long long>(1, ((long long)h * w) / 256));
+        float* partial = (float*)f.ar.take((size_t)B * nslab * 64 * 4);
+        float* gate = (float*)f.ar.take((size_t)B * 64 * 4);
+        stem(A);
+        f.tap("stem", A, h, w, 64, 48);
+        f.conv("input2", A, Bb, nullptr, h, w);
+        f.tap("input2", Bb, h, w, 64, 48);
+        for (int k = 1; k <= 3; ++k) {
+            const std::string key = "lb" + std::to_string(k);
+            f.conv(key + ".c1", Bb, Cc, nullptr, h, w);
+            f.conv(key + ".c2", Cc, Dd, nullptr, h, w);
+            if (!f.dry()) {
+                launch_pool_partial(Dd.hi, Dd.lo, partial, B, (long long)h * w, 64, nslab, s);
+                FrmArgs a{};
+                a.partial = partial; a.nslab = nslab; a.HW = (long long)h * w;
+                a.w0 = f.small<float>(key + ".w0"); a.b0 = f.small<float>(key + ".b0");
+                a.w2 = f.small<float>(key + ".w2"); a.b2 = f.small<float>(key + ".b2");
+                a.t = Dd.hi; a.x = Bb.hi; a.out = Bb.hi; a.t_lo = Dd.lo; a.x_lo = Bb.lo; a.out_lo = Bb.lo;
+                a.gate = gate; a.B = B;
+                launch_frm(a, s);
+            }
+            f.tap(key, Bb, h, w, 64, 48);
+        }
+        Act fin[2];
+        int H = h, W = w;
+        for (int br = 0; br < 2; ++br) {
+            Act cur = br == 0 ? Bb : A;
+            H = h; W = w;
+            for (int st = 0; st < n.stages; ++st) {
+                Act nxt = f.act((long long)B * H * 2 * W * 2);
+                f.conv(std::string(br == 0 ? "ures" : "uim") + ".up" + std::to_string(st), cur, nxt, nullptr, H, W);
+                H *= 2; W *= 2;
+                f.tap(std::string(br == 0 ? "r" : "u") + ".up" + std::to_string(st), nxt, H, W, 64, 48);
+                cur = nxt;
+            }
+            fin[br] = cur;
+        }
+        tail(&fin[0], &fin[1], H, W, false);
+    }
+    return MOE_OK;
+}
+
+size_t workspace_need(moe_net& n, int B, int h, int w)
+{
+    Fwd f{n, nullptr, B, h, w, Arena{}, n.precision == MOE_PREC_FP16X3, n.precision == MOE_PREC_DEBUG_DIRECT};
+    run_forward(n, f, nullptr, MOE_F32, 0, 0, 0, nullptr, nullptr, MOE_F32, nullptr);
+    return f.ar.off + 4096;
+}
+
+int forward_dev(moe_net& n, const void* x, int x_dtype, int B, int h, int w, long long sB, long long sH, long long sW,
+                const long long* x_off_dev, void* y, int y_dtype, const long long* y_off_dev, hipStream_t s)
+{
+    if (!n.finalized) return fail(MOE_ESTATE, "moe_net_forward: net is not finalized (load_state_dict + to(device) first)");
+    if (B < 1 || h < 1 || w < 1) return fail(MOE_EINVAL, "moe_net_forward: bad shape B=%d h=%d w=%d", B, h, w);
+    if ((x_dtype != MOE_F32 && x_dtype != MOE_F16) || (y_dtype != MOE_F32 && y_dtype != MOE_F16))
+        return fail(MOE_EINVAL, "moe_net_forward: x/y dtype must be MOE_F32 or MOE_F16");
+    int cur = -1;
+    HIP_TRY(hipGetDevice(&cur));
+    if (cur != n.device) HIP_TRY(hipSetDevice(n.device));
+    const size_t need = workspace_need(n, B, h, w);
+    if (need > n.ws_bytes) {
+        if (n.ws) { HIP_TRY(hipStreamSynchronize(s)); HIP_TRY(hipFree(n.ws)); n.ws = nullptr; n.ws_bytes = 0; }
+        hipError_t e = hipMalloc((void**)&n.ws, need);
+        if (e != hipSuccess) { (void)hipGetLastError(); return fail(MOE_ENOMEM, "workspace of %zu bytes for %d planes of %dx%d does not fit", need, B, h, w); }
+        n.ws_bytes = need;
+    }
+    Fwd f{n, s, B, h, w, Arena{n.ws, 0}, n.precision == MOE_PREC_FP16X3, n.precision == MOE_PREC_DEBUG_DIRECT};
+    int rc = run_forward(n, f, x, x_dtype, sB, sH, sW, x_off_dev, y, y_dtype, y_off_dev);
+    if (rc) return rc;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MOE_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+    return MOE_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================
+// plan device cache + stitch + run
+// =====================================================================================================
+static int plan_device_tables(const Plan& p, int device, int C, int64_t sC, int64_t sH, int64_t sW)
+{
+    PlanDeviceCache& d = p.dev;
+    if (d.blob && d.device == device && d.C == C && d.sC == sC && d.sH == sH && d.sW == sW) return MOE_OK;
+    if (d.blob) { (void)hipFree(d.blob); d.blob = nullptr; }
+    const size_t nt = p.tiles.size();
+    std::vector<long long> xo(nt * C), yo(nt * C);
+    size_t slot = 0;
+    for (const auto& g : p.groups)
+        for (int k : g.tiles) {
+            const TileRect& t = p.tiles[k];
+            const long long plane = (long long)(g.th * p.sc) * (g.tw * p.sc);
+            for (int c = 0; c < C; ++c) {
+                xo[slot * C + c] = (long long)c * sC + (long long)t.top * sH + (long long)t.left * sW;
+                yo[slot * C + c] = p.tile_off[k] / p.C * C + (long long)c * plane;
+            }
+            ++slot;
+        }
+    // tile_off scaled to C planes (C may differ from the planning shape's channel count, e.g. alpha stripped)
+    std::vector<long long> toff(nt);
+    for (size_t k = 0; k < nt; ++k) toff[k] = p.tile_off[k] / p.C * C;
+    std::vector<char> host;
+    auto put = [&](const void* src, size_t bytes) { const size_t a = (host.size() + 255) & ~(size_t)255; host.resize(a + bytes); memcpy(host.data() + a, src, bytes); return a; };
+    const size_t o_x = put(xo.data(), xo.size() * 8), o_y = put(yo.data(), yo.size() * 8), o_t = put(toff.data(), toff.size() * 8);
+    const size_t o_rf = put(p.row_first.data(), p.row_first.size() * 4), o_rc = put(p.row_cnt.data(), p.row_cnt.size() * 4);
+    const size_t o_cf = put(p.col_first.data(), p.col_first.size() * 4), o_cc = put(p.col_cnt.data(), p.col_cnt.size() * 4);
+    const size_t o_rt = put(p.row_tab.data(), p.row_tab.size() * 4), o_ct = put(p.col_tab.data(), p.col_tab.size() * 4);
+    const float zero = 0.f;
+    const size_t o_rp = put(p.ramp.empty() ? &zero : p.ramp.data(), std::max<size_t>(4, p.ramp.size() * 4));
+    HIP_TRY(hipMalloc(&d.blob, host.size()));
+    HIP_TRY(hipMemcpy(d.blob, host.data(), host.size(), hipMemcpyHostToDevice));
+    char* b = (char*)d.blob;
+    d.x_off = (long long*)(b + o_x); d.y_off = (long long*)(b + o_y); d.tile_off = (long long*)(b + o_t);
+    d.row_first = (int*)(b + o_rf); d.row_cnt = (int*)(b + o_rc); d.col_first = (int*)(b + o_cf); d.col_cnt = (int*)(b + o_cc);
+    d.row_tab = (int*)(b + o_rt); d.col_tab = (int*)(b + o_ct); d.ramp = (float*)(b + o_rp);
+    d.device = device; d.C = C; d.sC = sC; d.sH = sH; d.sW = sW;
+    return MOE_OK;
+}
+
+static void fill_stitch(const Plan& p, StitchArgs& a, const float* tiles, const long long* tile_off, int C, void* out, int out_dtype)
+{
+    const PlanDeviceCache& d = p.dev;
+    a.tiles = tiles; a.tile_off = tile_off;
+    a.row_first = d.row_first; a.row_cnt = d.row_cnt; a.col_first = d.col_first; a.col_cnt = d.col_cnt;
+    a.row_tab = d.row_tab; a.col_tab = d.col_tab; a.ramp = d.ramp;
+    a.out = out; a.out_dtype = out_dtype; a.C = C; a.out_h = p.out_h; a.out_w = p.out_w; a.step_w = p.aw.step;
+}
+
+// =====================================================================================================
+// extern "C"
+// =====================================================================================================
+struct moe_plan { Plan p; };
+
+extern "C" {
+
+const char* moe_last_error(void) { return g_err.c_str(); }
+int moe_abi_version(void) { return MOE_ABI_VERSION; }
+int moe_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int moe_net_create(int arch, int scale, moe_net** out)
+{
+    if (!out) return fail(MOE_EINVAL, "moe_net_create: out is NULL");
+    auto n = std::make_unique<moe_net>();
+    n->arch = arch;
+    switch (arch) {
+        case MOE_ARCH_NET2X: n->scale = 2; n->stages = 1; n->r = 2; break;
+        case MOE_ARCH_NET3X: n->scale = 3; n->stages = 1; n->r = 3; break;
+        case MOE_ARCH_NET4X: n->scale = 4; n->stages = 2; n->r = 2; break;
+        case MOE_ARCH_NETDN: n->scale = 1; n->stages = 0; n->C = 48; break;
+        case MOE_ARCH_SEDN: n->scale = 1; n->stages = 0; break;
+        case MOE_ARCH_LITE:
+            if (scale != 2 && scale != 4 && scale != 8) return fail(MOE_EINVAL, "MoeNet_lite2.Net: upscale must be 2, 4 or 8 (got %d)", scale);
+            n->scale = scale; n->r = 2; n->C = 48;
+            n->stages = scale == 2 ? 1 : (scale == 4 ? 2 : 3);
+            break;
+        default: return fail(MOE_EINVAL, "moe_net_create: unknown architecture %d", arch);
+    }
+    if (arch != MOE_ARCH_LITE && scale != 0 && scale != n->scale)
+        return fail(MOE_EINVAL, "moe_net_create: architecture %d has scale %d, not %d", arch, n->scale, scale);
+    declare_params(*n);
+    *out = n.release();
+    return MOE_OK;
+}
+
+void moe_net_destroy(moe_net* n)
+{
+    if (!n) return;
+    if (n->blob) (void)hipFree(n->blob);
+    if (n->ws) (void)hipFree(n->ws);
+    for (auto& t : n->taps) if (t.second.dev) (void)hipFree(t.second.dev);
+    delete n;
+}
+
+int moe_net_scale(const moe_net* n) { return n ? n->scale : 0; }
+int moe_net_num_params(const moe_net* n) { return n ? (int)n->params.size() : 0; }
+
+int moe_net_param_info(const moe_net* n, int i, const char** name, int64_t shape[4], int* ndim)
+{
+    if (!n || i < 0 || i >= (int)n->params.size()) return fail(MOE_EINVAL, "moe_net_param_info: index out of range");
+    const Param& p = n->params[i];
+    if (name) *name = p.name.c_str();
+    if (ndim) *ndim = (int)p.shape.size();
+    if (shape) for (size_t d = 0; d < p.shape.size() && d < 4; ++d) shape[d] = p.shape[d];
+    return MOE_OK;
+}
+
+int moe_net_set_param(moe_net* n, const char* name, const float* data, const int64_t* shape, int ndim)
+{
+    if (!n || !name || !data) return fail(MOE_EINVAL, "moe_net_set_param: NULL argument");
+    auto it = n->index.find(name);
+    if (it == n->index.end()) return fail(MOE_EINVAL, "Unexpected key(s) in state_dict: \"%s\"", name);
+    Param& p = n->params[it->second];
+    bool same = (int)p.shape.size() == ndim;
+    for (int d = 0; same && d < ndim; ++d) same = p.shape[d] == shape[d];
+    if (!same) {
+        std::string got, want;
+        for (int d = 0; d < ndim; ++d) got += (d ? ", " : "") + std::to_string((long long)shape[d]);
+        for (size_t d = 0; d < p.shape.size(); ++d) want += (d ? ", " : "") + std::to_string((long long)p.shape[d]);
+        return fail(MOE_EINVAL, "size mismatch for %s: copying a param with shape (%s), the shape in current model is (%s)", name, got.c_str(), want.c_str());
+    }
+    p.data.assign(data, data + p.numel());
+    p.set = true;
+    n->finalized = false;
+    return MOE_OK;
+}
+
+int moe_net_finalize(moe_net* n, int device, int precision)
+{
+    if (!n) return fail(MOE_EINVAL, "moe_net_finalize: NULL net");
+    if (precision != MOE_PREC_FP16 && precision != MOE_PREC_FP16X3 && precision != MOE_PREC_DEBUG_DIRECT)
+        return fail(MOE_EINVAL, "moe_net_finalize: unknown precision %d", precision);
+    std::string missing;
+    for (const auto& p : n->params) if (!p.set) missing += (missing.empty() ? "\"" : ", \"") + p.name + "\"";
+    if (!missing.empty()) return fail(MOE_ESTATE, "Missing key(s) in state_dict: %s", missing.c_str());
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt < 1) { (void)hipGetLastError(); return fail(MOE_EHIP, "no HIP device available (this engine has no CPU path)"); }
+    if (device < 0 || device >= cnt) return fail(MOE_EINVAL, "device %d out of range (%d visible)", device, cnt);
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(conv_mfma_init());
+    n->max_groups = conv_mfma_max_groups();
+    if (const char* e = getenv("MOE_MAX_GROUPS")) { const int v = atoi(e); if (v > 0) n->max_groups = v; }
+    n->device = device;
+    n->precision = precision;
+    int rc = build_device_weights(*n, precision);
+    if (rc) return rc;
+    n->finalized = true;
+    return MOE_OK;
+}
+
+int64_t moe_net_workspace_bytes(const moe_net* n, int B, int h, int w)
+{
+    if (!n || B < 1 || h < 1 || w < 1) return fail(MOE_EINVAL, "moe_net_workspace_bytes: bad argument");
+    if (!n->finalized) return fail(MOE_ESTATE, "moe_net_workspace_bytes: net is not finalized");
+    return (int64_t)workspace_need(*const_cast<moe_net*>(n), B, h, w);
+}
+
+int moe_net_forward(moe_net* n, const void* x, int x_dtype, int B, int h, int w, int64_t sB, int64_t sH, int64_t sW,
+                    const int64_t* x_off, void* y, int y_dtype, const int64_t* y_off, void* stream)
+{
+    if (!n || !x || !y) return fail(MOE_EINVAL, "moe_net_forward: NULL argument");
+    hipStream_t s = (hipStream_t)stream;
+    long long* xo = nullptr;
+    long long* yo = nullptr;
+    void* tmp = nullptr;
+    if (x_off || y_off) {   // slow path: blocking upload of the offset tables
+        HIP_TRY(hipSetDevice(n->device >= 0 ? n->device : 0));
+        HIP_TRY(hipMalloc(&tmp, (size_t)B * 16));
+        if (x_off) { xo = (long long*)tmp; HIP_TRY(hipMemcpy(xo, x_off, (size_t)B * 8, hipMemcpyHostToDevice)); }
+        if (y_off) { yo = (long long*)tmp + B; HIP_TRY(hipMemcpy(yo, y_off, (size_t)B * 8, hipMemcpyHostToDevice)); }
+    }
+    int rc = forward_dev(*n, x, x_dtype, B, h, w, sB, sH, sW, xo, y, y_dtype, yo, s);
+    if (tmp) { (void)hipStreamSynchronize(s); (void)hipFree(tmp); }
+    return rc;
+}
+
+int moe_net_set_debug(moe_net* n, int enable)
+{
+    if (!n) return fail(MOE_EINVAL, "moe_net_set_debug: NULL net");
+    n->debug = enable != 0;
+    return MOE_OK;
+}
+
+int64_t moe_net_debug_tap(moe_net* n, const char* tap, float* host, int64_t capacity, int64_t shape[4], void* stream)
+{
+    if (!n || !tap) return fail(MOE_EINVAL, "moe_net_debug_tap: NULL argument");
+    auto it = n->taps.find(tap);
+    if (it == n->taps.end() || !it->second.dev) return fail(MOE_EINVAL, "no tap named \"%s\" (enable moe_net_set_debug before the forward)", tap);
+    const auto& t = it->second;
+    const int64_t nel = t.shape[0] * t.shape[1] * t.shape[2] * t.shape[3];
+    if (shape) for (int d = 0; d < 4; ++d) shape[d] = t.shape[d];
+    if (!host) return nel;
+    if (capacity < nel) return fail(MOE_EINVAL, "moe_net_debug_tap: capacity %lld < %lld", (long long)capacity, (long long)nel);
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(hipMemcpy(host, t.dev, (size_t)nel * 4, hipMemcpyDeviceToHost));
+    return nel;
+}
+
+// ---- planner ------------------------------------------------------------------------------------------
+int moe_plan_create(const int64_t shape[3], double ram, double ram_coef, int pad, int scale, int align, int cropsize, moe_plan** out)
+{
+    if (!shape || !out) return fail(MOE_EINVAL, "moe_plan_create: NULL argument");
+    auto p = std::make_unique<moe_plan>();
+    std::string err;
+    int rc = build_plan(p->p, shape, ram, ram_coef, pad, scale, align, cropsize, err);
+    if (rc) return fail(rc, "%s", err.c_str());
+    *out = p.release();
+    return MOE_OK;
+}
+
+void moe_plan_destroy(moe_plan* p)
+{
+    if (!p) return;
+    if (p->p.dev.blob) (void)hipFree(p->p.dev.blob);
+    if (p->p.dev.pool) (void)hipFree(p->p.dev.pool);
+    delete p;
+}
+
+int moe_plan_info(const moe_plan* p, int64_t info[12])
+{
+    if (!p || !info) return fail(MOE_EINVAL, "moe_plan_info: NULL argument");
+    const Plan& q = p->p;
+    const int64_t v[12] = {(int64_t)q.tiles.size(), q.ah.step, q.aw.step, q.out_h, q.out_w, q.pad_h_to, q.pad_w_to, q.pad_sc,
+                           q.tile_h, q.tile_w, q.ah.clip, q.aw.clip};
+    memcpy(info, v, sizeof v);
+    return MOE_OK;
+}
+
+int moe_plan_tiles(const moe_plan* p, int32_t* tiles)
+{
+    if (!p || !tiles) return fail(MOE_EINVAL, "moe_plan_tiles: NULL argument");
+    for (size_t k = 0; k < p->p.tiles.size(); ++k) {
+        const TileRect& t = p->p.tiles[k];
+        const int32_t v[8] = {t.top, t.bottom, t.left, t.right, t.top_t, t.left_t, t.bsc, t.rsc};
+        memcpy(tiles + k * 8, v, sizeof v);
+    }
+    return MOE_OK;
+}
+
+int moe_plan_ramp(const moe_plan* p, float* ramp)
+{
+    if (!p || !ramp) return fail(MOE_EINVAL, "moe_plan_ramp: NULL argument");
+    memcpy(ramp, p->p.ramp.data(), p->p.ramp.size() * 4);
+    return MOE_OK;
+}
+
+// ---- stitch / run ------------------------------------------------------------------------------------
+int moe_stitch(const moe_plan* p, int device, const float* tiles_dev, const int64_t* tile_off, int C, void* out, int out_dtype, void* stream)
+{
+    if (!p || !tiles_dev || !tile_off || !out || C < 1) return fail(MOE_EINVAL, "moe_stitch: bad argument");
+    HIP_TRY(hipSetDevice(device));
+    int rc = plan_device_tables(p->p, device, C, p->p.dev.sC, p->p.dev.sH, p->p.dev.sW);
+    if (rc) return rc;
+    long long* toff = nullptr;
+    HIP_TRY(hipMalloc((void**)&toff, p->p.tiles.size() * 8));
+    HIP_TRY(hipMemcpy(toff, tile_off, p->p.tiles.size() * 8, hipMemcpyHostToDevice));
+    StitchArgs a{};
+    fill_stitch(p->p, a, tiles_dev, toff, C, out, out_dtype);
+    launch_stitch(a, (hipStream_t)stream);
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(hipFree(toff));
+    return MOE_OK;
+}
+
+int moe_run_plan(moe_net* n, const moe_plan* pl, const void* img, int img_dtype, int64_t sC, int64_t sH, int64_t sW,
+                 void* out, int out_dtype, int max_tiles, void* stream)
+{
+    if (!n || !pl || !img || !out) return fail(MOE_EINVAL, "moe_run_plan: NULL argument");
+    if (!n->finalized) return fail(MOE_ESTATE, "moe_run_plan: net is not finalized");
+    const Plan& p = pl->p;
+    if (p.sc != n->scale) return fail(MOE_EINVAL, "moe_run_plan: plan scale %d != net scale %d", p.sc, n->scale);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(n->device));
+    const int C = p.C;
+    int rc = plan_device_tables(p, n->device, C, sC, sH, sW);
+    if (rc) return rc;
+    PlanDeviceCache& d = p.dev;
+    const size_t pool_need = p.pool_elems_per_plane_set;
+    if (pool_need > d.pool_elems) {
+        if (d.pool) { HIP_TRY(hipStreamSynchronize(s)); HIP_TRY(hipFree(d.pool)); d.pool = nullptr; d.pool_elems = 0; }
+        if (hipMalloc((void**)&d.pool, pool_need * 4) != hipSuccess) { (void)hipGetLastError(); return fail(MOE_ENOMEM, "tile pool of %zu bytes does not fit", pool_need * 4); }
+        d.pool_elems = pool_need;
+    }
+    if (max_tiles <= 0) {
+        max_tiles = 4;
+        if (const char* e = getenv("MOE_TILES_PER_BATCH")) { const int v = atoi(e); if (v > 0) max_tiles = v; }
+    }
+    for (const auto& g : p.groups) {
+        const int nt = (int)g.tiles.size();
+        // bigger batches for small tiles: keep roughly max_tiles * 256^2 pixels per launch
+        long long px = (long long)g.th * g.tw;
+        int per = (int)std::max<long long>(1, std::min<long long>(nt, (long long)max_tiles * 65536 / std::max<long long>(px, 1)));
+        for (int t0 = 0; t0 < nt; t0 += per) {
+            const int cnt = std::min(per, nt - t0);
+            const long long slot = (long long)(g.first_slot + t0) * C;
+            rc = forward_dev(*n, img, img_dtype, cnt * C, g.th, g.tw, 0, sH, sW, d.x_off + slot, d.pool, MOE_F32, d.y_off + slot, s);
+            if (rc) return rc;
+        }
+    }
+    StitchArgs a{};
+    fill_stitch(p, a, d.pool, d.tile_off, C, out, out_dtype);
+    launch_stitch(a, s);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MOE_EHIP, "stitch launch failed: %s", hipGetErrorString(e));
+    return MOE_OK;
+}
+
+// ---- image edges ---------------------------------------------------------------------------------------
+int moe_to_float(const void* src, int src_dtype, int bits, int H, int W, int C, void* dst, int dst_dtype, int device, void* stream)
+{
+    if (!src || !dst || H < 1 || W < 1 || C < 1) return fail(MOE_EINVAL, "moe_to_float: bad argument");
+    if ((src_dtype != MOE_U8 && src_dtype != MOE_U16) || (dst_dtype != MOE_F32 && dst_dtype != MOE_F16)) return fail(MOE_EINVAL, "moe_to_float: bad dtype");
+    HIP_TRY(hipSetDevice(device));
+    if (src_dtype == MOE_U8) launch_to_float(src, src_dtype, 255.f, true, H, W, C, dst, dst_dtype, (hipStream_t)stream);
+    else launch_to_float(src, src_dtype, 1.f / (float)(1 << bits), false, H, W, C, dst, dst_dtype, (hipStream_t)stream);
+    return MOE_OK;
+}
+
+int moe_to_output(const void* src, int src_dtype, int H, int W, int C, int bits, void* dst, int dst_dtype, int device, void* stream)
+{
+    if (!src || !dst || H < 1 || W < 1 || C < 1 || bits < 1 || bits > 16) return fail(MOE_EINVAL, "moe_to_output: bad argument");
+    if ((dst_dtype != MOE_U8 && dst_dtype != MOE_U16) || (src_dtype != MOE_F32 && src_dtype != MOE_F16)) return fail(MOE_EINVAL, "moe_to_output: bad dtype");
+    if (dst_dtype == MOE_U8 && bits > 8) return fail(MOE_EINVAL, "moe_to_output: %d bits do not fit MOE_U8", bits);
+    HIP_TRY(hipSetDevice(device));
+    launch_to_output(src, src_dtype, H, W, C, (float)(1 << bits), dst, dst_dtype, (hipStream_t)stream);
+    return MOE_OK;
+}
+
+}  // extern "C"

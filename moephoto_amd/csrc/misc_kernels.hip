@@ -1,0 +1,454 @@
+// misc_kernels.hip -- the HBM-bound kernels around the MFMA convolution: 1->C stem, C->1 tail (+branch sum),
+// squeeze-excite pooling / gates, tile stitch, and the uint8/uint16 <-> float image edges.
+// All of them stream NHWC fp16 activations with 16-byte accesses (8 lanes = one 128-B pixel line).
+#include "common.h"
+#include "../../include/moephoto_amd.h"
+
+namespace {
+
+__device__ __forceinline__ float prelu(float v, float slope) { return v >= 0.f ? v : v * slope; }
+
+template <typename T>
+__device__ __forceinline__ float ld1(const void* p, long long i) { return (float)((const T*)p)[i]; }
+
+// ---------------------------------------------------------------------------------------------------
+// Stem: PReLU(conv 1->64) (models.py:112,117 conv_input+relu; SEDN :219,223; lite 1x1 MoeNet_lite2.py:28,40).
+// fp32 weights and arithmetic (the stem's weights are the single most sensitive ones to fp16 rounding).
+// One thread = one pixel x 8 channels -> one 16-byte store; 8 consecutive threads write one 128-B line.
+// ---------------------------------------------------------------------------------------------------
+template <typename TIN, int TAPS>
+__global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
+{
+    __shared__ float w[TAPS * 64];
+    for (int i = threadIdx.x; i < TAPS * 64; i += 256) w[i] = a.w[i];
+    __syncthreads();
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long npix = (long long)a.B * a.H * a.W;
+    const long long p = idx >> 3;
+    if (p >= npix) return;
+    const int cg = (int)(idx & 7) * 8;
+    const int x = (int)(p % a.W);
+    const long long t = p / a.W;
+    const int y = (int)(t % a.H);
+    const int b = (int)(t / a.H);
+    const TIN* xp = (const TIN*)a.x + (a.x_off ? a.x_off[b] : (long long)b * a.sB);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    constexpr int KD = (TAPS == 9) ? 3 : 1, PAD = (TAPS == 9) ? 1 : 0;
+#pragma unroll
+    for (int dy = 0; dy < KD; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < KD; ++dx) {
+            const int yy = y + dy - PAD, xx = x + dx - PAD;
+            float v = 0.f;
+            if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) v = (float)xp[yy * a.sH + xx * a.sW];
+            const float* wt = w + (dy * KD + dx) * 64 + cg;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v * wt[e];
+        }
+    half8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)prelu(acc[e], a.slope);
+    *(half8_t*)(a.out + p * 64 + cg) = o;
+    if (a.out_lo) {
+        half8_t l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) l[e] = (half_t)((prelu(acc[e], a.slope) - (float)o[e]) * 2048.f);
+        *(half8_t*)(a.out_lo + p * 64 + cg) = l;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Tail: y = conv C->1 (in0, w0) [+ conv C->1 (in1, w1)] [+ skip]   (models.py:129-131,149-153 last Conv3x3(64,1)
+// of u / convt_R1 and their sum in multiConvt :41-43; NetDN :161; SEDN :220,224; lite MoeNet_lite2.py:33-34,49-51).
+// Block = 32-px x 8-row strip; thread = (pixel column, 8-channel group).  Each thread walks the 10 input rows of
+// its column once (3 dx each), feeding every loaded 16 B into the up-to-3 output rows it contributes to
+// (v_dot2_f32_f16, fp32 accumulate); the 8 channel groups are summed with 3 xor-shuffles.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dot8(half8_t v, half8_t w, float acc)
+{
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        half2_t a = {v[2 * e], v[2 * e + 1]}, b = {w[2 * e], w[2 * e + 1]};
+        acc = __builtin_amdgcn_fdot2(a, b, acc, false);
+    }
+    return acc;
+}
+
+template <int TAPS>
+__global__ __launch_bounds__(256) void tail_kernel(TailArgs a)
+{
+    constexpr int KD = (TAPS == 9) ? 3 : 1, PAD = (TAPS == 9) ? 1 : 0;
+    const int cgi = threadIdx.x & 7, pc = threadIdx.x >> 3;
+    const int nbx = (a.W + 31) / 32, nby = (a.H + 7) / 8;
+    int blk = blockIdx.x;
+    const int bx = blk % nbx; blk /= nbx;
+    const int by = blk % nby;
+    const int b = blk / nby;
+    const int x = bx * 32 + pc, y0 = by * 8;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 1
+    for (int which = 0; which < 2; ++which) {
+        const half_t* in = which ? a.in1 : a.in0;
+        if (!in) continue;
+        const half_t* wsrc = (which ? a.w1 : a.w0) + cgi * 8;
+        half8_t w[TAPS];
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) w[t] = *(const half8_t*)(wsrc + t * 64);
+        const half_t* wlo_src = (which ? a.w1_lo : a.w0_lo);
+        const half_t* in_lo = which ? a.in1_lo : a.in0_lo;
+#pragma unroll
+        for (int r = 0; r < 8 + 2 * PAD; ++r) {
+            const int yy = y0 + r - PAD;
+            const bool rok = (yy >= 0) && (yy < a.H);
+#pragma unroll
+            for (int dx = 0; dx < KD; ++dx) {
+                const int xx = x + dx - PAD;
+                const bool ok = rok && xx >= 0 && xx < a.W;
+                half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+                const long long off = ((long long)(b * a.H + yy) * a.W + xx) * 64 + cgi * 8;
+                if (ok) v = *(const half8_t*)(in + off);
+#pragma unroll
+                for (int dy = 0; dy < KD; ++dy) {
+                    const int o = r - dy;
+                    if (o >= 0 && o < 8) acc[o] = dot8(v, w[dy * KD + dx], acc[o]);
+                }
+                if (in_lo) {   // FP16X3: (a_hi + a_lo/2048) * (w_hi + w_lo/2048), cross terms kept
+                    half8_t vl = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (ok) vl = *(const half8_t*)(in_lo + off);
+#pragma unroll
+                    for (int dy = 0; dy < KD; ++dy) {
+                        const int o = r - dy;
+                        if (o >= 0 && o < 8) {
+                            const half8_t wl = *(const half8_t*)(wlo_src + cgi * 8 + (dy * KD + dx) * 64);
+                            float c = dot8(vl, w[dy * KD + dx], 0.f);
+                            c = dot8(v, wl, c);
+                            acc[o] += c * 0.00048828125f;
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        float v = acc[o];
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        acc[o] = v;
+    }
+    if (cgi == 0 && x < a.W) {
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            const int y = y0 + o;
+            if (y >= a.H) break;
+            float v = acc[o];
+            if (a.skip) {
+                const long long so = (a.skip_off ? a.skip_off[b] : (long long)b * a.skip_sB) + y * a.skip_sH + x * a.skip_sW;
+                v += (a.skip_dtype == MOE_F16) ? ld1<half_t>(a.skip, so) : ld1<float>(a.skip, so);
+            }
+            const long long yo = (a.y_off ? a.y_off[b] : (long long)b * a.H * a.W) + (long long)y * a.W + x;
+            if (a.y_dtype == MOE_F16) ((half_t*)a.y)[yo] = (half_t)v;
+            else ((float*)a.y)[yo] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Global average pool partial sums (AdaptiveAvgPool2d(1): models.py:190,274): in [B][HW][C] -> [B][nslab][C].
+// Deterministic two-stage reduction (the second stage lives in the gate kernels).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pool_partial_kernel(const half_t* in, const half_t* in_lo, float* partial, long long HW, int C, int nslab)
+{
+    __shared__ float red[256 * 8];
+    const int b = blockIdx.y, slab = blockIdx.x;
+    const int ngrp = C / 8;                    // 8 or 32 channel groups
+    const int cg = threadIdx.x % ngrp, pl = threadIdx.x / ngrp, npl = 256 / ngrp;
+    const long long per = (HW + nslab - 1) / nslab;
+    const long long p0 = slab * per, p1 = (p0 + per < HW) ? p0 + per : HW;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (long long p = p0 + pl; p < p1; p += npl) {
+        const long long off = ((long long)b * HW + p) * C + cg * 8;
+        const half8_t v = *(const half8_t*)(in + off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+        if (in_lo) {
+            const half8_t l = *(const half8_t*)(in_lo + off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (float)l[e] * 0.00048828125f;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = acc[e];
+    __syncthreads();
+    if (pl == 0) {
+        for (int k = 1; k < npl; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += red[(k * ngrp + cg) * 8 + e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) partial[((long long)b * nslab + slab) * C + cg * 8 + e] = acc[e];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// SEDN squeeze-excite gate (models.py:198-208): g = sigmoid(W_up * lrelu(W_down * mean)); the gate multiplies the
+// 256 input channels of the following 1x1 `trans` conv, so it is folded into a per-plane copy of trans's packed
+// weights: W'[b][o][c] = W[o][c] * g[b][c]  (fp32 product, then fp16 -- the activations themselves stay untouched).
+// One block per plane.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sedn_se_kernel(SednSeArgs a)
+{
+    __shared__ float mean[256];
+    __shared__ float hid[16];
+    __shared__ float gate[256];
+    const int b = blockIdx.x, t = threadIdx.x;
+    float s = 0.f;
+    for (int k = 0; k < a.nslab; ++k) s += a.partial[((long long)b * a.nslab + k) * 256 + t];
+    mean[t] = s / (float)a.HW;
+    __syncthreads();
+    if (t < 16) {
+        float h = 0.f;
+        for (int c = 0; c < 256; ++c) h += a.w_down[t * 256 + c] * mean[c];
+        hid[t] = prelu(h, 0.2f);
+    }
+    __syncthreads();
+    {
+        float u = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) u += a.w_up[t * 16 + k] * hid[k];
+        gate[t] = 1.f / (1.f + __expf(-u));
+    }
+    __syncthreads();
+    if (a.nfrag < 0) {   // MOE_PREC_DEBUG_DIRECT: plain fp32 [cout][256] weights, -nfrag elements
+        const int total = -a.nfrag;
+        float* o = (float*)a.trans_out;
+        for (int i = t; i < total; i += 256) o[(long long)b * total + i] = a.trans_pk32[i] * gate[i & 255];
+        return;
+    }
+    // packed fragment element idx -> input channel:  frag f = (seg*4 + ks)*2 + nblk, lane l, e
+    const int total = a.nfrag * 512;
+    for (int i = t; i < total; i += 256) {
+        const int e = i & 7, l = (i >> 3) & 63, f = i >> 9;
+        const int ks = (f >> 1) & 3, seg = f >> 3;
+        const int cin = seg * 64 + ks * 16 + 8 * (l >> 5) + e;
+        const float v = a.trans_pk32[i] * gate[cin];
+        const half_t hv = (half_t)v;
+        a.trans_out[(long long)b * total + i] = hv;
+        if (a.trans_out_lo) a.trans_out_lo[(long long)b * total + i] = (half_t)((v - (float)hv) * 2048.f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// lite FRM gate (models.py:270-287) + LB residual (MoeNet_lite2.py:16-20): out = t * gate + x
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void frm_gate_kernel(FrmArgs a)
+{
+    __shared__ float mean[64];
+    __shared__ float hid[3];
+    const int b = blockIdx.x, t = threadIdx.x;
+    float s = 0.f;
+    for (int k = 0; k < a.nslab; ++k) s += a.partial[((long long)b * a.nslab + k) * 64 + t];
+    mean[t] = s / (float)a.HW;
+    __syncthreads();
+    if (t < 3) {
+        float h = a.b0[t];
+        for (int c = 0; c < 64; ++c) h += a.w0[t * 64 + c] * mean[c];
+        hid[t] = h > 0.f ? h : 0.f;
+    }
+    __syncthreads();
+    float u = a.b2[t];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) u += a.w2[t * 3 + k] * hid[k];
+    a.gate[b * 64 + t] = 1.f / (1.f + __expf(-u));
+}
+
+__global__ __launch_bounds__(256) void frm_apply_kernel(FrmArgs a)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // one 16-B group each
+    const long long total = (long long)a.B * a.HW * 8;
+    if (idx >= total) return;
+    const int cg = (int)(idx & 7) * 8;
+    const int b = (int)((idx >> 3) / a.HW);
+    const float* g = a.gate + b * 64 + cg;
+    const half8_t tv = *(const half8_t*)(a.t + idx * 8);
+    const half8_t xv = *(const half8_t*)(a.x + idx * 8);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)tv[e];
+    if (a.t_lo) {
+        const half8_t tl = *(const half8_t*)(a.t_lo + idx * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)tl[e] * 0.00048828125f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = v[e] * g[e] + (float)xv[e];
+    if (a.x_lo) {
+        const half8_t xl = *(const half8_t*)(a.x_lo + idx * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)xl[e] * 0.00048828125f;
+    }
+    half8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+    *(half8_t*)(a.out + idx * 8) = o;
+    if (a.out_lo) {
+        half8_t l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) l[e] = (half_t)((v[e] - (float)o[e]) * 2048.f);
+        *(half8_t*)(a.out_lo + idx * 8) = l;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Stitch: per-pixel fold of doCrop's sequential blend (imageProcess.py:120-131,167-170).  Every HR pixel visits,
+// in raster tile order, the tiles whose written region covers it and applies
+//     v1 = ex + wH*(r-ex)  (row inside the tile's blend band, else r);   v = ex + wW*(v1-ex)  (column likewise)
+// with the same fp32 operation order as the reference, so the result is bit-identical to the sequential loop.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stitch_kernel(StitchArgs a)
+{
+    const int X = blockIdx.x * 256 + threadIdx.x;
+    const int Y = blockIdx.y, c = blockIdx.z;
+    if (X >= a.out_w) return;
+    const int i0 = a.row_first[Y], ni = a.row_cnt[Y];
+    const int j0 = a.col_first[X], nj = a.col_cnt[X];
+    float cur = 0.f;
+    for (int i = i0; i < i0 + ni; ++i) {
+        const int fy = a.row_tab[i * 4 + 0], sy = a.row_tab[i * 4 + 1], oy = a.row_tab[i * 4 + 2], eh = a.row_tab[i * 4 + 3];
+        for (int j = j0; j < j0 + nj; ++j) {
+            const int fx = a.col_tab[j * 4 + 0], sx = a.col_tab[j * 4 + 1], ox = a.col_tab[j * 4 + 2], ew = a.col_tab[j * 4 + 3];
+            const float r = a.tiles[a.tile_off[i * a.step_w + j] + ((long long)c * eh + (Y - oy)) * ew + (X - ox)];
+            float v1 = r;
+            if (Y < sy) v1 = cur + a.ramp[Y - fy] * (r - cur);
+            float v = v1;
+            if (X < sx) v = cur + a.ramp[X - fx] * (v1 - cur);
+            cur = v;
+        }
+    }
+    const long long o = ((long long)c * a.out_h + Y) * a.out_w + X;
+    if (a.out_dtype == MOE_F16) ((half_t*)a.out)[o] = (half_t)cur;
+    else ((float*)a.out)[o] = cur;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Image edges: toTorch (imageProcess.py:259-263) and toOutput (:245-257)
+// ---------------------------------------------------------------------------------------------------
+template <typename TS, typename TD>
+__global__ void to_float_kernel(const TS* src, TD* dst, int H, int W, int C, float d, bool divide)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n = (long long)H * W * C;
+    if (idx >= n) return;
+    const int c = (int)(idx % C);
+    const long long p = idx / C;
+    const float v = (float)src[idx];
+    dst[(long long)c * H * W + p] = (TD)(divide ? v / d : v * d);
+}
+
+template <typename TS, typename TD>
+__global__ void to_output_kernel(const TS* src, TD* dst, int H, int W, int C, float quant)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n = (long long)H * W * C;
+    if (idx >= n) return;
+    const int c = (int)(idx % C);
+    const long long p = idx / C;
+    // reference: image * quant, clamp_(0, quant-1), truncate
+    // (toFloat casts to fp32 first: imageProcess.py:238-243)
+    float v = (float)src[(long long)c * H * W + p] * quant;
+    v = fminf(fmaxf(v, 0.f), quant - 1.f);
+    if (!(v == v)) v = 0.f;
+    dst[idx] = (TD)(int)v;
+}
+
+__global__ void nhwc_to_nchw_kernel(const half_t* in, const half_t* in_lo, float* out, int B, int H, int W, int cs, int C)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n = (long long)B * C * H * W;
+    if (idx >= n) return;
+    const int x = (int)(idx % W);
+    long long t = idx / W;
+    const int y = (int)(t % H); t /= H;
+    const int c = (int)(t % C);
+    const int b = (int)(t / C);
+    const long long o = ((long long)(b * H + y) * W + x) * cs + c;
+    float v = (float)in[o];
+    if (in_lo) v += (float)in_lo[o] * 0.00048828125f;
+    out[idx] = v;
+}
+
+}  // namespace
+
+void launch_stem(const StemArgs& a, hipStream_t s)
+{
+    const long long n = (long long)a.B * a.H * a.W * 8;
+    const int blocks = (int)((n + 255) / 256);
+    if (a.taps == 9) {
+        if (a.x_dtype == MOE_F16) hipLaunchKernelGGL((stem_kernel<half_t, 9>), dim3(blocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((stem_kernel<float, 9>), dim3(blocks), dim3(256), 0, s, a);
+    } else {
+        if (a.x_dtype == MOE_F16) hipLaunchKernelGGL((stem_kernel<half_t, 1>), dim3(blocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((stem_kernel<float, 1>), dim3(blocks), dim3(256), 0, s, a);
+    }
+}
+
+void launch_tail(const TailArgs& a, hipStream_t s)
+{
+    const int blocks = ((a.W + 31) / 32) * ((a.H + 7) / 8) * a.B;
+    if (a.taps == 9) hipLaunchKernelGGL((tail_kernel<9>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((tail_kernel<1>), dim3(blocks), dim3(256), 0, s, a);
+}
+
+void launch_pool_partial(const half_t* in, const half_t* in_lo, float* partial, int B, long long HW, int C, int nslab, hipStream_t s)
+{
+    hipLaunchKernelGGL(pool_partial_kernel, dim3(nslab, B), dim3(256), 0, s, in, in_lo, partial, HW, C, nslab);
+}
+
+void launch_sedn_se(const SednSeArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(sedn_se_kernel, dim3(a.B), dim3(256), 0, s, a);
+}
+
+void launch_frm(const FrmArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(frm_gate_kernel, dim3(a.B), dim3(64), 0, s, a);
+    const long long total = (long long)a.B * a.HW * 8;
+    hipLaunchKernelGGL(frm_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+}
+
+void launch_stitch(const StitchArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(stitch_kernel, dim3((a.out_w + 255) / 256, a.out_h, a.C), dim3(256), 0, s, a);
+}
+
+void launch_to_float(const void* src, int src_dtype, float d, bool divide, int H, int W, int C, void* dst, int dst_dtype, hipStream_t s)
+{
+    const long long n = (long long)H * W * C;
+    const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+    if (src_dtype == MOE_U8) {
+        if (dst_dtype == MOE_F16) hipLaunchKernelGGL((to_float_kernel<uint8_t, half_t>), grid, blk, 0, s, (const uint8_t*)src, (half_t*)dst, H, W, C, d, divide);
+        else hipLaunchKernelGGL((to_float_kernel<uint8_t, float>), grid, blk, 0, s, (const uint8_t*)src, (float*)dst, H, W, C, d, divide);
+    } else {
+        if (dst_dtype == MOE_F16) hipLaunchKernelGGL((to_float_kernel<uint16_t, half_t>), grid, blk, 0, s, (const uint16_t*)src, (half_t*)dst, H, W, C, d, divide);
+        else hipLaunchKernelGGL((to_float_kernel<uint16_t, float>), grid, blk, 0, s, (const uint16_t*)src, (float*)dst, H, W, C, d, divide);
+    }
+}
+
+void launch_to_output(const void* src, int src_dtype, int H, int W, int C, float quant, void* dst, int dst_dtype, hipStream_t s)
+{
+    const long long n = (long long)H * W * C;
+    const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+    if (src_dtype == MOE_F16) {
+        if (dst_dtype == MOE_U8) hipLaunchKernelGGL((to_output_kernel<half_t, uint8_t>), grid, blk, 0, s, (const half_t*)src, (uint8_t*)dst, H, W, C, quant);
+        else hipLaunchKernelGGL((to_output_kernel<half_t, uint16_t>), grid, blk, 0, s, (const half_t*)src, (uint16_t*)dst, H, W, C, quant);
+    } else {
+        if (dst_dtype == MOE_U8) hipLaunchKernelGGL((to_output_kernel<float, uint8_t>), grid, blk, 0, s, (const float*)src, (uint8_t*)dst, H, W, C, quant);
+        else hipLaunchKernelGGL((to_output_kernel<float, uint16_t>), grid, blk, 0, s, (const float*)src, (uint16_t*)dst, H, W, C, quant);
+    }
+}
+
+void launch_nhwc_to_nchw_f32(const half_t* in, const half_t* in_lo, float* out, int B, int H, int W, int cs, int C, hipStream_t s)
+{
+    const long long n = (long long)B * C * H * W;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, in_lo, out, B, H, W, cs, C);
+}
