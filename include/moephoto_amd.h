@@ -117,7 +117,8 @@ int moe_plan_ramp(const moe_plan* plan, float* ramp);
 /* ---- device-side stitch / whole-image run ------------------------------------------------------ */
 /* Fold the per-tile results into the canvas exactly as doCrop's sequential blend does.
  * tiles_dev: device buffer holding every tile's result as C contiguous fp32 planes of
- * ((bottom-top)*scale) x ((right-left)*scale); tile k starts at element tile_off[k] (HOST array).
+ * ((bottom-top)*scale) x ((right-left)*scale); tile k starts at element tile_off[k] (HOST array; NULL = the
+ * default layout of moe_plan_tile_offsets).
  * out: (C, out_h, out_w) contiguous, dtype MOE_F32/MOE_F16. */
 int moe_stitch(const moe_plan* plan, int device, const float* tiles_dev, const int64_t* tile_off, int C,
                void* out, int out_dtype, void* stream);
@@ -126,6 +127,17 @@ int moe_stitch(const moe_plan* plan, int device, const float* tiles_dev, const i
  * max_tiles_per_batch <= 0 picks a default. */
 int moe_run_plan(moe_net* net, const moe_plan* plan, const void* img, int img_dtype, int64_t sC, int64_t sH, int64_t sW,
                  void* out, int out_dtype, int max_tiles_per_batch, void* stream);
+
+/* General form: `pool` (device, fp32, >= moe_plan_pool_elems) receives the raw per-tile results (NULL: internal);
+ * only tiles with raster index k % shard_count == shard_index are computed (tile-parallel sharding across GPUs:
+ * the ranks then exchange pool slices, see moephoto_amd/dist.py); do_stitch = 0 skips the final fold. */
+int moe_run_plan_ex(moe_net* net, const moe_plan* plan, const void* img, int img_dtype, int64_t sC, int64_t sH, int64_t sW,
+                    void* out, int out_dtype, int max_tiles_per_batch, float* pool, int shard_index, int shard_count,
+                    int do_stitch, void* stream);
+/* elements of the fp32 tile pool for C planes, and the element offset of every tile inside it (default layout:
+ * tile k = C contiguous planes of its HR extent, tiles in raster order) */
+int64_t moe_plan_pool_elems(const moe_plan* plan, int C);
+int moe_plan_tile_offsets(const moe_plan* plan, int C, int64_t* off);
 
 /* ---- image I/O edges ---------------------------------------------------------------------------- */
 /* src: H x W x C interleaved MOE_U8 (v/255) or MOE_U16 (v/2^bits); dst: C planes H x W, MOE_F32/MOE_F16 */

@@ -1,0 +1,97 @@
+"""ctypes binding of libmoephoto_amd.so (include/moephoto_amd.h).
+
+There is deliberately NO fallback: if the HIP library is missing or no device is visible the
+product path raises.  (The CPU oracle under oracle/ is test infrastructure and is never imported
+from here.)
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libmoephoto_amd.so')
+
+OK, EINVAL, ENOMEM, EHIP, ESTATE = 0, -1, -2, -3, -4
+ARCH_NET2X, ARCH_NET3X, ARCH_NET4X, ARCH_NETDN, ARCH_SEDN, ARCH_LITE = range(6)
+F32, F16, U8, U16 = range(4)
+PREC_FP16, PREC_FP16X3, PREC_DEBUG_DIRECT = range(3)
+PRECISIONS = {'fp16': PREC_FP16, 'fp16x3': PREC_FP16X3, 'debug_direct': PREC_DEBUG_DIRECT}
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the C-ABI library.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError('{} not found: build it with `python -m moephoto_amd.build` (hipcc, gfx950). '
+                          'moephoto_amd has no CPU path.'.format(LIB_PATH))
+    L = ctypes.CDLL(LIB_PATH)
+    c_int, c_i64, c_vp, c_dbl = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_double
+    P = ctypes.POINTER
+    sig = {
+        'moe_last_error': (ctypes.c_char_p, []),
+        'moe_abi_version': (c_int, []),
+        'moe_device_count': (c_int, []),
+        'moe_net_create': (c_int, [c_int, c_int, P(c_vp)]),
+        'moe_net_destroy': (None, [c_vp]),
+        'moe_net_scale': (c_int, [c_vp]),
+        'moe_net_num_params': (c_int, [c_vp]),
+        'moe_net_param_info': (c_int, [c_vp, c_int, P(ctypes.c_char_p), P(c_i64), P(c_int)]),
+        'moe_net_set_param': (c_int, [c_vp, ctypes.c_char_p, c_vp, P(c_i64), c_int]),
+        'moe_net_finalize': (c_int, [c_vp, c_int, c_int]),
+        'moe_net_workspace_bytes': (c_i64, [c_vp, c_int, c_int, c_int]),
+        'moe_net_forward': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_int, c_vp, c_vp]),
+        'moe_net_set_debug': (c_int, [c_vp, c_int]),
+        'moe_net_debug_tap': (c_i64, [c_vp, ctypes.c_char_p, c_vp, c_i64, P(c_i64), c_vp]),
+        'moe_plan_create': (c_int, [P(c_i64), c_dbl, c_dbl, c_int, c_int, c_int, c_int, P(c_vp)]),
+        'moe_plan_destroy': (None, [c_vp]),
+        'moe_plan_info': (c_int, [c_vp, P(c_i64)]),
+        'moe_plan_tiles': (c_int, [c_vp, P(ctypes.c_int32)]),
+        'moe_plan_ramp': (c_int, [c_vp, P(ctypes.c_float)]),
+        'moe_plan_pool_elems': (c_i64, [c_vp, c_int]),
+        'moe_plan_tile_offsets': (c_int, [c_vp, c_int, P(c_i64)]),
+        'moe_stitch': (c_int, [c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_vp]),
+        'moe_run_plan': (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_vp, c_int, c_int, c_vp]),
+        'moe_run_plan_ex': (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp]),
+        'moe_to_float': (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp]),
+        'moe_to_output': (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)   # AttributeError here = header/library mismatch: fail loudly
+        fn.restype, fn.argtypes = res, args
+    if L.moe_abi_version() != 1:
+        raise EngineError('libmoephoto_amd.so ABI version mismatch')
+    _lib = L
+    return L
+
+
+EXPORTS = ['moe_last_error', 'moe_abi_version', 'moe_device_count', 'moe_net_create', 'moe_net_destroy', 'moe_net_scale',
+           'moe_net_num_params', 'moe_net_param_info', 'moe_net_set_param', 'moe_net_finalize', 'moe_net_workspace_bytes',
+           'moe_net_forward', 'moe_net_set_debug', 'moe_net_debug_tap', 'moe_plan_create', 'moe_plan_destroy', 'moe_plan_info',
+           'moe_plan_tiles', 'moe_plan_ramp', 'moe_plan_pool_elems', 'moe_plan_tile_offsets', 'moe_stitch', 'moe_run_plan',
+           'moe_run_plan_ex', 'moe_to_float', 'moe_to_output']
+
+
+def check(rc):
+    """Translate a C status into the exception the reference's callers expect
+    (worker.enhance catches everything and reports the traceback: python/worker.py:52-74;
+    MemoryError is the planner's "tile does not fit" convention: python/imageProcess.py:58-59)."""
+    if rc is not None and rc < 0:
+        msg = lib().moe_last_error().decode('utf-8', 'replace')
+        if rc == ENOMEM:
+            raise MemoryError(msg)
+        raise EngineError(msg)
+    return rc
+
+
+def require_device():
+    n = lib().moe_device_count()
+    if n < 1:
+        raise EngineError('no HIP device visible: moephoto_amd runs on MI355X (gfx950) only and has no CPU path')
+    return n

@@ -651,24 +651,42 @@ int forward_dev(moe_net& n, const void* x, int x_dtype, int B, int h, int w, lon
 // =====================================================================================================
 // plan device cache + stitch + run
 // =====================================================================================================
-static int plan_device_tables(const Plan& p, int device, int C, int64_t sC, int64_t sH, int64_t sW)
+static int plan_device_tables(const Plan& p, int device, int C, int64_t sC, int64_t sH, int64_t sW, int si, int scnt,
+                              PlanDeviceCache** outp)
 {
-    PlanDeviceCache& d = p.dev;
-    if (d.blob && d.device == device && d.C == C && d.sC == sC && d.sH == sH && d.sW == sW) return MOE_OK;
-    if (d.blob) { (void)hipFree(d.blob); d.blob = nullptr; }
+    if (scnt < 1) { scnt = 1; si = 0; }
+    for (auto& up : p.dev) {
+        PlanDeviceCache& d = *up;
+        if (d.blob && d.device == device && d.C == C && d.sC == sC && d.sH == sH && d.sW == sW && d.shard_index == si && d.shard_count == scnt) {
+            *outp = &d;
+            return MOE_OK;
+        }
+    }
+    if (p.dev.size() >= 16) {   // bounded: drop the oldest layout
+        if (p.dev.front()->blob) (void)hipFree(p.dev.front()->blob);
+        p.dev.erase(p.dev.begin());
+    }
+    p.dev.push_back(std::make_unique<PlanDeviceCache>());
+    PlanDeviceCache& d = *p.dev.back();
     const size_t nt = p.tiles.size();
-    std::vector<long long> xo(nt * C), yo(nt * C);
-    size_t slot = 0;
-    for (const auto& g : p.groups)
+    std::vector<long long> xo, yo;
+    int slot = 0;
+    for (const auto& g : p.groups) {
+        d.group_first.push_back(slot);
+        int cnt = 0;
         for (int k : g.tiles) {
+            if (k % scnt != si) continue;
             const TileRect& t = p.tiles[k];
             const long long plane = (long long)(g.th * p.sc) * (g.tw * p.sc);
             for (int c = 0; c < C; ++c) {
-                xo[slot * C + c] = (long long)c * sC + (long long)t.top * sH + (long long)t.left * sW;
-                yo[slot * C + c] = p.tile_off[k] / p.C * C + (long long)c * plane;
+                xo.push_back((long long)c * sC + (long long)t.top * sH + (long long)t.left * sW);
+                yo.push_back(p.tile_off[k] / p.C * C + (long long)c * plane);
             }
-            ++slot;
+            ++slot; ++cnt;
         }
+        d.group_count.push_back(cnt);
+    }
+    if (xo.empty()) { xo.push_back(0); yo.push_back(0); }
     // tile_off scaled to C planes (C may differ from the planning shape's channel count, e.g. alpha stripped)
     std::vector<long long> toff(nt);
     for (size_t k = 0; k < nt; ++k) toff[k] = p.tile_off[k] / p.C * C;
@@ -686,13 +704,13 @@ static int plan_device_tables(const Plan& p, int device, int C, int64_t sC, int6
     d.x_off = (long long*)(b + o_x); d.y_off = (long long*)(b + o_y); d.tile_off = (long long*)(b + o_t);
     d.row_first = (int*)(b + o_rf); d.row_cnt = (int*)(b + o_rc); d.col_first = (int*)(b + o_cf); d.col_cnt = (int*)(b + o_cc);
     d.row_tab = (int*)(b + o_rt); d.col_tab = (int*)(b + o_ct); d.ramp = (float*)(b + o_rp);
-    d.device = device; d.C = C; d.sC = sC; d.sH = sH; d.sW = sW;
+    d.device = device; d.C = C; d.sC = sC; d.sH = sH; d.sW = sW; d.shard_index = si; d.shard_count = scnt;
+    *outp = &d;
     return MOE_OK;
 }
 
-static void fill_stitch(const Plan& p, StitchArgs& a, const float* tiles, const long long* tile_off, int C, void* out, int out_dtype)
+static void fill_stitch(const Plan& p, const PlanDeviceCache& d, StitchArgs& a, const float* tiles, const long long* tile_off, int C, void* out, int out_dtype)
 {
-    const PlanDeviceCache& d = p.dev;
     a.tiles = tiles; a.tile_off = tile_off;
     a.row_first = d.row_first; a.row_cnt = d.row_cnt; a.col_first = d.col_first; a.col_cnt = d.col_cnt;
     a.row_tab = d.row_tab; a.col_tab = d.col_tab; a.ramp = d.ramp;
@@ -868,8 +886,8 @@ int moe_plan_create(const int64_t shape[3], double ram, double ram_coef, int pad
 void moe_plan_destroy(moe_plan* p)
 {
     if (!p) return;
-    if (p->p.dev.blob) (void)hipFree(p->p.dev.blob);
-    if (p->p.dev.pool) (void)hipFree(p->p.dev.pool);
+    for (auto& d : p->p.dev) if (d->blob) (void)hipFree(d->blob);
+    if (p->p.pool) (void)hipFree(p->p.pool);
     delete p;
 }
 
@@ -902,64 +920,96 @@ int moe_plan_ramp(const moe_plan* p, float* ramp)
 }
 
 // ---- stitch / run ------------------------------------------------------------------------------------
+int64_t moe_plan_pool_elems(const moe_plan* p, int C)
+{
+    if (!p || C < 1) return fail(MOE_EINVAL, "moe_plan_pool_elems: bad argument");
+    return (int64_t)(p->p.pool_elems_per_plane_set / p->p.C * C);
+}
+
+int moe_plan_tile_offsets(const moe_plan* p, int C, int64_t* off)
+{
+    if (!p || !off || C < 1) return fail(MOE_EINVAL, "moe_plan_tile_offsets: bad argument");
+    for (size_t k = 0; k < p->p.tiles.size(); ++k) off[k] = p->p.tile_off[k] / p->p.C * C;
+    return MOE_OK;
+}
+
 int moe_stitch(const moe_plan* p, int device, const float* tiles_dev, const int64_t* tile_off, int C, void* out, int out_dtype, void* stream)
 {
-    if (!p || !tiles_dev || !tile_off || !out || C < 1) return fail(MOE_EINVAL, "moe_stitch: bad argument");
+    if (!p || !tiles_dev || !out || C < 1) return fail(MOE_EINVAL, "moe_stitch: bad argument");
     HIP_TRY(hipSetDevice(device));
-    int rc = plan_device_tables(p->p, device, C, p->p.dev.sC, p->p.dev.sH, p->p.dev.sW);
+    PlanDeviceCache* d = nullptr;
+    int rc = plan_device_tables(p->p, device, C, 0, 0, 0, 0, 1, &d);
     if (rc) return rc;
     long long* toff = nullptr;
-    HIP_TRY(hipMalloc((void**)&toff, p->p.tiles.size() * 8));
-    HIP_TRY(hipMemcpy(toff, tile_off, p->p.tiles.size() * 8, hipMemcpyHostToDevice));
+    if (tile_off) {   // caller-defined pool layout: blocking upload
+        HIP_TRY(hipMalloc((void**)&toff, p->p.tiles.size() * 8));
+        HIP_TRY(hipMemcpy(toff, tile_off, p->p.tiles.size() * 8, hipMemcpyHostToDevice));
+    }
     StitchArgs a{};
-    fill_stitch(p->p, a, tiles_dev, toff, C, out, out_dtype);
+    fill_stitch(p->p, *d, a, tiles_dev, toff ? toff : d->tile_off, C, out, out_dtype);
     launch_stitch(a, (hipStream_t)stream);
-    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    HIP_TRY(hipFree(toff));
+    hipError_t e = hipGetLastError();
+    if (toff) { HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); HIP_TRY(hipFree(toff)); }
+    if (e != hipSuccess) return fail(MOE_EHIP, "stitch launch failed: %s", hipGetErrorString(e));
+    return MOE_OK;
+}
+
+int moe_run_plan_ex(moe_net* n, const moe_plan* pl, const void* img, int img_dtype, int64_t sC, int64_t sH, int64_t sW,
+                    void* out, int out_dtype, int max_tiles, float* pool, int shard_index, int shard_count, int do_stitch, void* stream)
+{
+    if (!n || !pl || !img || (do_stitch && !out)) return fail(MOE_EINVAL, "moe_run_plan: NULL argument");
+    if (!n->finalized) return fail(MOE_ESTATE, "moe_run_plan: net is not finalized");
+    const Plan& p = pl->p;
+    if (p.sc != n->scale) return fail(MOE_EINVAL, "moe_run_plan: plan scale %d != net scale %d", p.sc, n->scale);
+    if (shard_count < 1) { shard_count = 1; shard_index = 0; }
+    if (shard_index < 0 || shard_index >= shard_count) return fail(MOE_EINVAL, "moe_run_plan: shard %d of %d", shard_index, shard_count);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(n->device));
+    const int C = p.C;
+    PlanDeviceCache* d = nullptr;
+    int rc = plan_device_tables(p, n->device, C, sC, sH, sW, shard_index, shard_count, &d);
+    if (rc) return rc;
+    if (!pool) {
+        const size_t pool_need = p.pool_elems_per_plane_set;
+        if (pool_need > p.pool_elems) {
+            if (p.pool) { HIP_TRY(hipStreamSynchronize(s)); HIP_TRY(hipFree(p.pool)); p.pool = nullptr; p.pool_elems = 0; }
+            if (hipMalloc((void**)&p.pool, pool_need * 4) != hipSuccess) { (void)hipGetLastError(); return fail(MOE_ENOMEM, "tile pool of %zu bytes does not fit", pool_need * 4); }
+            p.pool_elems = pool_need;
+        }
+        pool = p.pool;
+    }
+    if (max_tiles <= 0) {
+        max_tiles = 4;
+        if (const char* e = getenv("MOE_TILES_PER_BATCH")) { const int v = atoi(e); if (v > 0) max_tiles = v; }
+    }
+    for (size_t gi = 0; gi < p.groups.size(); ++gi) {
+        const auto& g = p.groups[gi];
+        const int nt = d->group_count[gi];
+        if (nt < 1) continue;
+        // bigger batches for small tiles: keep roughly max_tiles * 256^2 pixels per launch
+        const long long px = (long long)g.th * g.tw;
+        const int per = (int)std::max<long long>(1, std::min<long long>(nt, (long long)max_tiles * 65536 / std::max<long long>(px, 1)));
+        for (int t0 = 0; t0 < nt; t0 += per) {
+            const int cnt = std::min(per, nt - t0);
+            const long long slot = (long long)(d->group_first[gi] + t0) * C;
+            rc = forward_dev(*n, img, img_dtype, cnt * C, g.th, g.tw, 0, sH, sW, d->x_off + slot, pool, MOE_F32, d->y_off + slot, s);
+            if (rc) return rc;
+        }
+    }
+    if (do_stitch) {
+        StitchArgs a{};
+        fill_stitch(p, *d, a, pool, d->tile_off, C, out, out_dtype);
+        launch_stitch(a, s);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(MOE_EHIP, "stitch launch failed: %s", hipGetErrorString(e));
+    }
     return MOE_OK;
 }
 
 int moe_run_plan(moe_net* n, const moe_plan* pl, const void* img, int img_dtype, int64_t sC, int64_t sH, int64_t sW,
                  void* out, int out_dtype, int max_tiles, void* stream)
 {
-    if (!n || !pl || !img || !out) return fail(MOE_EINVAL, "moe_run_plan: NULL argument");
-    if (!n->finalized) return fail(MOE_ESTATE, "moe_run_plan: net is not finalized");
-    const Plan& p = pl->p;
-    if (p.sc != n->scale) return fail(MOE_EINVAL, "moe_run_plan: plan scale %d != net scale %d", p.sc, n->scale);
-    hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(hipSetDevice(n->device));
-    const int C = p.C;
-    int rc = plan_device_tables(p, n->device, C, sC, sH, sW);
-    if (rc) return rc;
-    PlanDeviceCache& d = p.dev;
-    const size_t pool_need = p.pool_elems_per_plane_set;
-    if (pool_need > d.pool_elems) {
-        if (d.pool) { HIP_TRY(hipStreamSynchronize(s)); HIP_TRY(hipFree(d.pool)); d.pool = nullptr; d.pool_elems = 0; }
-        if (hipMalloc((void**)&d.pool, pool_need * 4) != hipSuccess) { (void)hipGetLastError(); return fail(MOE_ENOMEM, "tile pool of %zu bytes does not fit", pool_need * 4); }
-        d.pool_elems = pool_need;
-    }
-    if (max_tiles <= 0) {
-        max_tiles = 4;
-        if (const char* e = getenv("MOE_TILES_PER_BATCH")) { const int v = atoi(e); if (v > 0) max_tiles = v; }
-    }
-    for (const auto& g : p.groups) {
-        const int nt = (int)g.tiles.size();
-        // bigger batches for small tiles: keep roughly max_tiles * 256^2 pixels per launch
-        long long px = (long long)g.th * g.tw;
-        int per = (int)std::max<long long>(1, std::min<long long>(nt, (long long)max_tiles * 65536 / std::max<long long>(px, 1)));
-        for (int t0 = 0; t0 < nt; t0 += per) {
-            const int cnt = std::min(per, nt - t0);
-            const long long slot = (long long)(g.first_slot + t0) * C;
-            rc = forward_dev(*n, img, img_dtype, cnt * C, g.th, g.tw, 0, sH, sW, d.x_off + slot, d.pool, MOE_F32, d.y_off + slot, s);
-            if (rc) return rc;
-        }
-    }
-    StitchArgs a{};
-    fill_stitch(p, a, d.pool, d.tile_off, C, out, out_dtype);
-    launch_stitch(a, s);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(MOE_EHIP, "stitch launch failed: %s", hipGetErrorString(e));
-    return MOE_OK;
+    return moe_run_plan_ex(n, pl, img, img_dtype, sC, sH, sW, out, out_dtype, max_tiles, nullptr, 0, 1, 1, stream);
 }
 
 // ---- image edges ---------------------------------------------------------------------------------------

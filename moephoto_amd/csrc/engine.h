@@ -21,18 +21,18 @@ AxisAnchors get_anchors(int64_t s, int64_t ns, int64_t l, int pad, int align, in
 
 struct TileRect { int top, bottom, left, right, top_t, left_t, bsc, rsc; };
 
-struct PlanDeviceCache {       // device-side tables of a plan, built on first use on a device
+struct PlanDeviceCache {       // device-side tables of a plan for one (layout, shard), built on first use
     int device = -1;
     int C = 0;
     int64_t sC = 0, sH = 0, sW = 0;
+    int shard_index = 0, shard_count = 1;
+    std::vector<int> group_first, group_count;   // per plan group: first slot / number of this shard's tiles
     void* blob = nullptr;      // one allocation: all tables below
     long long* x_off = nullptr;    // [ngroups-concatenated tiles][C]
     long long* y_off = nullptr;    // same order: offset of each plane inside the tile pool
     long long* tile_off = nullptr; // [n_tiles] raster order
     int *row_first = nullptr, *row_cnt = nullptr, *col_first = nullptr, *col_cnt = nullptr, *row_tab = nullptr, *col_tab = nullptr;
     float* ramp = nullptr;
-    float* pool = nullptr;     // per-tile fp32 results
-    size_t pool_elems = 0;
 };
 
 struct TileGroup { int th, tw; std::vector<int> tiles; int first_slot; };   // same-shaped tiles, slots in x_off order
@@ -47,7 +47,9 @@ struct Plan {
     std::vector<TileGroup> groups;
     std::vector<long long> tile_off;   // element offsets inside the pool
     size_t pool_elems_per_plane_set = 0;
-    mutable PlanDeviceCache dev;
+    mutable std::vector<std::unique_ptr<PlanDeviceCache>> dev;   // a few entries at most (one per shard/layout seen)
+    mutable float* pool = nullptr;     // internal per-tile fp32 results (when the caller passes none)
+    mutable size_t pool_elems = 0;
 };
 int build_plan(Plan& p, const int64_t shape[3], double ram, double ram_coef, int pad, int sc, int align, int cropsize,
                std::string& err);

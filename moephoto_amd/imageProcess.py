@@ -1,0 +1,394 @@
+"""Host-side mirror of the tiling runtime of python/imageProcess.py, on top of the HIP engine.
+
+Same names and argument meaning as the reference so callers (runSR/runDN adapters, the pipeline
+builder) read unchanged; the work itself is done on the device by libmoephoto_amd.so:
+
+  Option, initModel, getStateDict      python/imageProcess.py:304-334, 379-395
+  prepare / getAnchors / TilePlan      :19-35, 73-118   -> C planner (moe_plan_create)
+  prepareOpt, doCrop                   :133-172         -> moe_run_plan (tile gather, net, stitch on device)
+  ensemble, trans/transInv             :563-572
+  RGBFilter, strengthOp, alpha helpers :350-377, 562
+  toTorch / toFloat / toOutput         :238-263         -> moe_to_float / moe_to_output kernels
+  readFile / writeFile                 :265-302         (PIL, host)
+
+There is no CPU path: models must be moephoto_amd.models.EngineModule instances on a HIP device.
+"""
+import ctypes
+import logging
+import time
+from functools import reduce
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from .config import config
+from .models import EngineModule
+from .weights import load_state_dict_file
+
+log = logging.getLogger('Moe')
+modelCache = {}
+weightCache = {}
+minSize = 28
+identity = lambda x, *_, **__: x
+apply = lambda v, f: f(v)
+_DT = {torch.float32: _lib.F32, torch.float16: _lib.F16}
+
+
+def ceilBy(d):
+    return lambda x: ((int(x) + d - 1) // d) * d
+
+
+alignF = {1: identity}
+alignF.update((1 << k, ceilBy(1 << k)) for k in (3, 4, 5, 6, 7, 9))
+
+
+# ---------------------------------------------------------------------------------------------------
+# planner
+# ---------------------------------------------------------------------------------------------------
+class TilePlan(object):
+    """A tile plan for one image shape: the C planner's result plus its device tables."""
+
+    def __init__(self, shape, ram, ramCoef, pad, sc, align=8, cropsize=0):
+        L = _lib.lib()
+        self.shape = tuple(int(v) for v in shape[-3:])
+        self._h = ctypes.c_void_p()
+        _lib.check(L.moe_plan_create((ctypes.c_int64 * 3)(*self.shape), float(ram), float(ramCoef), int(pad), int(sc),
+                                     int(align), int(cropsize), ctypes.byref(self._h)))
+        info = (ctypes.c_int64 * 12)()
+        _lib.check(L.moe_plan_info(self._h, info))
+        (self.n_tiles, self.stepH, self.stepW, self.outH, self.outW, self.padHTo, self.padWTo, self.padSc,
+         self.tileH, self.tileW, self.clipH, self.clipW) = [int(v) for v in info]
+        t = (ctypes.c_int32 * (8 * self.n_tiles))()
+        _lib.check(L.moe_plan_tiles(self._h, t))
+        self.tiles = [tuple(t[k * 8:(k + 1) * 8]) for k in range(self.n_tiles)]
+        r = (ctypes.c_float * max(1, self.padSc))()
+        _lib.check(L.moe_plan_ramp(self._h, r))
+        self.ramp = np.array(r[:self.padSc], np.float32)
+        self.sc, self.pad, self.align = int(sc), int(pad), int(align)
+
+    def __del__(self):
+        try:
+            if self._h.value:
+                _lib.lib().moe_plan_destroy(self._h)
+                self._h = ctypes.c_void_p()
+        except Exception:
+            pass
+
+    def pool_elems(self, C):
+        return int(_lib.check(_lib.lib().moe_plan_pool_elems(self._h, int(C))))
+
+    def tile_offsets(self, C):
+        off = (ctypes.c_int64 * self.n_tiles)()
+        _lib.check(_lib.lib().moe_plan_tile_offsets(self._h, int(C), off))
+        return list(off)
+
+    def padImage(self, x):
+        """getPad (python/imageProcess.py:47-56) restricted to the region a single-tile axis reads:
+        reflect (edge not repeated) up to len-1, then zeros."""
+        def pad_axis(t, from_end, to):      # from_end: 1 = width, 2 = height
+            n = t.shape[-from_end]
+            if not to or to <= n:
+                return t
+            refl = min(n - 1, to - n)
+            if refl > 0:
+                p = (0, refl, 0, 0) if from_end == 1 else (0, 0, 0, refl)
+                t = F.pad(t.unsqueeze(0), p, mode='reflect').squeeze(0)
+            rest = to - n - refl
+            if rest > 0:
+                t = F.pad(t, (0, rest, 0, 0) if from_end == 1 else (0, 0, 0, rest))
+            return t
+        x = pad_axis(x, 1, self.padWTo)
+        x = pad_axis(x, 2, self.padHTo)
+        return x
+
+    def unpad(self, im):
+        return im[..., :self.outH, :self.outW]
+
+
+def getAnchors(s, ns, l, pad, af, sc):
+    """python/imageProcess.py:19-35 (host arithmetic; the C planner computes the same per axis)."""
+    n = l - 2 * pad
+    step = 1 if l >= af(s) else max(2, -(-int(ns) // n))
+    start = [k * n + pad for k in range(step)]
+    start[0] = 0
+    end = [a + l for a in start]
+    endSc = [e * sc for e in end]
+    if step > 1:
+        start[-1] = s - af(s - end[-2] + pad)
+        end[-1] = s
+        clip = int((end[-2] - s) * sc)
+    else:
+        end[-1] = af(s)
+        clip = 0
+    endSc[-1] = s * sc
+    return start, end, clip, step, [int(e) for e in endSc]
+
+
+def prepare(shape, ram, opt, pad, sc, align=8, cropsize=0):
+    """python/imageProcess.py:73-118.  Returns (iterClip, padImage, unpad, outShape, blend) like the
+    reference; the TilePlan itself is attached to the returned iterClip as `.plan`."""
+    plan = TilePlan(shape, ram, opt.ramCoef, pad, sc, align, cropsize)
+
+    def iterClip():
+        for t in plan.tiles:
+            yield t
+    iterClip.plan = plan
+    b = torch.from_numpy(plan.ramp.copy()).view(1, -1)
+    return iterClip, plan.padImage, plan.unpad, (*shape[:-2], plan.outH, plan.outW), b
+
+
+class Option(object):
+    """python/imageProcess.py:379-395."""
+
+    def __init__(self, path=''):
+        self.ramCoef, self.count = 1e-3, 0
+        self.padding, self.cropsize, self.align, self.fixChannel = 1, 0, 8, 1
+        self.scale, self.ensemble, self.strength = 1, 0, 1.0
+        self.model = path
+        self.outShape, self.oShape = None, None
+        self.iterClip = None
+        self.prepare = identity
+        self.squeeze = lambda x: x.squeeze(0)
+        self.unsqueeze = lambda x: x.unsqueeze(0)
+        self.modelCached = None
+        self._plans = {}
+
+    def __call__(self, x, *args, **kwargs):
+        out = self.modelCached(x, *args, **kwargs)
+        if type(out) == list:
+            out = out[-1]
+        return out
+
+
+def getStateDict(path):
+    """python/imageProcess.py:304-307, with our own closed parser of the legacy zoo format."""
+    if path not in weightCache:
+        sd = load_state_dict_file(path)
+        weightCache[path] = type(sd)((k, torch.from_numpy(v)) for k, v in sd.items())
+    return weightCache[path]
+
+
+def castModel(model):
+    """python/imageProcess.py:309-317.  Every engine model computes with fp16 MFMA operands and fp32
+    accumulation whatever castDtype says; the dtype only selects the I/O element type."""
+    return model.to(dtype=config.dtype(), device=config.device())
+
+
+def initModel(opt, weights=None, key=None, f=lambda opt: opt.modelDef(), args=[]):
+    """python/imageProcess.py:319-334."""
+    if key and key in modelCache:
+        return castModel(modelCache[key])
+    log.info('loading model {}'.format(opt.model))
+    model = f(opt, *args)
+    if weights:
+        log.info('reloading weights')
+        if type(weights) == str:
+            weights = getStateDict(weights)
+        model.load_state_dict(weights)
+    for param in model.parameters():
+        param.requires_grad_(False)
+    model.eval()
+    if key:
+        modelCache[key] = model
+    return castModel(model)
+
+
+def _plan_for(opt, shape):
+    """prepareOpt (python/imageProcess.py:133-155): plans are cached per image shape; the reference
+    re-plans every 29 calls to follow free memory -- here the plan only depends on free memory when
+    cropsize is 'auto', and is then re-derived with the same cadence."""
+    key = tuple(int(v) for v in shape[-3:])
+    ent = opt._plans.get(key)
+    if ent is None or (opt.cropsize <= 0 and ent[1] > 28):
+        try:
+            freeMem = config.calcFreeMem()
+        except Exception:
+            raise MemoryError('Can not calculate free memory.')
+        it, padImage, unpad, outShape, bl = prepare(key, freeMem, opt, opt.padding, opt.scale, opt.align, opt.cropsize)
+        ent = [it.plan, 0]
+        opt._plans[key] = ent
+        opt.iterClip, opt.padImage, opt.unpad, opt.blend = it, padImage, unpad, bl
+        opt.outShape = list(outShape)
+    else:
+        ent[1] += 1
+    return ent[0]
+
+
+def prepareOpt(opt, shape):
+    _plan_for(opt, shape)
+    return opt.scale, int(opt.padding * opt.scale)
+
+
+def doCrop(opt, x, *args, **_):
+    """python/imageProcess.py:157-172, entirely on the device: the planes of x (C,H,W) become the batch
+    (runSR.py:37-40), tiles are gathered straight from x by the stem kernel, same-shaped tiles are batched
+    through the net, and the gather-stitch kernel folds them with the reference's sequential blend."""
+    model = opt.modelCached
+    if not isinstance(model, EngineModule):
+        raise TypeError('doCrop needs an engine-backed model (moephoto_amd.models.*), got {}'.format(type(model).__name__))
+    if x.device.type != 'cuda':
+        raise _lib.EngineError('doCrop: input must live on a HIP device (moephoto_amd has no CPU path)')
+    if x.dim() != 3:
+        raise ValueError('doCrop expects a (C,H,W) image')
+    plan = _plan_for(opt, x.shape)
+    xp = plan.padImage(x)
+    if xp.dtype not in _DT:
+        xp = xp.to(config.dtype())
+    model.to(device=x.device)
+    C = xp.shape[0]
+    out = xp.new_empty((C, plan.outH, plan.outW))
+    sC, sH, sW = xp.stride()
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    _lib.check(_lib.lib().moe_run_plan(model._h, plan._h, xp.data_ptr(), _DT[xp.dtype], sC, sH, sW,
+                                       out.data_ptr(), _DT[out.dtype], int(config.tilesPerBatch), stream))
+    # the engine reads xp asynchronously: keep it alive until the stream has consumed it
+    xp.record_stream(torch.cuda.current_stream(x.device))
+    return out
+
+
+# ---- self-ensemble (python/imageProcess.py:563-572) -------------------------------------------------
+transpose = lambda x: x.transpose(-1, -2)
+flip = lambda x: x.flip(-1)
+flip2 = lambda x: x.flip(-1, -2)
+combine = lambda *fs: lambda x: reduce(apply, fs, x)
+trans = [transpose, flip, flip2, combine(flip, transpose), combine(transpose, flip), combine(transpose, flip, transpose), combine(flip2, transpose)]
+transInv = [transpose, flip, flip2, trans[4], trans[3], trans[5], trans[6]]
+
+
+def ensemble(opt):
+    """x -> doCrop(x) + sum_i transInv_i(doCrop(trans_i(x))) for the first opt.ensemble transforms.
+    (The reference keeps a second Option for transposed shapes; here plans are keyed by shape.)"""
+    def f(x):
+        v = doCrop(opt, x)
+        for i in range(opt.ensemble):
+            v = v + transInv[i](doCrop(opt, trans[i](x)))
+        return v
+    return f
+
+
+# ---- DN wrapper (python/imageProcess.py:336-377, 562) -----------------------------------------------
+strengthOp = lambda x, inp, s=1: x if s == 1 else s * x + (1 - s) * inp
+
+
+def extractAlpha(t):
+    def f(im):
+        if im.shape[0] == 4:
+            t['im'] = im[3]
+            return im[:3]
+        return im
+    return f
+
+
+def mergeAlpha(t):
+    def f(im):
+        if len(t):
+            image = torch.empty((4, *im.shape[1:]), dtype=im.dtype, device=im.device)
+            image[:3] = im
+            image[3] = t['im']
+            return image
+        return im
+    return f
+
+
+def _RGBFilter(opt, img):
+    t = {}
+    imgIn = opt.prepare(extractAlpha(t)(img))
+    prediction = doCrop(opt, imgIn)
+    out = strengthOp(prediction, imgIn, opt.strength)
+    return mergeAlpha(t)(out)
+
+
+RGBFilter = lambda opt: lambda img: _RGBFilter(opt, img)
+
+
+# ---- image edges (python/imageProcess.py:238-302) ----------------------------------------------------
+def toTorch(bitDepth, dtype=None, device=None):
+    """HWC uint8 / uint16 numpy image -> (C,H,W) tensor on the device, v/255 (8 bit) or v/2^bits."""
+    def f(image):
+        dt = dtype if dtype is not None else config.dtype()
+        dev = torch.device(device if device is not None else config.device())
+        a = np.ascontiguousarray(image)
+        if a.ndim == 2:
+            a = a[:, :, None]
+        if bitDepth <= 8:
+            a = a.astype(np.uint8, copy=False)
+            src_dt = _lib.U8
+        else:
+            a = a.astype(np.uint16)
+            src_dt = _lib.U16
+        H, W, C = a.shape
+        src = torch.from_numpy(a).to(dev)
+        dst = torch.empty((C, H, W), dtype=dt, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(_lib.lib().moe_to_float(src.data_ptr(), src_dt, int(bitDepth), H, W, C, dst.data_ptr(), _DT[dt], dev.index or 0, stream))
+        src.record_stream(torch.cuda.current_stream(dev))
+        return dst
+    return f
+
+
+def toFloat(image):
+    """python/imageProcess.py:238-243: (C,H,W) -> (H,W,C) fp32 (a permuted view when already fp32)."""
+    if len(image.shape) == 3:
+        image = image.permute(1, 2, 0)
+    else:
+        image = image.squeeze(0)
+    return image.to(dtype=torch.float)
+
+
+def toOutput(bitDepth):
+    """python/imageProcess.py:245-257: x * 2^bits, clamp [0, 2^bits - 1], truncate, to host numpy (H,W,C)."""
+    def f(image):
+        if image.dim() == 2:
+            image = image.unsqueeze(2)
+        H, W, C = image.shape
+        planar = image.permute(2, 0, 1)
+        if not planar.is_contiguous():
+            planar = planar.contiguous()
+        if planar.dtype not in _DT:
+            planar = planar.float()
+        dev = planar.device
+        out_dt, np_dt, lib_dt = (torch.uint8, np.uint8, _lib.U8) if bitDepth <= 8 else (torch.int16, np.uint16, _lib.U16)
+        dst = torch.empty((H, W, C), dtype=out_dt, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(_lib.lib().moe_to_output(planar.data_ptr(), _DT[planar.dtype], H, W, C, int(bitDepth), dst.data_ptr(), lib_dt, dev.index or 0, stream))
+        planar.record_stream(torch.cuda.current_stream(dev))
+        res = dst.cpu().numpy()
+        return res.view(np_dt) if bitDepth > 8 else res
+    return f
+
+
+toOutput8 = toOutput(8)
+
+
+def readFile(nodes=[], context=None):
+    from PIL import Image
+
+    def f(file):
+        image = Image.open(file)
+        if context is not None:
+            context.imageMode = image.mode
+        if image.mode == 'P':
+            if context is not None:
+                context.palette = image
+            image = image.convert('RGB')
+        image = np.array(image)
+        if len(image.shape) == 2:
+            return image.reshape(*image.shape, 1)
+        if image.shape[2] in (3, 4):
+            return image
+        raise RuntimeError('Unknown image format')
+    return f
+
+
+def writeFile(image, name, context=None, *args):
+    from PIL import Image
+    if not name:
+        name = 'output_{}.png'.format(int(time.time()))
+    elif hasattr(name, 'seek'):
+        name.seek(0)
+    if image.shape[2] == 1:
+        image = image.squeeze(2)
+    Image.fromarray(image).save(name, *args)
+    return name

@@ -1,0 +1,226 @@
+"""Engine-backed stand-ins for the reference's model classes -- the drop-in boundary.
+
+The reference builds its nets in the "constructor slot" of the plugin tables
+(python/runSR.py:10-24, python/runDN.py:10-21) and then does, in initModel
+(python/imageProcess.py:319-334):
+
+    m = ctor(); m.load_state_dict(sd); [p.requires_grad_(False) for p in m.parameters()]; m.eval()
+    m = m.to(dtype=config.dtype(), device=config.device())        # castModel, :309-317
+    y = m(x)                                                        # Option.__call__, :391-395
+
+The classes here accept exactly that protocol, with the same names, and run the forward on the
+HIP engine (libmoephoto_amd.so) on torch's current stream:
+
+    Net2x / Net3x / Net4x   python/models.py:125-154     (a2/a3/a4, p2/p3/p4)
+    NetDN                   python/models.py:158-164     (dn_lite5/10/15)
+    SEDN                    python/models.py:215-224     (l15/l25/l50)
+    Net(upscale)            python/MoeNet_lite2.py:22-54 (lite2/4/8; re-exported by moephoto_amd.MoeNet_lite2)
+
+x: torch tensor (B,1,h,w), fp16 or fp32, on a HIP device, any strides (doCrop hands in a slice view).
+Returns a one-element list [y], y: (B,1,scale*h,scale*w) in x's dtype -- the reference's forwards return
+lists and Option.__call__ takes the last entry.
+"""
+import ctypes
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: _lib.F32, torch.float16: _lib.F16}
+
+
+class EngineModule(object):
+    ARCH = None
+    SCALE = 0
+    castDtype = 'float16'     # class attribute castModel looks up (python/imageProcess.py:310)
+
+    def __init__(self, scale=None):
+        L = _lib.lib()
+        self._h = ctypes.c_void_p()
+        _lib.check(L.moe_net_create(self.ARCH, int(scale if scale is not None else self.SCALE), ctypes.byref(self._h)))
+        self.scale = L.moe_net_scale(self._h)
+        self._params = OrderedDict()
+        self._device = None
+        self._dtype = torch.float32
+        self._finalized_key = None
+        self.training = False
+        self.precision = os.environ.get('MOE_PRECISION', 'fp16')
+
+    def __del__(self):
+        try:
+            if getattr(self, '_h', None) is not None and self._h.value:
+                _lib.lib().moe_net_destroy(self._h)
+                self._h = ctypes.c_void_p()
+        except Exception:
+            pass
+
+    # ---- nn.Module protocol used by initModel / castModel ----------------------------------------
+    def expected_keys(self):
+        L = _lib.lib()
+        out = OrderedDict()
+        name, shape, nd = ctypes.c_char_p(), (ctypes.c_int64 * 4)(), ctypes.c_int()
+        for i in range(L.moe_net_num_params(self._h)):
+            _lib.check(L.moe_net_param_info(self._h, i, ctypes.byref(name), shape, ctypes.byref(nd)))
+            out[name.value.decode()] = tuple(shape[d] for d in range(nd.value))
+        return out
+
+    def load_state_dict(self, state_dict, strict=True):
+        L = _lib.lib()
+        exp = self.expected_keys()
+        keys = list(state_dict.keys())
+        missing = [k for k in exp if k not in state_dict]
+        unexpected = [k for k in keys if k not in exp]
+        if strict and (missing or unexpected):
+            msg = 'Error(s) in loading state_dict for {}:'.format(type(self).__name__)
+            if missing:
+                msg += '\n\tMissing key(s) in state_dict: {}. '.format(', '.join('"{}"'.format(k) for k in missing))
+            if unexpected:
+                msg += '\n\tUnexpected key(s) in state_dict: {}. '.format(', '.join('"{}"'.format(k) for k in unexpected))
+            raise RuntimeError(msg)
+        for k in keys:
+            if k not in exp:
+                continue
+            v = state_dict[k]
+            a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            shape = (ctypes.c_int64 * max(1, a.ndim))(*a.shape)
+            try:
+                _lib.check(L.moe_net_set_param(self._h, k.encode(), a.ctypes.data_as(ctypes.c_void_p), shape, a.ndim))
+            except _lib.EngineError as e:
+                raise RuntimeError('Error(s) in loading state_dict for {}:\n\t{}'.format(type(self).__name__, e))
+            self._params[k] = torch.from_numpy(a.copy())
+        self._finalized_key = None
+        return self
+
+    def state_dict(self):
+        return OrderedDict((k, v.clone()) for k, v in self._params.items())
+
+    def parameters(self):
+        return iter(self._params.values())
+
+    def named_parameters(self):
+        return iter(self._params.items())
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError('moephoto_amd models are inference-only')
+        return self.eval()
+
+    def requires_grad_(self, flag=False):
+        return self
+
+    def to(self, *args, **kwargs):
+        dtype, device = kwargs.get('dtype'), kwargs.get('device')
+        for a in args:
+            if isinstance(a, torch.dtype):
+                dtype = a
+            elif a is not None:
+                device = a
+        if dtype is not None:
+            if dtype not in _DT:
+                raise TypeError('moephoto_amd models run with fp16 or fp32 I/O, not {}'.format(dtype))
+            self._dtype = dtype
+        if device is not None:
+            device = torch.device(device)
+            if device.type != 'cuda':
+                raise _lib.EngineError('moephoto_amd models run on a HIP device only (got device "{}"); there is no CPU path'.format(device))
+            self._device = torch.device('cuda', device.index if device.index is not None else torch.cuda.current_device())
+        if self._device is not None:
+            self._finalize()
+        return self
+
+    def half(self):
+        return self.to(dtype=torch.float16)
+
+    def float(self):
+        return self.to(dtype=torch.float32)
+
+    def cuda(self, device=None):
+        return self.to(device=torch.device('cuda', device if device is not None else torch.cuda.current_device()))
+
+    def set_precision(self, precision):
+        if precision not in _lib.PRECISIONS:
+            raise ValueError('precision must be one of {}'.format(sorted(_lib.PRECISIONS)))
+        self.precision = precision
+        if self._device is not None:
+            self._finalize()
+        return self
+
+    def _finalize(self):
+        key = (self._device.index, self.precision)
+        if self._finalized_key == key:
+            return
+        _lib.require_device()
+        _lib.check(_lib.lib().moe_net_finalize(self._h, self._device.index, _lib.PRECISIONS[self.precision]))
+        self._finalized_key = key
+
+    # ---- forward -------------------------------------------------------------------------------------
+    def forward(self, x):
+        if not isinstance(x, torch.Tensor) or x.dim() != 4 or x.shape[1] != 1:
+            raise ValueError('expected a (B,1,h,w) tensor, got {}'.format(tuple(getattr(x, 'shape', ()))))
+        if x.device.type != 'cuda':
+            raise _lib.EngineError('input must live on a HIP device (moephoto_amd has no CPU path)')
+        if x.dtype not in _DT:
+            raise TypeError('input must be fp16 or fp32')
+        if self._device is None or self._device != x.device:
+            self.to(device=x.device)
+        B, _, h, w = x.shape
+        y = torch.empty((B, 1, h * self.scale, w * self.scale), dtype=x.dtype, device=x.device)
+        sB, _, sH, sW = x.stride()
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _lib.check(_lib.lib().moe_net_forward(self._h, x.data_ptr(), _DT[x.dtype], B, h, w, sB, sH, sW, None,
+                                              y.data_ptr(), _DT[y.dtype], None, stream))
+        return [y]
+
+    __call__ = forward
+
+    # ---- debugging -----------------------------------------------------------------------------------
+    def set_debug(self, flag=True):
+        _lib.check(_lib.lib().moe_net_set_debug(self._h, 1 if flag else 0))
+        return self
+
+    def debug_tap(self, name):
+        """fp32 NCHW copy of a named intermediate of the last forward (after set_debug(True))."""
+        L = _lib.lib()
+        shape = (ctypes.c_int64 * 4)()
+        stream = torch.cuda.current_stream(self._device).cuda_stream
+        n = _lib.check(L.moe_net_debug_tap(self._h, name.encode(), None, 0, shape, stream))
+        out = np.empty(tuple(shape), np.float32)
+        _lib.check(L.moe_net_debug_tap(self._h, name.encode(), out.ctypes.data_as(ctypes.c_void_p), n, shape, stream))
+        return out
+
+
+class Net2x(EngineModule):
+    ARCH, SCALE = _lib.ARCH_NET2X, 2
+
+
+class Net3x(EngineModule):
+    ARCH, SCALE = _lib.ARCH_NET3X, 3
+
+
+class Net4x(EngineModule):
+    ARCH, SCALE = _lib.ARCH_NET4X, 4
+
+
+class NetDN(EngineModule):
+    ARCH, SCALE = _lib.ARCH_NETDN, 1
+
+
+class SEDN(EngineModule):
+    ARCH, SCALE = _lib.ARCH_SEDN, 1
+
+
+class Net(EngineModule):
+    """MoeNet_lite2.Net(upscale=2|4|8)."""
+    ARCH = _lib.ARCH_LITE
+
+    def __init__(self, upscale=2):
+        super(Net, self).__init__(scale=upscale)
+        self.upscale = upscale

@@ -58,7 +58,7 @@ class _LazyTensor:
         v = np.lib.stride_tricks.as_strided(
             base[self.offset:], shape=self.size,
             strides=tuple(s * base.dtype.itemsize for s in self.stride), writeable=False)
-        return np.ascontiguousarray(v)
+        return np.array(v)   # writable, C-contiguous copy
 
 
 def _rebuild_tensor_v2(storage, storage_offset, size, stride, requires_grad=False, backward_hooks=None, metadata=None):
@@ -143,28 +143,8 @@ def load_state_dict_file(path_or_file):
     sd = OrderedDict()
     for k, v in _strip(obj).items():
         a = v.materialize() if isinstance(v, _LazyTensor) else np.asarray(v)
-        sd[k] = np.ascontiguousarray(a, dtype=np.float32) if a.dtype.kind == 'f' else a
+        sd[k] = np.array(a, dtype=np.float32) if a.dtype.kind == 'f' else np.array(a)
     return sd
-
-
-class _PersId:
-    def __init__(self, pid):
-        self.pid = pid
-
-
-class _ZooPickler(pickle.Pickler):
-    def persistent_id(self, obj):
-        return obj.pid if isinstance(obj, _PersId) else None
-
-
-class _Global:
-    """Pickles as a reference to `module.name` without importing it (writer side)."""
-
-    def __init__(self, module, name):
-        self.module, self.name = module, name
-
-    def __reduce__(self):
-        raise RuntimeError('use _emit_global')
 
 
 def save_state_dict_file(sd, path):

@@ -1,0 +1,74 @@
+"""World-size-2 (and 3) CPU runs of the tile-parallel exchange (moephoto_amd/dist.py) under gloo:
+ownership, the all-to-all of packed tile results, weight broadcast.  No engine calls."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ['MOE_ROOT']); sys.path.insert(0, os.path.join(os.environ['MOE_ROOT'], 'tests'))
+import numpy as np, torch, torch.distributed as dist
+from collections import OrderedDict
+from moephoto_amd.dist import TileExchange, broadcast_state_dict
+from oracle import planner as oplanner, stitch as ostitch
+dist.init_process_group('gloo')
+rank, world = dist.get_rank(), dist.get_world_size()
+shape, sc, pad, crop, frames = (2, 70, 90), 2, 5, 40, 5
+pl = oplanner.prepare(shape, 1 << 40, 1e-3, pad, sc, 8, crop)
+C = shape[0]
+sizes = [C * (t[1] - t[0]) * (t[3] - t[2]) * sc * sc for t in pl.tiles]
+off = [0] + list(np.cumsum(sizes))[:-1]
+ex = TileExchange(len(pl.tiles), off, sum(sizes), rank, world)
+# every (frame, tile) has exactly one owner and the shard formula agrees with it
+for f in range(frames):
+    owners = [[r for r in range(world) if k in ex.tiles_of(f, r)] for k in range(len(pl.tiles))]
+    assert all(len(o) == 1 and o[0] == ex.owner(f, k) for k, o in enumerate(owners))
+def tile_value(f, k):
+    t = pl.tiles[k]
+    return np.random.default_rng(1000 * f + k).random((C, (t[1] - t[0]) * sc, (t[3] - t[2]) * sc), dtype=np.float32)
+pools = {}
+for f in range(frames):
+    p = torch.full((sum(sizes),), float('nan'))
+    for k in ex.tiles_of(f, rank):
+        p[off[k]:off[k] + sizes[k]] = torch.from_numpy(tile_value(f, k).reshape(-1))
+    pools[f] = p
+mine = ex.exchange(pools)
+assert mine == [f for f in range(frames) if f % world == rank]
+for f in mine:
+    assert not torch.isnan(pools[f]).any()
+    tiles = [pools[f][off[k]:off[k] + sizes[k]].numpy().reshape(tile_value(f, k).shape) for k in range(len(pl.tiles))]
+    want = ostitch.fold_stitch([tile_value(f, k) for k in range(len(pl.tiles))], pl, sc)
+    got = ostitch.fold_stitch(tiles, pl, sc)
+    assert np.array_equal(got, want)
+sd = OrderedDict([('a.weight', torch.arange(12.).reshape(3, 4)), ('b', torch.tensor([2.5]))]) if rank == 0 else None
+out = broadcast_state_dict(sd, src=0)
+assert list(out.keys()) == ['a.weight', 'b'] and out['a.weight'].shape == (3, 4) and float(out['b']) == 2.5
+assert torch.equal(out['a.weight'], torch.arange(12.).reshape(3, 4))
+dist.barrier()
+print('RANK_OK', rank)
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_tile_exchange_gloo(world, tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER)
+    env = dict(os.environ, MOE_ROOT=ROOT, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count('RANK_OK') == world

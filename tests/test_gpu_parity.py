@@ -1,0 +1,321 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the reference's golden vectors.
+Needs a HIP device: `pytest -m gpu`.
+
+Tolerances (max-abs, compared in fp32; north star: 1e-3 vs the reference's PyTorch-CPU fp32 path):
+  precision 'fp16'   (fp16 MFMA operands, fp32 accumulate)  natural-image-like input: 1e-3
+                                                             white-noise input (adversarial: outputs span
+                                                             [-0.6, 1.8]):              5e-3
+  precision 'fp16x3' (hi/lo split operands, 3 MFMA passes)  any input:                  1e-3 (observed ~1e-5)
+  stitch kernel alone (fp32 in/out): 1e-6 (the ramp's sigmoid differs from torch's by <= 1 ulp)
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_defs as gd
+from moephoto_amd.weights import load_state_dict_file
+from oracle import imageio as oio, nets as onets, planner as oplanner, stitch as ostitch
+from tests_util import oracle_ensemble
+
+pytestmark = pytest.mark.gpu
+G = gd.GOLDEN
+TOL_NATURAL, TOL_NOISE_FP16, TOL_X3 = 1e-3, 5e-3, 1e-3
+
+
+@pytest.fixture(scope='module')
+def dev():
+    from moephoto_amd import _lib
+    _lib.require_device()
+    return torch.device('cuda:0')
+
+
+_models = {}
+
+
+def module_for(key, precision='fp16', dtype=torch.float32):
+    from moephoto_amd import models
+    ctor = {'net2x': models.Net2x, 'net3x': models.Net3x, 'net4x': models.Net4x, 'netdn': models.NetDN, 'sedn': models.SEDN,
+            'lite2': lambda: models.Net(2), 'lite4': lambda: models.Net(4), 'lite8': lambda: models.Net(8)}[gd.MODELS[key][0]]
+    k = (key, precision)
+    if k not in _models:
+        m = ctor()
+        m.load_state_dict({n: torch.from_numpy(v) for n, v in gd.state_dict_for(key, load_state_dict_file).items()})
+        m.eval()
+        m.precision = precision
+        _models[k] = m
+    return _models[k].to(dtype=dtype, device='cuda:0')
+
+
+NET_KEYS = [os.path.basename(p)[:-4] for p in sorted(glob.glob(os.path.join(G, 'nets', '*.npz')))]
+
+
+@pytest.mark.parametrize('key', NET_KEYS)
+def test_net_forward_vs_reference_golden(key, dev):
+    """Single-tile forward of every net family on the seeded inputs of tests/golden/nets (reference outputs)."""
+    z = np.load(os.path.join(G, 'nets', key + '.npz'))
+    h, w = [int(v) for v in z['hw']]
+    seed = int(z['seed'])
+    m = module_for(key)
+    for kind, tol in (('natural', TOL_NATURAL), ('noise', TOL_NOISE_FP16)):
+        x = gd.natural_image(seed, (3, h, w))[:, None] if kind == 'natural' else gd.noise_image(seed, (3, 1, h, w))
+        y = m(torch.from_numpy(x).to(dev))[-1].float().cpu().numpy()
+        err = np.abs(y - z['y_' + kind]).max()
+        assert err <= tol, '{} {}: {:.3e}'.format(key, kind, err)
+
+
+@pytest.mark.parametrize('key', ['a2', 'a4', 'dn_lite5', 'l25', 'lite2'])
+def test_net_forward_exact_mode_noise(key, dev):
+    z = np.load(os.path.join(G, 'nets', key + '.npz'))
+    h, w = [int(v) for v in z['hw']]
+    m = module_for(key, 'fp16x3')
+    x = gd.noise_image(int(z['seed']), (3, 1, h, w))
+    y = m(torch.from_numpy(x).to(dev))[-1].float().cpu().numpy()
+    assert np.abs(y - z['y_noise']).max() <= TOL_X3
+
+
+@pytest.mark.parametrize('key', ['a2', 'dn_lite10', 'l25', 'lite4'])
+def test_layer_by_layer(key, dev):
+    """Named intermediates (debug taps) against the oracle's, to localise a failing kernel."""
+    arch = gd.MODELS[key][0]
+    sd = gd.state_dict_for(key, load_state_dict_file)
+    x = gd.natural_image(3, (2, 24, 40))[:, None]
+    taps = {}
+    onets.forward(arch, sd, x, 'torch', taps)
+    m = module_for(key).set_debug(True)
+    m(torch.from_numpy(x).to(dev))
+    torch.cuda.synchronize()
+    for name, want in taps.items():
+        got = m.debug_tap(name)
+        want = want.numpy()
+        scale = max(1.0, float(np.abs(want).max()))
+        assert got.shape == want.shape, name
+        assert np.abs(got - want).max() <= 4e-3 * scale, '{} {}: {:.3e}'.format(key, name, np.abs(got - want).max())
+    m.set_debug(False)
+
+
+def test_ragged_and_tiny_tiles(dev):
+    """Edge tiles the planner produces: 8x16 up to non-multiples of the 8x32 patch; fp16 and fp32 I/O; strided views."""
+    sd = gd.state_dict_for('a2', load_state_dict_file)
+    m32 = module_for('a2')
+    for (h, w) in ((8, 16), (8, 8), (16, 88), (40, 33 * 8), (88, 192), (24, 24)):
+        big = gd.natural_image(9, (3, h + 6, w + 10))
+        xs = torch.from_numpy(big).to(dev)[:, None, 3:3 + h, 5:5 + w]            # non-contiguous slice view, like doCrop's
+        want = onets.forward('net2x', sd, np.ascontiguousarray(big[:, None, 3:3 + h, 5:5 + w])).numpy()
+        y = m32(xs)[-1]
+        assert y.shape == (3, 1, 2 * h, 2 * w) and y.dtype == torch.float32
+        assert np.abs(y.cpu().numpy() - want).max() <= TOL_NATURAL, (h, w)
+    m16 = module_for('a2', dtype=torch.float16)
+    x = gd.natural_image(9, (4, 1, 40, 48))                                       # 4 planes: RGBA through SR
+    y = m16(torch.from_numpy(x).to(dev).half())[-1]
+    assert y.dtype == torch.float16
+    want = onets.forward('net2x', sd, x).numpy()
+    assert np.abs(y.float().cpu().numpy() - want).max() <= 2e-3                   # + fp16 rounding of input and output
+
+
+STITCH_ONLY = [os.path.basename(p)[:-4] for p in sorted(glob.glob(os.path.join(G, 'stitch_only', '*.npz')))]
+
+
+@pytest.mark.parametrize('name', STITCH_ONLY)
+def test_stitch_kernel_golden(name, dev):
+    """moe_stitch alone: seeded tile results in, the reference's stitched canvas out."""
+    import ctypes
+    from moephoto_amd import _lib
+    from moephoto_amd.imageProcess import TilePlan
+    z = np.load(os.path.join(G, 'stitch_only', name + '.npz'))
+    shape = tuple(int(v) for v in z['shape'])
+    sc = int(z['sc'])
+    pl = TilePlan(shape, 1 << 40, 1e-3, int(z['pad']), sc, int(z['align']), int(z['crop']))
+    C = shape[0]
+    pool = np.empty(pl.pool_elems(C), np.float32)
+    off = pl.tile_offsets(C)
+    for k, t in enumerate(pl.tiles):
+        r = np.random.default_rng(9000 + k).random((C, 1, (t[1] - t[0]) * sc, (t[3] - t[2]) * sc), dtype=np.float32)
+        pool[off[k]:off[k] + r.size] = r.reshape(-1)
+    pool_d = torch.from_numpy(pool).to(dev)
+    out = torch.empty((C, pl.outH, pl.outW), dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().moe_stitch(pl._h, 0, pool_d.data_ptr(), None, C, out.data_ptr(), _lib.F32, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert np.abs(out.cpu().numpy() - z['y']).max() <= 1e-6
+
+
+def _opt_sr(model, scale, crop, ensemble=0, precision='fp16', fp16_io=False):
+    from moephoto_amd import imageProcess as ip, runSR
+    from moephoto_amd.config import config
+    config.modelRoot, config.crop_sr, config.fp16, config.deviceId = gd.ZOO, crop, fp16_io, 0
+    key = model + str(scale)
+    ip.modelCache.pop('SR' + key, None)
+    if gd.MODELS[key][1] is None:      # a3 / a4: synthetic weights, written in the zoo's own format
+        from moephoto_amd.weights import save_state_dict_file
+        path = os.path.join('/tmp', 'moe_synth_{}.pth'.format(key))
+        save_state_dict_file(gd.synth_state_dict(key, load_state_dict_file), path)
+        runSR.mode_switch[key] = (path, runSR.mode_switch[key][1])
+    opt = runSR.getOpt({'op': 'SR', 'model': model, 'scale': scale, 'ensemble': ensemble})
+    opt.modelCached.set_precision(precision)
+    return opt
+
+
+STITCHED = [('a2_natural', 'a', 2, TOL_NATURAL), ('a2_noise', 'a', 2, TOL_NOISE_FP16), ('a4_natural', 'a', 4, TOL_NATURAL),
+            ('lite2_natural', 'lite', 2, TOL_NATURAL), ('a2_onetile_pad', 'a', 2, TOL_NATURAL)]
+
+
+@pytest.mark.parametrize('name,model,scale,tol', STITCHED)
+def test_docrop_vs_reference_golden(name, model, scale, tol, dev):
+    """The whole device-resident doCrop (plugin table -> zoo file -> tile gather -> net -> stitch) on the
+    reference's multi-tile goldens."""
+    from moephoto_amd import runSR
+    z = np.load(os.path.join(G, 'stitched', name + '.npz'))
+    shape = tuple(int(v) for v in z['shape'])
+    x = gd.noise_image(101, shape) if str(z['kind']) == 'noise' else gd.natural_image(101, shape)
+    opt = _opt_sr(model, scale, int(z['crop']))
+    y = runSR.sr(opt)(torch.from_numpy(x).to(dev))
+    assert tuple(y.shape) == z['y'].shape
+    assert np.abs(y.float().cpu().numpy() - z['y']).max() <= tol
+    if 'noise' in name:
+        opt = _opt_sr(model, scale, int(z['crop']), precision='fp16x3')
+        y = runSR.sr(opt)(torch.from_numpy(x).to(dev))
+        assert np.abs(y.float().cpu().numpy() - z['y']).max() <= TOL_X3
+
+
+def test_ensemble_golden(dev):
+    from moephoto_amd import runSR
+    z = np.load(os.path.join(G, 'stitched', 'a2_ens3.npz'))
+    x = gd.natural_image(101, (3, 60, 72))
+    opt = _opt_sr('a', 2, 48, ensemble=3)
+    y = runSR.sr(opt)(torch.from_numpy(x).to(dev))
+    assert np.abs(y.float().cpu().numpy() - z['y']).max() <= TOL_NATURAL
+    z = np.load(os.path.join(G, 'stitched', 'a2_ens7.npz'))
+    x = gd.noise_image(101, (3, 52, 60))
+    opt = _opt_sr('a', 2, 48, ensemble=7, precision='fp16x3')
+    y = runSR.sr(opt)(torch.from_numpy(x).to(dev))
+    assert np.abs(y.float().cpu().numpy() - z['y']).max() <= TOL_X3
+
+
+def test_dn_rgbfilter_golden(dev):
+    from moephoto_amd import imageProcess as ip, runDN
+    from moephoto_amd.config import config
+    config.modelRoot, config.crop_dn, config.crop_dns, config.fp16 = gd.ZOO, 48, 48, False
+    ip.modelCache.clear()
+    z = np.load(os.path.join(G, 'stitched', 'dn5_rgba_s06.npz'))
+    x = gd.natural_image(101, (4, 64, 80))
+    opt = runDN.getOpt({'op': 'DN', 'model': 'lite5', 'strength': 0.6})
+    y = ip.RGBFilter(opt)(torch.from_numpy(x).to(dev))
+    assert tuple(y.shape) == (4, 64, 80)
+    assert np.abs(y.float().cpu().numpy() - z['y']).max() <= TOL_NATURAL
+    z = np.load(os.path.join(G, 'stitched', 'dn10_noise.npz'))
+    opt = runDN.getOpt({'op': 'DN', 'model': 'lite10'})
+    y = ip.RGBFilter(opt)(torch.from_numpy(gd.noise_image(101, (3, 100, 140))).to(dev))
+    assert np.abs(y.float().cpu().numpy() - z['y']).max() <= TOL_NOISE_FP16
+    # SEDN (l25, synthetic weights written in the zoo format)
+    from moephoto_amd.weights import save_state_dict_file
+    path = '/tmp/moe_synth_l25.pth'
+    save_state_dict_file(gd.synth_state_dict('l25', load_state_dict_file), path)
+    runDN.mode_switch['25'] = (path,) + tuple(runDN.mode_switch['25'][1:])
+    z = np.load(os.path.join(G, 'stitched', 'l25_natural.npz'))
+    opt = runDN.getOpt({'op': 'DN', 'model': '25'})
+    y = ip.RGBFilter(opt)(torch.from_numpy(gd.natural_image(101, (3, 60, 72))).to(dev))
+    assert np.abs(y.float().cpu().numpy() - z['y']).max() <= 2e-3     # 98 fp16 layers deep
+
+
+def test_e2e_uint8_config1(dev):
+    """Config 1: 256x256 RGB uint8 -> toTorch -> a2 x2 -> toFloat -> toOutput -> uint8, vs the reference's bytes."""
+    from moephoto_amd import imageProcess as ip, runSR
+    z = np.load(os.path.join(G, 'e2e', 'a2_256_natural.npz'))
+    img = gd.to_u8(gd.natural_image(7, (3, 256, 256)))
+    opt = _opt_sr('a', 2, 0)
+    x = ip.toTorch(8, torch.float32, dev)(img)
+    assert np.array_equal(x.cpu().numpy(), oio.to_float_image(img))              # the /255 edge is bit exact
+    y = runSR.sr(opt)(x)
+    out = ip.toOutput(8)(ip.toFloat(y))
+    assert out.dtype == np.uint8 and out.shape == (512, 512, 3)
+    d = np.abs(out.astype(np.int32) - z['out'].astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 0.1                                  # 1e-3 * 256 < 1 level
+    assert np.array_equal(out, oio.to_output(oio.to_hwc(y.float().cpu().numpy())))  # the quantiser itself is exact
+    v = torch.tensor([[[0.998, 0.5, -0.2, 1.7, 0.00390625, 0.0039]]], device=dev)
+    assert ip.toOutput(8)(v).reshape(-1).tolist() == [255, 128, 0, 255, 1, 0]
+
+
+def test_dropin_protocol_reference_loop(dev):
+    """The reference's own doCrop loop (imageProcess.py:157-172) restated here with torch ops, calling the
+    engine-backed module exactly like Option.__call__ does: per tile, on a slice view, list result."""
+    from moephoto_amd.imageProcess import Option, initModel
+    from moephoto_amd.models import Net2x
+    from moephoto_amd.config import config
+    config.fp16, config.deviceId = False, 0
+    sd = gd.state_dict_for('a2', load_state_dict_file)
+    opt = Option()
+    opt.modelDef = Net2x
+    opt.modelCached = initModel(opt, {k: torch.from_numpy(v) for k, v in sd.items()})
+    z = np.load(os.path.join(G, 'stitched', 'a2_natural.npz'))
+    x = torch.from_numpy(gd.natural_image(101, (3, 100, 140))).to(dev)
+    pl = oplanner.prepare((3, 100, 140), 1 << 40, 1e-3, 5, 2, 8, 48)
+    ramp = torch.from_numpy(oplanner.blend_ramp(pl.pad_sc)).to(dev)
+    out = torch.full((3, 200, 280), float('nan'), device=dev)
+    xu = x.unsqueeze(1)
+
+    def blend(r, ex, lt, pad, dim, b):
+        l = r.shape[dim]
+        lt = l + lt if lt < 0 else lt
+        if lt < 1:
+            return r, ex
+        st = lt - pad
+        rb, rc = r.narrow(dim, st, pad), r.narrow(dim, lt, l - lt)
+        eb = ex.narrow(dim, st, pad)
+        return torch.cat([eb + b * (rb - eb), rc], dim), ex.narrow(dim, st, l - st)
+    for (top, bottom, left, right, tt, lt, bsc, rsc) in pl.tiles:
+        s = xu[..., top:bottom, left:right]
+        r = opt(s).squeeze(1)
+        t = out[..., top * 2:bsc, left * 2:rsc]
+        q, t2 = blend(r, t, tt, pl.pad_sc, -2, ramp.view(-1, 1))
+        q, _ = blend(q, t2, lt, pl.pad_sc, -1, ramp.view(1, -1))
+        hh, ww = q.shape[-2:]
+        out[..., bsc - hh:bsc, rsc - ww:rsc] = q
+    assert np.abs(out.cpu().numpy() - z['y']).max() <= TOL_NATURAL
+
+
+def test_full_size_properties_config2(dev):
+    """BASELINE config 2 at full size (1080p -> 7680x4320, a4-synth, 256-px tiles, 40 tiles), checked through
+    properties that do not need a full CPU run:
+      * two full-size tiles (an interior 256x256 one and the ragged 88x192 corner) against the oracle,
+      * the stitched canvas equals the oracle's closed-form fold of the engine's OWN tile results,
+      * batching invariance: 1 tile per launch == 4 tiles per launch, bit for bit,
+      * sharding invariance: tiles computed as 3 shards land in the same pool, bit for bit."""
+    import ctypes
+    from moephoto_amd import _lib, imageProcess as ip
+    from moephoto_amd.config import config
+    opt = _opt_sr('a', 4, 256)
+    x = gd.natural_image(0, (3, 1080, 1920))
+    xd = torch.from_numpy(x).to(dev)
+    plan = ip._plan_for(opt, xd.shape)
+    assert plan.n_tiles == 40
+    L, model = _lib.lib(), opt.modelCached
+    stream = torch.cuda.current_stream().cuda_stream
+    sC, sH, sW = xd.stride()
+
+    def run(per_batch, shards=1):
+        pool = torch.zeros(plan.pool_elems(3), dtype=torch.float32, device=dev)
+        out = torch.empty((3, plan.outH, plan.outW), dtype=torch.float32, device=dev)
+        for si in range(shards):
+            _lib.check(L.moe_run_plan_ex(model._h, plan._h, xd.data_ptr(), _lib.F32, sC, sH, sW, out.data_ptr(), _lib.F32, per_batch,
+                                         ctypes.c_void_p(pool.data_ptr()), si, shards, 1 if si == shards - 1 else 0, stream))
+        torch.cuda.synchronize()
+        return pool, out
+    pool4, out4 = run(4)
+    pool1, out1 = run(1)
+    assert torch.equal(pool1, pool4) and torch.equal(out1, out4)
+    pool3, out3 = run(4, shards=3)
+    assert torch.equal(pool3, pool4) and torch.equal(out3, out4)
+    off = plan.tile_offsets(3)
+    sd = gd.state_dict_for('a4', load_state_dict_file)
+    for k in (9, 39):
+        top, bottom, left, right = plan.tiles[k][:4]
+        want = onets.forward('net4x', sd, np.ascontiguousarray(x[:, None, top:bottom, left:right])).numpy()[:, 0]
+        got = pool4[off[k]:off[k] + want.size].reshape(want.shape).cpu().numpy()
+        assert np.abs(got - want).max() <= TOL_NATURAL, k
+    pl = oplanner.prepare((3, 1080, 1920), 1 << 40, 1e-3, 5, 4, 8, 256)
+    hp = pool4.cpu().numpy()
+    tiles = [hp[off[k]:off[k] + 3 * (t[1] - t[0]) * (t[3] - t[2]) * 16].reshape(3, (t[1] - t[0]) * 4, (t[3] - t[2]) * 4) for k, t in enumerate(pl.tiles)]
+    want = ostitch.fold_stitch(tiles, pl, 4)
+    assert np.abs(out4.cpu().numpy() - want).max() <= 1e-6
