@@ -95,6 +95,12 @@ int64_t moe_net_workspace_bytes(const moe_net* net, int B, int h, int w);
 int moe_net_forward(moe_net* net, const void* x, int x_dtype, int B, int h, int w,
                     int64_t sB, int64_t sH, int64_t sW, const int64_t* x_off,
                     void* y, int y_dtype, const int64_t* y_off, void* stream);
+/* Live kernel timing for the roofline report: bracket every MFMA-conv launch whose layer key contains
+ * `layer_substring` (e.g. "up1": the 64->256 upsampler convs at 2x resolution) with hipEvents on the launch
+ * stream.  NULL / "" disables.  moe_net_get_profile waits for the recorded events, returns the summed kernel time,
+ * the number of launches and their algorithmic FLOPs (2*pixels*Cout*Cin*taps, real channel counts), and resets. */
+int moe_net_set_profile(moe_net* net, const char* layer_substring);
+int moe_net_get_profile(moe_net* net, double* total_ms, int64_t* launches, double* flops);
 /* keep fp32 copies of named intermediates during forwards (slow; debugging / layer-by-layer parity only) */
 int moe_net_set_debug(moe_net* net, int enable);
 /* copy a named intermediate of the LAST forward to host as fp32 NCHW (debug / layer-by-layer parity);

@@ -47,6 +47,8 @@ def lib():
         'moe_net_finalize': (c_int, [c_vp, c_int, c_int]),
         'moe_net_workspace_bytes': (c_i64, [c_vp, c_int, c_int, c_int]),
         'moe_net_forward': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_int, c_vp, c_vp]),
+        'moe_net_set_profile': (c_int, [c_vp, ctypes.c_char_p]),
+        'moe_net_get_profile': (c_int, [c_vp, P(c_dbl), P(c_i64), P(c_dbl)]),
         'moe_net_set_debug': (c_int, [c_vp, c_int]),
         'moe_net_debug_tap': (c_i64, [c_vp, ctypes.c_char_p, c_vp, c_i64, P(c_i64), c_vp]),
         'moe_plan_create': (c_int, [P(c_i64), c_dbl, c_dbl, c_int, c_int, c_int, c_int, P(c_vp)]),
@@ -73,7 +75,7 @@ def lib():
 
 EXPORTS = ['moe_last_error', 'moe_abi_version', 'moe_device_count', 'moe_net_create', 'moe_net_destroy', 'moe_net_scale',
            'moe_net_num_params', 'moe_net_param_info', 'moe_net_set_param', 'moe_net_finalize', 'moe_net_workspace_bytes',
-           'moe_net_forward', 'moe_net_set_debug', 'moe_net_debug_tap', 'moe_plan_create', 'moe_plan_destroy', 'moe_plan_info',
+           'moe_net_forward', 'moe_net_set_profile', 'moe_net_get_profile', 'moe_net_set_debug', 'moe_net_debug_tap', 'moe_plan_create', 'moe_plan_destroy', 'moe_plan_info',
            'moe_plan_tiles', 'moe_plan_ramp', 'moe_plan_pool_elems', 'moe_plan_tile_offsets', 'moe_stitch', 'moe_run_plan',
            'moe_run_plan_ex', 'moe_to_float', 'moe_to_output']
 

@@ -92,6 +92,11 @@ struct moe_net {
     char* ws = nullptr;
     size_t ws_bytes = 0;
     int max_groups = 256;
+    // live kernel timing of selected conv layers (bench.py's roofline leg): hipEvent pairs on the launch stream
+    std::string prof_key;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
+    size_t prof_used = 0;
+    double prof_flops = 0;
     // debug taps
     bool debug = false;
     struct Tap { float* dev = nullptr; int64_t shape[4] = {0, 0, 0, 0}; };
@@ -443,7 +448,23 @@ struct Fwd {
         if (G > items) G = (int)items;
         a.G = G;
         a.slope = L.slope; a.scale = L.scale;
-        if (!x3) { launch_conv_mfma(a, L.taps, L.nseg, s); return; }
+        if (!x3) {
+            const bool prof = !n.prof_key.empty() && key.find(n.prof_key) != std::string::npos;
+            if (prof) {
+                if (n.prof_used == n.prof_ev.size()) {
+                    hipEvent_t e0, e1;
+                    if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) n.prof_ev.push_back({e0, e1});
+                }
+                if (n.prof_used < n.prof_ev.size()) (void)hipEventRecord(n.prof_ev[n.prof_used].first, s);
+            }
+            launch_conv_mfma(a, L.taps, L.nseg, s);
+            if (prof && n.prof_used < n.prof_ev.size()) {
+                (void)hipEventRecord(n.prof_ev[n.prof_used].second, s);
+                n.prof_used += 1;
+                n.prof_flops += 2.0 * (double)B * H * W * L.cout * L.cin * L.taps;   // algorithmic (real channel counts)
+            }
+            return;
+        }
         // hi/lo split: (w_lo * a_hi) -> acc32,  += (w_hi * a_lo),  then (w_hi * a_hi) + acc32/2048 and the epilogue
         a.acc32 = acc32;
         ConvArgs p1 = a; p1.wpk = L.per_plane ? plane_w_lo : blob<half_t>(L.w_lo); p1.acc_mode = 1; p1.res = nullptr; p1.bias = nullptr;
@@ -764,6 +785,7 @@ void moe_net_destroy(moe_net* n)
     if (n->blob) (void)hipFree(n->blob);
     if (n->ws) (void)hipFree(n->ws);
     for (auto& t : n->taps) if (t.second.dev) (void)hipFree(t.second.dev);
+    for (auto& ev : n->prof_ev) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     delete n;
 }
 
@@ -847,6 +869,31 @@ int moe_net_forward(moe_net* n, const void* x, int x_dtype, int B, int h, int w,
     int rc = forward_dev(*n, x, x_dtype, B, h, w, sB, sH, sW, xo, y, y_dtype, yo, s);
     if (tmp) { (void)hipStreamSynchronize(s); (void)hipFree(tmp); }
     return rc;
+}
+
+int moe_net_set_profile(moe_net* n, const char* layer_substring)
+{
+    if (!n) return fail(MOE_EINVAL, "moe_net_set_profile: NULL net");
+    n->prof_key = layer_substring ? layer_substring : "";
+    n->prof_used = 0;
+    n->prof_flops = 0;
+    return MOE_OK;
+}
+
+int moe_net_get_profile(moe_net* n, double* total_ms, int64_t* launches, double* flops)
+{
+    if (!n || !total_ms || !launches || !flops) return fail(MOE_EINVAL, "moe_net_get_profile: NULL argument");
+    double ms = 0;
+    for (size_t i = 0; i < n->prof_used; ++i) {
+        HIP_TRY(hipEventSynchronize(n->prof_ev[i].second));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, n->prof_ev[i].first, n->prof_ev[i].second));
+        ms += t;
+    }
+    *total_ms = ms; *launches = (int64_t)n->prof_used; *flops = n->prof_flops;
+    n->prof_used = 0;
+    n->prof_flops = 0;
+    return MOE_OK;
 }
 
 int moe_net_set_debug(moe_net* n, int enable)

@@ -181,6 +181,16 @@ class EngineModule(object):
 
     __call__ = forward
 
+    # ---- live kernel timing (bench.py roofline leg) -----------------------------------------------------
+    def set_profile(self, layer_substring):
+        _lib.check(_lib.lib().moe_net_set_profile(self._h, layer_substring.encode() if layer_substring else None))
+        return self
+
+    def get_profile(self):
+        ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+        _lib.check(_lib.lib().moe_net_get_profile(self._h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)))
+        return dict(total_ms=ms.value, launches=n.value, flops=fl.value)
+
     # ---- debugging -----------------------------------------------------------------------------------
     def set_debug(self, flag=True):
         _lib.check(_lib.lib().moe_net_set_debug(self._h, 1 if flag else 0))
