@@ -47,7 +47,10 @@ class EngineModule(object):
         self._dtype = torch.float32
         self._finalized_key = None
         self.training = False
-        self.precision = os.environ.get('MOE_PRECISION', 'fp16')
+        # 'auto': fp16 operands for the deep 64-channel nets (Net2x/3x/4x, SEDN: <= 1e-3 vs the fp32 reference on
+        # natural images), hi/lo-split operands for the cheap 48-channel nets (NetDN, lite*) whose fp16 activation
+        # rounding alone costs 1-3e-3.  MOE_PRECISION=fp16 forces the single-pass mode everywhere.
+        self.precision = os.environ.get('MOE_PRECISION', 'auto')
 
     def __del__(self):
         try:
@@ -146,19 +149,24 @@ class EngineModule(object):
         return self.to(device=torch.device('cuda', device if device is not None else torch.cuda.current_device()))
 
     def set_precision(self, precision):
-        if precision not in _lib.PRECISIONS:
-            raise ValueError('precision must be one of {}'.format(sorted(_lib.PRECISIONS)))
+        if precision != 'auto' and precision not in _lib.PRECISIONS:
+            raise ValueError('precision must be "auto" or one of {}'.format(sorted(_lib.PRECISIONS)))
         self.precision = precision
         if self._device is not None:
             self._finalize()
         return self
 
+    def resolved_precision(self):
+        if self.precision == 'auto':
+            return 'fp16x3' if self.ARCH in (_lib.ARCH_NETDN, _lib.ARCH_LITE) else 'fp16'
+        return self.precision
+
     def _finalize(self):
-        key = (self._device.index, self.precision)
+        key = (self._device.index, self.resolved_precision())
         if self._finalized_key == key:
             return
         _lib.require_device()
-        _lib.check(_lib.lib().moe_net_finalize(self._h, self._device.index, _lib.PRECISIONS[self.precision]))
+        _lib.check(_lib.lib().moe_net_finalize(self._h, self._device.index, _lib.PRECISIONS[self.resolved_precision()]))
         self._finalized_key = key
 
     # ---- forward -------------------------------------------------------------------------------------

@@ -2,10 +2,15 @@
 Needs a HIP device: `pytest -m gpu`.
 
 Tolerances (max-abs, compared in fp32; north star: 1e-3 vs the reference's PyTorch-CPU fp32 path):
-  precision 'fp16'   (fp16 MFMA operands, fp32 accumulate)  natural-image-like input: 1e-3
-                                                             white-noise input (adversarial: outputs span
-                                                             [-0.6, 1.8]):              5e-3
-  precision 'fp16x3' (hi/lo split operands, 3 MFMA passes)  any input:                  1e-3 (observed ~1e-5)
+  precision 'auto' (the product default):  fp16 MFMA operands + fp32 accumulate for Net2x/3x/4x and SEDN,
+      hi/lo-split operands (3 MFMA passes) for the 48-channel NetDN / lite nets
+                                  natural-image-like input:   1e-3   every family
+                                  white-noise input:          1e-3   NetDN / lite (split operands, observed ~1e-6)
+                                                              5e-3   Net*x / SEDN (adversarial for fp16 operands: the
+                                                                     outputs span [-0.6, 1.8]; measured 0.7-2.5e-3)
+  precision 'fp16x3' forced:      any input, any family:      1e-3   (observed ~1e-6)
+  precision 'fp16' forced (= the arithmetic of the reference's own GPU fp16 mode, fp32 accumulate on top):
+                                  natural: 1e-3 Net*x/SEDN, 2.5e-3 NetDN, 6e-3 lite;  noise: 1e-2
   stitch kernel alone (fp32 in/out): 1e-6 (the ramp's sigmoid differs from torch's by <= 1 ulp)
 """
 import glob
@@ -35,7 +40,7 @@ def dev():
 _models = {}
 
 
-def module_for(key, precision='fp16', dtype=torch.float32):
+def module_for(key, precision='auto', dtype=torch.float32):
     from moephoto_amd import models
     ctor = {'net2x': models.Net2x, 'net3x': models.Net3x, 'net4x': models.Net4x, 'netdn': models.NetDN, 'sedn': models.SEDN,
             'lite2': lambda: models.Net(2), 'lite4': lambda: models.Net(4), 'lite8': lambda: models.Net(8)}[gd.MODELS[key][0]]
@@ -59,7 +64,24 @@ def test_net_forward_vs_reference_golden(key, dev):
     h, w = [int(v) for v in z['hw']]
     seed = int(z['seed'])
     m = module_for(key)
-    for kind, tol in (('natural', TOL_NATURAL), ('noise', TOL_NOISE_FP16)):
+    split = m.resolved_precision() == 'fp16x3'
+    for kind, tol in (('natural', TOL_NATURAL), ('noise', TOL_X3 if split else TOL_NOISE_FP16)):
+        x = gd.natural_image(seed, (3, h, w))[:, None] if kind == 'natural' else gd.noise_image(seed, (3, 1, h, w))
+        y = m(torch.from_numpy(x).to(dev))[-1].float().cpu().numpy()
+        err = np.abs(y - z['y_' + kind]).max()
+        assert err <= tol, '{} {}: {:.3e}'.format(key, kind, err)
+
+
+@pytest.mark.parametrize('key', NET_KEYS)
+def test_net_forward_fast_mode_documented_error(key, dev):
+    """Forced single-pass fp16 operands: what fp16 activation/weight rounding costs per family (documented bound)."""
+    z = np.load(os.path.join(G, 'nets', key + '.npz'))
+    h, w = [int(v) for v in z['hw']]
+    seed = int(z['seed'])
+    arch = gd.MODELS[key][0]
+    tol_nat = 1e-3 if arch in ('net2x', 'net3x', 'net4x', 'sedn') else (2.5e-3 if arch == 'netdn' else 6e-3)
+    m = module_for(key, 'fp16')
+    for kind, tol in (('natural', tol_nat), ('noise', 1e-2)):
         x = gd.natural_image(seed, (3, h, w))[:, None] if kind == 'natural' else gd.noise_image(seed, (3, 1, h, w))
         y = m(torch.from_numpy(x).to(dev))[-1].float().cpu().numpy()
         err = np.abs(y - z['y_' + kind]).max()
@@ -73,7 +95,7 @@ def test_net_forward_exact_mode_noise(key, dev):
     m = module_for(key, 'fp16x3')
     x = gd.noise_image(int(z['seed']), (3, 1, h, w))
     y = m(torch.from_numpy(x).to(dev))[-1].float().cpu().numpy()
-    assert np.abs(y - z['y_noise']).max() <= TOL_X3
+    assert np.abs(y - z['y_noise']).max() <= 2e-5      # far inside the 1e-3 bar
 
 
 @pytest.mark.parametrize('key', ['a2', 'dn_lite10', 'l25', 'lite4'])
@@ -141,7 +163,7 @@ def test_stitch_kernel_golden(name, dev):
     assert np.abs(out.cpu().numpy() - z['y']).max() <= 1e-6
 
 
-def _opt_sr(model, scale, crop, ensemble=0, precision='fp16', fp16_io=False):
+def _opt_sr(model, scale, crop, ensemble=0, precision='auto', fp16_io=False):
     from moephoto_amd import imageProcess as ip, runSR
     from moephoto_amd.config import config
     config.modelRoot, config.crop_sr, config.fp16, config.deviceId = gd.ZOO, crop, fp16_io, 0
@@ -207,7 +229,7 @@ def test_dn_rgbfilter_golden(dev):
     z = np.load(os.path.join(G, 'stitched', 'dn10_noise.npz'))
     opt = runDN.getOpt({'op': 'DN', 'model': 'lite10'})
     y = ip.RGBFilter(opt)(torch.from_numpy(gd.noise_image(101, (3, 100, 140))).to(dev))
-    assert np.abs(y.float().cpu().numpy() - z['y']).max() <= TOL_NOISE_FP16
+    assert np.abs(y.float().cpu().numpy() - z['y']).max() <= TOL_X3     # NetDN runs with split operands by default
     # SEDN (l25, synthetic weights written in the zoo format)
     from moephoto_amd.weights import save_state_dict_file
     path = '/tmp/moe_synth_l25.pth'
@@ -216,7 +238,7 @@ def test_dn_rgbfilter_golden(dev):
     z = np.load(os.path.join(G, 'stitched', 'l25_natural.npz'))
     opt = runDN.getOpt({'op': 'DN', 'model': '25'})
     y = ip.RGBFilter(opt)(torch.from_numpy(gd.natural_image(101, (3, 60, 72))).to(dev))
-    assert np.abs(y.float().cpu().numpy() - z['y']).max() <= 2e-3     # 98 fp16 layers deep
+    assert np.abs(y.float().cpu().numpy() - z['y']).max() <= TOL_NATURAL
 
 
 def test_e2e_uint8_config1(dev):
