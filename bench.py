@@ -48,7 +48,7 @@ def main():
     ap.add_argument('--precision', default='fp16', choices=['fp16', 'fp16x3'])
     ap.add_argument('--tiles-per-batch', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-tiles', type=int, default=2, help='tiles of the frame timed on the CPU oracle')
+    ap.add_argument('--cpu-tiles', type=int, default=1, help='tiles of the frame timed on the CPU oracle')
     args = ap.parse_args()
 
     import numpy as np
