@@ -46,6 +46,9 @@ struct ConvArgs {
 void launch_conv_mfma(const ConvArgs& a, int taps, int nseg, hipStream_t s);
 int conv_mfma_max_groups();  // persistent workgroups the device holds (1 per CU)
 hipError_t conv_mfma_init(); // raise dynamic-LDS limits once per process
+// 3x3 / 64-channel specialisation with the two-group ping-pong schedule (conv3x3_pp.hip)
+void launch_conv3x3_pp(const ConvArgs& a, hipStream_t s);
+hipError_t conv3x3_pp_init();
 
 struct DirectConvArgs {
     const half_t* in; half_t* out; const half_t* res;

@@ -448,6 +448,9 @@ struct Fwd {
         if (G > items) G = (int)items;
         a.G = G;
         a.slope = L.slope; a.scale = L.scale;
+        static const bool force_v1 = [] { const char* e = getenv("MOE_CONV_IMPL"); return e && !strcmp(e, "v1"); }();
+        const bool pp = L.taps == 9 && L.nseg == 1 && !L.per_plane && !force_v1;
+        auto launch = [&](const ConvArgs& ca) { if (pp) launch_conv3x3_pp(ca, s); else launch_conv_mfma(ca, L.taps, L.nseg, s); };
         if (!x3) {
             const bool prof = !n.prof_key.empty() && key.find(n.prof_key) != std::string::npos;
             if (prof) {
@@ -457,7 +460,7 @@ struct Fwd {
                 }
                 if (n.prof_used < n.prof_ev.size()) (void)hipEventRecord(n.prof_ev[n.prof_used].first, s);
             }
-            launch_conv_mfma(a, L.taps, L.nseg, s);
+            launch(a);
             if (prof && n.prof_used < n.prof_ev.size()) {
                 (void)hipEventRecord(n.prof_ev[n.prof_used].second, s);
                 n.prof_used += 1;
@@ -468,11 +471,11 @@ struct Fwd {
         // hi/lo split: (w_lo * a_hi) -> acc32,  += (w_hi * a_lo),  then (w_hi * a_hi) + acc32/2048 and the epilogue
         a.acc32 = acc32;
         ConvArgs p1 = a; p1.wpk = L.per_plane ? plane_w_lo : blob<half_t>(L.w_lo); p1.acc_mode = 1; p1.res = nullptr; p1.bias = nullptr;
-        launch_conv_mfma(p1, L.taps, L.nseg, s);
+        launch(p1);
         ConvArgs p2 = a; p2.in = in.lo; p2.acc_mode = 2; p2.res = nullptr; p2.bias = nullptr;
-        launch_conv_mfma(p2, L.taps, L.nseg, s);
+        launch(p2);
         ConvArgs p3 = a; p3.acc_mode = 3; p3.out_lo = out.lo; p3.res_lo = res ? res->lo : nullptr;
-        launch_conv_mfma(p3, L.taps, L.nseg, s);
+        launch(p3);
     }
 };
 
