@@ -27,6 +27,7 @@ struct ConvArgs {
     const half_t* wpk;    // packed weight fragments [wbatch][chunk][frag][lane][8]
     const float* bias;    // [nchunks*64] in packed output-channel order, or nullptr
     const half_t* zero;   // >= 256 B of zeros (out-of-image taps are redirected here)
+    half_t* trash;        // >= 1 KiB write-only scratch (predicated-off stores of the branch-free epilogue land here)
     // FP16X3 (hi/lo split operands): partial products are combined through an fp32 side buffer
     half_t* out_lo;       // low part of the output activation ((v - hi) * 2^11), or nullptr
     const half_t* res_lo; // low part of the residual, or nullptr
@@ -41,6 +42,7 @@ struct ConvArgs {
     int px, py;           // patches along x / y
     float slope;          // PReLU / LeakyReLU slope (1: identity)
     float scale;          // multiplier applied before the activation (ARSB ScaleLayer); 1: none
+    int dbg;              // timing ablations (MOE_DBG env; results are wrong when set): 1 no patch DMA, 2 no MFMA, 4 no stores, 8 no epilogue
 };
 
 void launch_conv_mfma(const ConvArgs& a, int taps, int nseg, hipStream_t s);
@@ -48,6 +50,9 @@ int conv_mfma_max_groups();  // persistent workgroups the device holds (1 per CU
 hipError_t conv_mfma_init(); // raise dynamic-LDS limits once per process
 // 3x3 / 64-channel specialisation with the two-group ping-pong schedule (conv3x3_pp.hip)
 void launch_conv3x3_pp(const ConvArgs& a, hipStream_t s);
+// same work, one wave per SIMD with the epilogue software-pipelined into the MFMA stream (conv3x3_sp.hip)
+bool launch_conv3x3_sp(const ConvArgs& a, hipStream_t s);   // false: epilogue variant not compiled, use another kernel
+hipError_t conv3x3_sp_init();
 hipError_t conv3x3_pp_init();
 
 struct DirectConvArgs {

@@ -1,0 +1,318 @@
+// conv3x3_sp.hip -- the hot kernel: 3x3, 64-in-channel implicit-GEMM convolution, one wave per SIMD, with the
+// epilogue of patch p-1 and the LDS-DMA of patch p+1 software-pipelined INTO the MFMA stream of patch p.
+//
+// Measured background (profiles/r01): the matrix loop alone runs at ~69 % of the fp16 MFMA peak, but the epilogue
+// (64 outputs per lane per 144 MFMAs: K is only 576) costs as many issue cycles as the MFMAs.  Running it in a second
+// wave on the same SIMD (conv3x3_pp.hip) does not hide it: s_memtime traces show the two waves of a SIMD slowing each
+// other down to the SUM of their solo times.  What the hardware does hide is a wave's OWN independent VALU / LDS / VMEM
+// instructions issued in the shadow of its MFMAs (about 5 issue slots per 32-cycle v_mfma_f32_32x32x16_f16).  So:
+//
+//   * 4 waves per workgroup (one per SIMD, all 512 registers each), two accumulator sets per wave;
+//   * iteration p multiplies patch p into set A while draining set B (patch p-1): in each of the 12 k-steps, next to
+//     its 12 MFMAs and 10 ds_read_b128, the wave finishes one eighth of the previous tile (bias/scale/PReLU in fp32,
+//     fp16, v_permlane32_swap pair, one 16-byte store) and issues one 1-KiB DMA piece of patch p+1;
+//   * one workgroup barrier per patch.
+//
+// GEMM view, LDS image (column-keyed XOR swizzle), weight fragment order and the fused epilogue are those of
+// conv_mfma.hip / conv3x3_pp.hip; wave tile = 2 output rows x 32 pixels x 64 output channels.
+#include "common.h"
+
+namespace {
+
+constexpr int PW = kTileW + 2, PH = kTileH + 2, NPIX = PW * PH;   // 34 x 10 halo'd patch
+constexpr int NDMA = (NPIX + 7) / 8;                               // 43 one-KiB pieces
+constexpr int NDMA_W = (NDMA + 3) / 4;                             // 11 per wave
+constexpr int PATCH_BYTES = NDMA_W * 4 * 1024;                      // 45,056: 44 pieces, the last one all padding
+constexpr int NFRAG = 72;                                          // 9 taps x 4 k-slices x 2 n-blocks
+constexpr int WBYTES = NFRAG * kFragBytes;                         // 73,728
+constexpr int LDS_BYTES = WBYTES + 2 * PATCH_BYTES;                // 163,840 = all of the CU's LDS
+
+__device__ __forceinline__ void dma16(const half_t* src, char* lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+struct Item { int b, pyi, pxi; };
+
+__device__ __forceinline__ Item decode(int item, int px, int py)
+{
+    Item it;
+    it.pxi = item % px;
+    const int t = item / px;
+    it.pyi = t % py;
+    it.b = t / py;
+    return it;
+}
+
+struct PatchSrc { const half_t* base; int y0, x0; };
+
+// EPI selects the fused epilogue at compile time (no control flow inside the pipelined iteration):
+//   0  plain                      (conv_input2, SEDN rblock.4, lite conv_2)
+//   1  PReLU/LeakyReLU            (ARSB conv_1, SEDN rblock.0/2, lite conv_1)          max(x, slope*x), slope <= 1
+//   2  (x + bias)*scale + residual (ARSB conv_2 with its ScaleLayer)
+//   3  (x + bias)*scale, PReLU     (upsampler convs: +bias, PixelShuffle folded into the store, PReLU)
+template <int EPI>
+__global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const wlds = smem;
+    char* const pbuf = smem + WBYTES;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w4 = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0..3
+    const int j = lane & 31, hh = lane >> 5;
+
+    const int bid = blockIdx.x;
+    const int chunk = (bid >> 3) % a.nchunks;
+    const int g = (bid & 7) + 8 * (bid / (8 * a.nchunks));
+    if (g >= a.G) return;
+    const int nitems = a.B * a.py * a.px;
+    const int K = (nitems - g + a.G - 1) / a.G;                  // this workgroup's items: g, g+G, ...
+    if (K <= 0) return;
+
+    const half_t* const zsrc = a.zero + (lane & 7) * 8;
+    // launch-invariant per-lane source offsets of this wave's 11 DMA pieces (elements, relative to the patch origin)
+    int poff[NDMA_W];
+#pragma unroll
+    for (int i = 0; i < NDMA_W; ++i) {
+        const int q = (i * 4 + w4) * 8 + (lane >> 3);
+        const int r = (q * 241) >> 13;                            // q / 34 for q < 352
+        const int c = q - r * PW;
+        const int sl = (lane & 7) ^ ((c >> 1) & 7);               // logical 16-B slot behind this physical slot
+        poff[i] = (r * a.W + c) * a.in_cs + sl * 8;
+    }
+    auto patch_src = [&](int k) {
+        const Item it = decode(g + k * a.G, a.px, a.py);
+        PatchSrc ps;
+        ps.y0 = it.pyi * kTileH - 1; ps.x0 = it.pxi * kTileW - 1;
+        ps.base = a.in + ((long long)(it.b * a.H + ps.y0) * a.W + ps.x0) * a.in_cs;
+        return ps;
+    };
+    auto issue_piece = [&](const PatchSrc& ps, int i, char* dstbuf, bool live = true) {
+        const int n = i * 4 + w4;                                 // 0..43, no branch: piece 43 is pure padding
+        const int q = n * 8 + (lane >> 3);
+        const int r = (q * 241) >> 13;
+        const int c = q - r * PW;
+        const bool ok = ((unsigned)(ps.y0 + r) < (unsigned)a.H) & ((unsigned)(ps.x0 + c) < (unsigned)a.W) & (q < NPIX) & live;
+        const half_t* src = ps.base + poff[i];
+        src = ok ? src : zsrc;
+        dma16(src, dstbuf + n * 1024);
+    };
+
+    {   // prologue: weights + the first patch
+        const half_t* wsrc = a.wpk + (long long)chunk * (WBYTES / 2);
+        for (int f = w4; f < NFRAG; f += 4) dma16(wsrc + f * 512 + lane * 8, wlds + f * 1024);
+        const PatchSrc ps = patch_src(0);
+#pragma unroll
+        for (int i = 0; i < NDMA_W; ++i) issue_piece(ps, i, pbuf);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // LDS read addressing: pixel (row, col) at (row*34 + col)*128, 16-B slot s stored at slot s ^ ((col>>1)&7)
+    int Ad[3], Zd[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        const int c = j + dx;
+        const int z = (c >> 1) & 7;
+        Ad[dx] = (w4 * 2 * PW + c) * 128 + ((hh ^ (z & 1)) << 4);
+        Zd[dx] = (z >> 1) << 5;
+    }
+    const char* const wl = wlds + lane * 16;
+
+    const int r = a.r;
+    const int si = (r > 1) ? chunk / r : 0, sj = (r > 1) ? chunk % r : 0;
+    const int cout0 = (r > 1) ? 0 : chunk * kCB;                   // first output channel of this chunk in `out`
+    const int Wo = a.W * r, Ho = a.H * r;
+
+    // predicated-off lanes read/write the 1-KiB slack every activation buffer carries behind its last element
+    const unsigned trash_off = (unsigned)a.B * Ho * Wo * a.out_cs + lane * 8;
+
+    float16_t accA[2][2], accB[2][2];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { accA[o][nb][e] = 0.f; accB[o][nb][e] = 0.f; }
+
+    // this lane's 32 bias values (channels nb*32 + gp*16 + g2*8 + hh*4 + e) live in registers for the whole launch
+    float4_t biasr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        biasr[i] = float4_t{0.f, 0.f, 0.f, 0.f};
+        if (EPI == 2 || EPI == 3) biasr[i] = *(const float4_t*)(a.bias + chunk * kCB + (i >> 2) * 32 + ((i >> 1) & 1) * 16 + (i & 1) * 8 + hh * 4);
+    }
+    // One eighth (index s8 = (o, nb, gp)) of the epilogue of a finished tile held in `ac`.  Branch-free: lanes outside the
+    // image (or a disabled slice) store to a trash line and read their residual from the zero page.
+    constexpr bool AFF = (EPI == 2) || (EPI == 3), ACT = (EPI == 1) || (EPI == 3), RES = (EPI == 2);
+    auto drain_slice = [&](float16_t (&ac)[2][2], const Item& it, int s8, bool live) {
+        const int o = s8 >> 2, nb = (s8 >> 1) & 1, gp = s8 & 1;
+        const int y = it.pyi * kTileH + w4 * 2 + o, x = it.pxi * kTileW + j;
+        const bool ok = (y < a.H) & (x < a.W) & live;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = ac[o][nb][gp * 8 + e];     // channels nb*32 + 16*gp + {0..3 | 8..11} + 4*hh
+        if (AFF) {
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[g2 * 4 + e] = (v[g2 * 4 + e] + biasr[(nb * 2 + gp) * 2 + g2][e]) * a.scale;
+            }
+        }
+        if (ACT) {                 // slope <= 1 (negative slopes included): PReLU(x) = max(x, slope*x)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], v[e] * a.slope);
+        }
+        // 32-bit element offset (the launcher guarantees the output tensor has < 2^32 elements): cheap enough that the
+        // compiler keeps the predicated-off lanes on a v_cndmask instead of branching around the address arithmetic
+        const unsigned opix = ((unsigned)(it.b * Ho + y * r + si) * (unsigned)Wo + (unsigned)(x * r + sj)) * (unsigned)a.out_cs + (unsigned)(cout0 + nb * 32 + gp * 16);
+        if (RES) {
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2) {
+                const half4_t rv = *(const half4_t*)(a.res + (ok ? opix + g2 * 8 + hh * 4 : trash_off));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[g2 * 4 + e] += (float)rv[e];
+            }
+        }
+        // fp16, then one v_permlane32_swap per register: lane (j,0) gets channels 16*gp .. +7, lane (j,1) 16*gp+8 .. +15
+        half4_t h0, h1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { h0[e] = (half_t)v[e]; h1[e] = (half_t)v[4 + e]; }
+        const uint2 u0 = __builtin_bit_cast(uint2, h0), u1 = __builtin_bit_cast(uint2, h1);
+        const auto sx = __builtin_amdgcn_permlane32_swap(u0.x, u1.x, false, false);
+        const auto sy = __builtin_amdgcn_permlane32_swap(u0.y, u1.y, false, false);
+        *(uint4*)(a.out + (ok ? opix + hh * 8 : trash_off)) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+    };
+
+    // iteration p (0 <= p < K): multiply patch p (buffer p&1) into `cur`; drain patch p-1 from `prev` (stores predicated
+    // off for p == 0); fetch patch p+1 (source predicated to the zero page for the last one).  No branches inside: the
+    // whole iteration is one scheduling region so the VALU/VMEM work lands in the shadow of the MFMAs.
+    auto iteration = [&](int p, float16_t (&cur)[2][2], float16_t (&prev)[2][2]) {
+        const bool drain = (p >= 1) && !(a.dbg & 4);
+        const bool fetch = (p + 1 < K) && !(a.dbg & 1);
+        const Item itp = decode(g + (p >= 1 ? p - 1 : 0) * a.G, a.px, a.py);
+        const PatchSrc ps = patch_src(p + 1 < K ? p + 1 : p);
+        const char* abuf = pbuf + (p & 1) * PATCH_BYTES;
+        char* nbuf = pbuf + ((p + 1) & 1) * PATCH_BYTES;
+        half8_t wf[2][3][2], af[2][4];
+#define MOE_LOAD_STEP(S, BUF)                                                                              \
+    {                                                                                                      \
+        constexpr int dx_ = (S) / 4, ks_ = (S) % 4;                                                        \
+        _Pragma("unroll") for (int dy = 0; dy < 3; ++dy)                                                   \
+            _Pragma("unroll") for (int nb = 0; nb < 2; ++nb)                                               \
+                wf[BUF][dy][nb] = *(const half8_t*)(wl + ((((dy * 3 + dx_) * 4 + ks_) * 2 + nb) << 10));   \
+        const char* ap_ = abuf + Ad[dx_] + ((ks_ << 5) ^ Zd[dx_]);                                         \
+        _Pragma("unroll") for (int pr = 0; pr < 4; ++pr)                                                   \
+            af[BUF][pr] = *(const half8_t*)(ap_ + pr * (PW * 128));                                        \
+    }
+        MOE_LOAD_STEP(0, 0)
+#pragma unroll
+        for (int s = 0; s < 12; ++s) {
+            const int cb = s & 1;
+            switch (s + 1) {   // constant after unrolling
+#define MOE_CASE(N) case N: MOE_LOAD_STEP(N, ((N) & 1)) break;
+                MOE_CASE(1) MOE_CASE(2) MOE_CASE(3) MOE_CASE(4) MOE_CASE(5) MOE_CASE(6)
+                MOE_CASE(7) MOE_CASE(8) MOE_CASE(9) MOE_CASE(10) MOE_CASE(11)
+#undef MOE_CASE
+                default: break;
+            }
+            if (s < NDMA_W) issue_piece(ps, s, nbuf, fetch);
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int o = pr - dy;
+                    if (o >= 0 && o < 2) {
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb)
+                            cur[o][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cb][dy][nb], af[cb][pr], cur[o][nb], 0, 0, 0);
+                    }
+                }
+            if (s < 8) drain_slice(prev, itp, s, drain);
+            // pin the issue order: every MFMA is followed by one LDS read (the next step's fragments) and up to five VALU
+            // instructions of the drain / address arithmetic -- the slots that fit in the shadow of a 32-cycle MFMA
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i < 10 && s + 1 < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                if (i == 9 && s < NDMA_W) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if (i == 11 && s < 8) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+            }
+        }
+#undef MOE_LOAD_STEP
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) prev[o][nb][e] = 0.f;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
+    int p = 0;
+    for (; p + 1 < K; p += 2) {
+        iteration(p, accA, accB);
+        iteration(p + 1, accB, accA);
+    }
+    if (p < K) {
+        iteration(p, accA, accB);
+        ++p;
+    }
+    {   // drain the last tile (patch K-1): it sits in A when K is odd, in B when K is even
+        const Item itp = decode(g + (K - 1) * a.G, a.px, a.py);
+        const bool live = !(a.dbg & 4);
+        if (K & 1) {
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) drain_slice(accA, itp, s8, live);
+        } else {
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) drain_slice(accB, itp, s8, live);
+        }
+    }
+}
+
+template <int EPI>
+hipError_t set_limit()
+{
+    return hipFuncSetAttribute((const void*)conv3x3_sp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+}
+
+}  // namespace
+
+hipError_t conv3x3_sp_init()
+{
+    hipError_t e;
+    if ((e = set_limit<0>()) != hipSuccess) return e;
+    if ((e = set_limit<1>()) != hipSuccess) return e;
+    if ((e = set_limit<2>()) != hipSuccess) return e;
+    if ((e = set_limit<3>()) != hipSuccess) return e;
+    return hipSuccess;
+}
+
+// Returns false when the layer's epilogue is not one of the four compiled variants (caller uses another kernel).
+bool launch_conv3x3_sp(const ConvArgs& a, hipStream_t s)
+{
+    if (a.acc_mode != 0 || a.slope > 1.f) return false;
+    if ((long long)a.B * a.H * a.r * a.W * a.r * a.out_cs >= (1ll << 32) - 4096) return false;   // 32-bit store offsets
+    const bool aff = a.bias != nullptr || a.scale != 1.f, act = a.slope != 1.f, res = a.res != nullptr;
+    int epi;
+    if (!aff && !act && !res) epi = 0;
+    else if (!aff && act && !res) epi = 1;
+    else if (!act && res) epi = 2;
+    else if (aff && act && !res) epi = 3;
+    else return false;
+    if ((epi == 2 || epi == 3) && !a.bias) return false;      // the engine passes a zero bias vector for scale-only layers
+    const int blocks = a.nchunks * ((a.G + 7) / 8) * 8;
+    const dim3 grid(blocks), blk(256);
+    switch (epi) {
+        case 0: conv3x3_sp_kernel<0><<<grid, blk, LDS_BYTES, s>>>(a); break;
+        case 1: conv3x3_sp_kernel<1><<<grid, blk, LDS_BYTES, s>>>(a); break;
+        case 2: conv3x3_sp_kernel<2><<<grid, blk, LDS_BYTES, s>>>(a); break;
+        default: conv3x3_sp_kernel<3><<<grid, blk, LDS_BYTES, s>>>(a); break;
+    }
+    return true;
+}

@@ -307,6 +307,8 @@ static int build_device_weights(moe_net& n, int precision)
         n.scalars["tail_taps"] = (float)taps;
     };
     n.small["zero"] = bb.take(1024);
+    n.small["trash"] = bb.take(4096);
+    n.small["zero_bias"] = bb.take(1024 * 4);      // up to 16 chunks of 64 fp32 zeros
 
     if (n.arch == MOE_ARCH_NET2X || n.arch == MOE_ARCH_NET3X || n.arch == MOE_ARCH_NET4X || n.arch == MOE_ARCH_NETDN) {
         stem("conv_input.weight");
@@ -397,8 +399,9 @@ struct Fwd {
     Act act(long long pixels, int ch = 64)
     {
         Act a;
-        a.hi = (half_t*)ar.take((size_t)pixels * ch * 2);
-        if (x3) a.lo = (half_t*)ar.take((size_t)pixels * ch * 2);
+        // + 2 KiB slack: the branch-free conv epilogue parks its predicated-off lanes just behind the last element
+        a.hi = (half_t*)ar.take((size_t)pixels * ch * 2 + 2048);
+        if (x3) a.lo = (half_t*)ar.take((size_t)pixels * ch * 2 + 2048);
         return a;
     }
     template <typename T> T* blob(size_t off) const { return (T*)(n.blob + off); }
@@ -439,6 +442,8 @@ struct Fwd {
         a.wpk = L.per_plane ? plane_w : blob<half_t>(L.w_hi);
         a.bias = L.has_bias ? blob<float>(L.bias) : nullptr;
         a.zero = small<half_t>("zero");
+        a.trash = small<half_t>("trash");
+        if (!a.bias && L.scale != 1.f) a.bias = small<float>("zero_bias");   // scale-only epilogue: (x + 0) * scale
         a.w_batch_stride = L.per_plane ? (long long)L.nchunks * L.nfrag() * 512 : 0;
         a.B = B; a.H = H; a.W = W; a.in_cs = 64 * L.nseg; a.out_cs = out_cs; a.r = L.r; a.nchunks = L.nchunks;
         a.px = (W + kTileW - 1) / kTileW; a.py = (H + kTileH - 1) / kTileH;
@@ -448,9 +453,31 @@ struct Fwd {
         if (G > items) G = (int)items;
         a.G = G;
         a.slope = L.slope; a.scale = L.scale;
-        static const bool force_v1 = [] { const char* e = getenv("MOE_CONV_IMPL"); return e && !strcmp(e, "v1"); }();
-        const bool pp = L.taps == 9 && L.nseg == 1 && !L.per_plane && !force_v1;
-        auto launch = [&](const ConvArgs& ca) { if (pp) launch_conv3x3_pp(ca, s); else launch_conv_mfma(ca, L.taps, L.nseg, s); };
+        static const int dbg = [] { const char* e = getenv("MOE_DBG"); return e ? atoi(e) : 0; }();
+        a.dbg = dbg;
+        // MOE_CONV_IMPL = sp (default: software-pipelined epilogue) | pp (two-group ping-pong) | v1 (generic kernel)
+        static const int impl = [] { const char* e = getenv("MOE_CONV_IMPL"); return !e ? 2 : (!strcmp(e, "v1") ? 0 : (!strcmp(e, "pp") ? 1 : 2)); }();
+        const bool pp = L.taps == 9 && L.nseg == 1 && !L.per_plane && impl != 0;
+        auto launch = [&](const ConvArgs& ca) {
+            if (pp && impl == 2 && launch_conv3x3_sp(ca, s)) return;
+            if (pp) launch_conv3x3_pp(ca, s);
+            else launch_conv_mfma(ca, L.taps, L.nseg, s);
+        };
+        if (!x3 && (dbg & 64) && pp && key == "convt_R1.up1") {   // timing trace of one launch -> /tmp/moe_trace.bin
+            unsigned long long* tr = nullptr;
+            const size_t nb = 8 * 32 * 2 * 8 * 8;
+            if (hipMalloc((void**)&tr, nb) == hipSuccess) {
+                (void)hipMemsetAsync(tr, 0, nb, s);
+                ConvArgs t = a; t.acc32 = (float*)tr;
+                launch(t);
+                std::vector<unsigned long long> host(nb / 8);
+                (void)hipStreamSynchronize(s);
+                (void)hipMemcpy(host.data(), tr, nb, hipMemcpyDeviceToHost);
+                if (FILE* f = fopen("/tmp/moe_trace.bin", "wb")) { fwrite(host.data(), 1, nb, f); fclose(f); }
+                (void)hipFree(tr);
+                return;
+            }
+        }
         if (!x3) {
             const bool prof = !n.prof_key.empty() && key.find(n.prof_key) != std::string::npos;
             if (prof) {

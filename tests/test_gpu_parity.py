@@ -133,11 +133,11 @@ def test_ragged_and_tiny_tiles(dev):
         assert y.shape == (3, 1, 2 * h, 2 * w) and y.dtype == torch.float32
         assert np.abs(y.cpu().numpy() - want).max() <= 2e-5, (h, w)
     mf = module_for('a2', 'fp16')
-    x = gd.natural_image(9, (3, 1, 40, 264))
+    x = gd.natural_image(9, (3, 40, 264))[:, None]
     y = mf(torch.from_numpy(x).to(dev))[-1].cpu().numpy()
     assert np.abs(y - onets.forward('net2x', sd, x).numpy()).max() <= 2e-3        # single-pass fp16 operands on a busy tile: 1.4e-3
     m16 = module_for('a2', dtype=torch.float16)
-    x = gd.natural_image(9, (4, 1, 40, 48))                                       # 4 planes: RGBA through SR
+    x = gd.natural_image(9, (4, 40, 48))[:, None]                                 # 4 planes: RGBA through SR
     y = m16(torch.from_numpy(x).to(dev).half())[-1]
     assert y.dtype == torch.float16
     want = onets.forward('net2x', sd, x).numpy()
