@@ -48,10 +48,15 @@ __device__ __forceinline__ Item decode(int item, int px, int py)
 struct PatchSrc { const half_t* base; int y0, x0; };
 
 // EPI selects the fused epilogue at compile time (no control flow inside the pipelined iteration):
-//   0  plain                      (conv_input2, SEDN rblock.4, lite conv_2)
-//   1  PReLU/LeakyReLU            (ARSB conv_1, SEDN rblock.0/2, lite conv_1)          max(x, slope*x), slope <= 1
-//   2  (x + bias)*scale + residual (ARSB conv_2 with its ScaleLayer)
-//   3  (x + bias)*scale, PReLU     (upsampler convs: +bias, PixelShuffle folded into the store, PReLU)
+//   0  plain                  (conv_input2, SEDN rblock.4, lite conv_2)
+//   1  PReLU/LeakyReLU        (ARSB conv_1, SEDN rblock.0/2, lite conv_1, upsampler convs)   max(x, slope*x), slope <= 1
+//   2  + residual             (ARSB conv_2; its ScaleLayer is folded into the packed weights by the engine)
+// The bias (upsampler convs) costs nothing here: the accumulators are initialised with it instead of zero.
+// timing trace (MOE_DBG & 64): acc32 doubles as a [wg<8][iter<32][wave<4][slot<4] table of s_memtime stamps
+#define MOE_STAMP(SLOT)                                                                                 \
+    if ((a.dbg & 64) && a.acc32 && bid < 8 && p < 32 && lane == 0)                                        \
+        ((unsigned long long*)a.acc32)[((bid * 32 + p) * 4 + w4) * 4 + (SLOT)] = __builtin_amdgcn_s_memtime();
+
 template <int EPI>
 __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
 {
@@ -82,8 +87,20 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         const int sl = (lane & 7) ^ ((c >> 1) & 7);               // logical 16-B slot behind this physical slot
         poff[i] = (r * a.W + c) * a.in_cs + sl * 8;
     }
-    auto patch_src = [&](int k) {
-        const Item it = decode(g + k * a.G, a.px, a.py);
+    // work items g, g+G, g+2G, ... are walked with carries instead of divisions
+    const int Gx = a.G % a.px, Gy = (a.G / a.px) % a.py, Gb = a.G / (a.px * a.py);
+    auto advance = [&](const Item& it) {
+        Item n;
+        int x = it.pxi + Gx;
+        const int cx = x >= a.px;
+        x -= cx ? a.px : 0;
+        int y = it.pyi + Gy + cx;
+        const int cy = y >= a.py;
+        y -= cy ? a.py : 0;
+        n.pxi = x; n.pyi = y; n.b = it.b + Gb + cy;
+        return n;
+    };
+    auto patch_src = [&](const Item& it) {
         PatchSrc ps;
         ps.y0 = it.pyi * kTileH - 1; ps.x0 = it.pxi * kTileW - 1;
         ps.base = a.in + ((long long)(it.b * a.H + ps.y0) * a.W + ps.x0) * a.in_cs;
@@ -103,7 +120,7 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
     {   // prologue: weights + the first patch
         const half_t* wsrc = a.wpk + (long long)chunk * (WBYTES / 2);
         for (int f = w4; f < NFRAG; f += 4) dma16(wsrc + f * 512 + lane * 8, wlds + f * 1024);
-        const PatchSrc ps = patch_src(0);
+        const PatchSrc ps = patch_src(decode(g, a.px, a.py));
 #pragma unroll
         for (int i = 0; i < NDMA_W; ++i) issue_piece(ps, i, pbuf);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -126,27 +143,29 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
     const int cout0 = (r > 1) ? 0 : chunk * kCB;                   // first output channel of this chunk in `out`
     const int Wo = a.W * r, Ho = a.H * r;
 
+    // accumulators start from the bias (engine passes a zero vector when the layer has none): lane (j, hh) register
+    // e of tile [o][nb] is channel nb*32 + 8*(e>>2) + 4*hh + (e&3); the 256-byte vector stays L1/L2 resident
+    const float* const bias_lane = a.bias + chunk * kCB + hh * 4;
+    auto reset_acc = [&](float16_t (&ac)[2][2]) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4_t b4 = *(const float4_t*)(bias_lane + nb * 32 + g4 * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ac[0][nb][g4 * 4 + e] = b4[e]; ac[1][nb][g4 * 4 + e] = b4[e]; }
+            }
+    };
     // predicated-off lanes read/write the 1-KiB slack every activation buffer carries behind its last element
     const unsigned trash_off = (unsigned)a.B * Ho * Wo * a.out_cs + lane * 8;
 
     float16_t accA[2][2], accB[2][2];
-#pragma unroll
-    for (int o = 0; o < 2; ++o)
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { accA[o][nb][e] = 0.f; accB[o][nb][e] = 0.f; }
+    reset_acc(accA);
+    reset_acc(accB);
 
-    // this lane's 32 bias values (channels nb*32 + gp*16 + g2*8 + hh*4 + e) live in registers for the whole launch
-    float4_t biasr[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        biasr[i] = float4_t{0.f, 0.f, 0.f, 0.f};
-        if (EPI == 2 || EPI == 3) biasr[i] = *(const float4_t*)(a.bias + chunk * kCB + (i >> 2) * 32 + ((i >> 1) & 1) * 16 + (i & 1) * 8 + hh * 4);
-    }
     // One eighth (index s8 = (o, nb, gp)) of the epilogue of a finished tile held in `ac`.  Branch-free: lanes outside the
     // image (or a disabled slice) store to a trash line and read their residual from the zero page.
-    constexpr bool AFF = (EPI == 2) || (EPI == 3), ACT = (EPI == 1) || (EPI == 3), RES = (EPI == 2);
+    constexpr bool ACT = (EPI == 1), RES = (EPI == 2);
     auto drain_slice = [&](float16_t (&ac)[2][2], const Item& it, int s8, bool live) {
         const int o = s8 >> 2, nb = (s8 >> 1) & 1, gp = s8 & 1;
         const int y = it.pyi * kTileH + w4 * 2 + o, x = it.pxi * kTileW + j;
@@ -154,16 +173,12 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = ac[o][nb][gp * 8 + e];     // channels nb*32 + 16*gp + {0..3 | 8..11} + 4*hh
-        if (AFF) {
-#pragma unroll
-            for (int g2 = 0; g2 < 2; ++g2) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[g2 * 4 + e] = (v[g2 * 4 + e] + biasr[(nb * 2 + gp) * 2 + g2][e]) * a.scale;
-            }
-        }
         if (ACT) {                 // slope <= 1 (negative slopes included): PReLU(x) = max(x, slope*x)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], v[e] * a.slope);
+            for (int e = 0; e < 8; ++e) {      // plain v_max_f32: fmaxf would add a canonicalising v_max per operand
+                const float t = v[e] * a.slope;
+                asm("v_max_f32 %0, %1, %2" : "=v"(v[e]) : "v"(v[e]), "v"(t));
+            }
         }
         // 32-bit element offset (the launcher guarantees the output tensor has < 2^32 elements): cheap enough that the
         // compiler keeps the predicated-off lanes on a v_cndmask instead of branching around the address arithmetic
@@ -186,16 +201,18 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         *(uint4*)(a.out + (ok ? opix + hh * 8 : trash_off)) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
     };
 
+    Item it_cur = decode(g, a.px, a.py), it_prev = it_cur, it_next = advance(it_cur);
     // iteration p (0 <= p < K): multiply patch p (buffer p&1) into `cur`; drain patch p-1 from `prev` (stores predicated
     // off for p == 0); fetch patch p+1 (source predicated to the zero page for the last one).  No branches inside: the
     // whole iteration is one scheduling region so the VALU/VMEM work lands in the shadow of the MFMAs.
     auto iteration = [&](int p, float16_t (&cur)[2][2], float16_t (&prev)[2][2]) {
         const bool drain = (p >= 1) && !(a.dbg & 4);
         const bool fetch = (p + 1 < K) && !(a.dbg & 1);
-        const Item itp = decode(g + (p >= 1 ? p - 1 : 0) * a.G, a.px, a.py);
-        const PatchSrc ps = patch_src(p + 1 < K ? p + 1 : p);
+        const Item itp = it_prev;
+        const PatchSrc ps = patch_src(it_next);
         const char* abuf = pbuf + (p & 1) * PATCH_BYTES;
         char* nbuf = pbuf + ((p + 1) & 1) * PATCH_BYTES;
+        MOE_STAMP(0)
         half8_t wf[2][3][2], af[2][4];
 #define MOE_LOAD_STEP(S, BUF)                                                                              \
     {                                                                                                      \
@@ -218,7 +235,8 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
 #undef MOE_CASE
                 default: break;
             }
-            if (s < NDMA_W) issue_piece(ps, s, nbuf, fetch);
+            if (s < 5) { issue_piece(ps, 2 * s, nbuf, fetch); issue_piece(ps, 2 * s + 1, nbuf, fetch); }
+            if (s == 5) issue_piece(ps, 10, nbuf, fetch);
 #pragma unroll
             for (int pr = 0; pr < 4; ++pr)
 #pragma unroll
@@ -231,26 +249,27 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
                     }
                 }
             if (s < 8) drain_slice(prev, itp, s, drain);
-            // pin the issue order: every MFMA is followed by one LDS read (the next step's fragments) and up to five VALU
-            // instructions of the drain / address arithmetic -- the slots that fit in the shadow of a 32-cycle MFMA
+            // pin the issue order: the ten LDS reads of the next step go out behind the first five MFMAs (their latency
+            // then hides under the other seven), the two DMA pieces and the store sit in the middle, and every MFMA is
+            // followed by up to five VALU instructions of the drain / address arithmetic (what fits in a 32-cycle shadow)
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (i < 10 && s + 1 < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-                if (i == 9 && s < NDMA_W) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                if (i == 11 && s < 8) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+                if (i < 5 && s + 1 < 12) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                if (i < 5) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                else __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                if ((i == 5 || i == 6) && s <= 5) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if (i == 8 && s < 8) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
             }
         }
 #undef MOE_LOAD_STEP
-#pragma unroll
-        for (int o = 0; o < 2; ++o)
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) prev[o][nb][e] = 0.f;
+        reset_acc(prev);
+        MOE_STAMP(1)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MOE_STAMP(2)
         __syncthreads();
+        MOE_STAMP(3)
+        it_prev = it_cur; it_cur = it_next; it_next = advance(it_next);
     };
 
     int p = 0;
@@ -263,7 +282,7 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         ++p;
     }
     {   // drain the last tile (patch K-1): it sits in A when K is odd, in B when K is even
-        const Item itp = decode(g + (K - 1) * a.G, a.px, a.py);
+        const Item itp = it_prev;
         const bool live = !(a.dbg & 4);
         if (K & 1) {
 #pragma unroll
@@ -289,30 +308,24 @@ hipError_t conv3x3_sp_init()
     if ((e = set_limit<0>()) != hipSuccess) return e;
     if ((e = set_limit<1>()) != hipSuccess) return e;
     if ((e = set_limit<2>()) != hipSuccess) return e;
-    if ((e = set_limit<3>()) != hipSuccess) return e;
     return hipSuccess;
 }
 
 // Returns false when the layer's epilogue is not one of the four compiled variants (caller uses another kernel).
 bool launch_conv3x3_sp(const ConvArgs& a, hipStream_t s)
 {
-    if (a.acc_mode != 0 || a.slope > 1.f) return false;
+    if ((a.acc_mode != 0 && !(a.dbg & 64)) || a.slope > 1.f) return false;
     if ((long long)a.B * a.H * a.r * a.W * a.r * a.out_cs >= (1ll << 32) - 4096) return false;   // 32-bit store offsets
-    const bool aff = a.bias != nullptr || a.scale != 1.f, act = a.slope != 1.f, res = a.res != nullptr;
-    int epi;
-    if (!aff && !act && !res) epi = 0;
-    else if (!aff && act && !res) epi = 1;
-    else if (!act && res) epi = 2;
-    else if (aff && act && !res) epi = 3;
-    else return false;
-    if ((epi == 2 || epi == 3) && !a.bias) return false;      // the engine passes a zero bias vector for scale-only layers
+    if (a.scale != 1.f || !a.bias) return false;           // the engine folds ScaleLayer into the weights and always passes a bias vector
+    const bool act = a.slope != 1.f, res = a.res != nullptr;
+    if (act && res) return false;
+    const int epi = res ? 2 : (act ? 1 : 0);
     const int blocks = a.nchunks * ((a.G + 7) / 8) * 8;
     const dim3 grid(blocks), blk(256);
     switch (epi) {
         case 0: conv3x3_sp_kernel<0><<<grid, blk, LDS_BYTES, s>>>(a); break;
         case 1: conv3x3_sp_kernel<1><<<grid, blk, LDS_BYTES, s>>>(a); break;
-        case 2: conv3x3_sp_kernel<2><<<grid, blk, LDS_BYTES, s>>>(a); break;
-        default: conv3x3_sp_kernel<3><<<grid, blk, LDS_BYTES, s>>>(a); break;
+        default: conv3x3_sp_kernel<2><<<grid, blk, LDS_BYTES, s>>>(a); break;
     }
     return true;
 }

@@ -213,7 +213,8 @@ inline int orig_cout(int np, int cout, int r)
 
 // A-operand fragments of v_mfma_f32_32x32x16_f16 for D[cout][pixel]: fragment f = ((seg*taps + tap)*4 + ks)*2 + nblk,
 // lane l holds W[cout = chunk*64 + nblk*32 + (l&31)][cin = seg*64 + ks*16 + 8*(l>>5) + e][tap], e = 0..7
-void pack_conv(const Param& W, const Param* bias, int r, ConvLayer& L, BlobBuilder& bb, bool want_lo, bool want_plain, bool want_pk32)
+void pack_conv(const Param& W, const Param* bias, int r, ConvLayer& L, BlobBuilder& bb, bool want_lo, bool want_plain, bool want_pk32,
+               float fold = 1.f)   // ScaleLayer folded into the MFMA weights: conv(x, w) * s == conv(x, w * s), product formed in fp32
 {
     const int cout = (int)W.shape[0], cin = (int)W.shape[1], k = (int)W.shape[2];
     L.cout = cout; L.cin = cin; L.k = k; L.r = r;
@@ -235,7 +236,7 @@ void pack_conv(const Param& W, const Param* bias, int r, ConvLayer& L, BlobBuild
                     const int ci = seg * 64 + ks * 16 + 8 * (l >> 5) + e;
                     const int oc = orig_cout(np, cout, r);
                     float v = 0.f;
-                    if (oc >= 0 && ci < cin) v = W.data[((size_t)oc * cin + ci) * L.taps + tap];
+                    if (oc >= 0 && ci < cin) v = W.data[((size_t)oc * cin + ci) * L.taps + tap] * fold;
                     const size_t idx = ((size_t)(chunk * nfrag + f) * 64 + l) * 8 + e;
                     const half_t hv = (half_t)v;
                     bb.at<half_t>(L.w_hi)[idx] = hv;
@@ -248,7 +249,7 @@ void pack_conv(const Param& W, const Param* bias, int r, ConvLayer& L, BlobBuild
         L.bias = bb.take((size_t)L.nchunks * 64 * 4);
         for (int np = 0; np < L.nchunks * 64; ++np) {
             const int oc = orig_cout(np, cout, r);
-            bb.at<float>(L.bias)[np] = oc >= 0 ? bias->data[oc] : 0.f;
+            bb.at<float>(L.bias)[np] = oc >= 0 ? bias->data[oc] * fold : 0.f;
         }
     }
     if (want_plain) {
@@ -274,8 +275,9 @@ static int build_device_weights(moe_net& n, int precision)
                     bool per_plane = false) {
         ConvLayer L;
         const Param* b = bname ? n.get(bname) : nullptr;
-        pack_conv(*n.get(wname), b, r, L, bb, lo, plain, per_plane);
-        L.slope = slope; L.scale = scale; L.per_plane = per_plane;
+        // the debug path keeps the plain weights and applies the scale in its epilogue; the MFMA kernels get it pre-multiplied
+        pack_conv(*n.get(wname), b, r, L, bb, lo, plain, per_plane, plain ? 1.f : scale);
+        L.slope = slope; L.scale = plain ? scale : 1.f; L.per_plane = per_plane;
         n.conv_index[key] = (int)n.convs.size();
         n.convs.push_back(L);
     };
@@ -443,7 +445,7 @@ struct Fwd {
         a.bias = L.has_bias ? blob<float>(L.bias) : nullptr;
         a.zero = small<half_t>("zero");
         a.trash = small<half_t>("trash");
-        if (!a.bias && L.scale != 1.f) a.bias = small<float>("zero_bias");   // scale-only epilogue: (x + 0) * scale
+        if (!a.bias) a.bias = small<float>("zero_bias");   // kernels initialise their accumulators from the bias vector
         a.w_batch_stride = L.per_plane ? (long long)L.nchunks * L.nfrag() * 512 : 0;
         a.B = B; a.H = H; a.W = W; a.in_cs = 64 * L.nseg; a.out_cs = out_cs; a.r = L.r; a.nchunks = L.nchunks;
         a.px = (W + kTileW - 1) / kTileW; a.py = (H + kTileH - 1) / kTileH;

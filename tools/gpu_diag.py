@@ -70,10 +70,10 @@ def facts():
 
 def nets():
     RES['nets'] = {}
-    for key in ('a2', 'a4', 'a3', 'dn_lite5', 'l25', 'lite2', 'lite4'):
+    for key in os.environ.get('DIAG_KEYS', 'a2,a4,a3,dn_lite5,l25,lite2,lite4').split(','):
         arch = gd.MODELS[key][0]
         sd = gd.state_dict_for(key, load_state_dict_file)
-        for prec in ('debug_direct', 'fp16', 'fp16x3'):
+        for prec in os.environ.get('DIAG_PREC', 'debug_direct,fp16,fp16x3').split(','):
             try:
                 m = make(key, prec).set_debug(True)
                 for kind in ('natural', 'noise'):
