@@ -42,6 +42,9 @@ struct ConvArgs {
     int px, py;           // patches along x / y
     float slope;          // PReLU / LeakyReLU slope (1: identity)
     float scale;          // multiplier applied before the activation (ARSB ScaleLayer); 1: none
+    // fused tail (conv3x3_sp EPI 3): A fragments of the 64->1 tail conv and the planar fp32 per-tap sums [9][B][H*r][W*r]
+    const half_t* tail_w;
+    float* tplanes;
     int dbg;              // timing ablations (MOE_DBG env; results are wrong when set): 1 no patch DMA, 2 no MFMA, 4 no stores, 8 no epilogue
 };
 
@@ -92,6 +95,14 @@ struct TailArgs {
     int B, H, W, taps;
 };
 void launch_tail(const TailArgs& a, hipStream_t s);
+
+// y = sum over the nine taps of both branches' planar partial sums (fused-tail path):  t0/t1 [9][B][H][W] fp32
+struct TapSumArgs {
+    const float* t0; const float* t1;
+    void* y; int y_dtype; const long long* y_off;
+    int B, H, W;
+};
+void launch_tapsum(const TapSumArgs& a, hipStream_t s);
 
 // per-plane channel sums: in [B][HW][C] fp16 -> partial [B][nslab][C] fp32
 void launch_pool_partial(const half_t* in, const half_t* in_lo, float* partial, int B, long long HW, int C, int nslab, hipStream_t s);

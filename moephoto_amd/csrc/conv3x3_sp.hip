@@ -51,6 +51,11 @@ struct PatchSrc { const half_t* base; int y0, x0; };
 //   0  plain                  (conv_input2, SEDN rblock.4, lite conv_2)
 //   1  PReLU/LeakyReLU        (ARSB conv_1, SEDN rblock.0/2, lite conv_1, upsampler convs)   max(x, slope*x), slope <= 1
 //   2  + residual             (ARSB conv_2; its ScaleLayer is folded into the packed weights by the engine)
+//   3  PReLU + FUSED TAIL     (last upsampler conv of a branch): the activated fp16 tile is not stored; it is the B operand
+//                             of a second implicit GEMM against the 64->1 tail conv's weights, G[tap][pixel] += Wt[tap][c]*act[c][pixel]
+//                             (8 extra MFMAs per tile), and only the nine per-tap partial sums per HR pixel are written (fp32,
+//                             planar).  A small gather kernel then adds the 9 shifted taps of both branches: the 64-channel
+//                             HR tensor (1.6 GB per 12 planes of 1024x1024, written once and read back) never exists.
 // The bias (upsampler convs) costs nothing here: the accumulators are initialised with it instead of zero.
 // timing trace (MOE_DBG & 64): acc32 doubles as a [wg<8][iter<32][wave<4][slot<4] table of s_memtime stamps
 #define MOE_STAMP(SLOT)                                                                                 \
@@ -165,7 +170,21 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
 
     // One eighth (index s8 = (o, nb, gp)) of the epilogue of a finished tile held in `ac`.  Branch-free: lanes outside the
     // image (or a disabled slice) store to a trash line and read their residual from the zero page.
-    constexpr bool ACT = (EPI == 1), RES = (EPI == 2);
+    constexpr bool ACT = (EPI == 1) || (EPI == 3), RES = (EPI == 2), TAIL = (EPI == 3);
+    // fused tail: A fragments of the 64->1 conv for the four 16-channel k-slices, rows = taps (9 of 32 used)
+    half8_t tailw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        tailw[i] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        if (TAIL) tailw[i] = *(const half8_t*)(a.tail_w + i * 512 + lane * 8);
+    }
+    float16_t Gacc[2];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Gacc[o][e] = 0.f;
+    const unsigned tplane = (unsigned)a.B * Ho * Wo;                   // elements per tap plane
+    const unsigned ttrash = 9u * tplane + lane;                          // slack behind the nine planes
     auto drain_slice = [&](float16_t (&ac)[2][2], const Item& it, int s8, bool live) {
         const int o = s8 >> 2, nb = (s8 >> 1) & 1, gp = s8 & 1;
         const int y = it.pyi * kTileH + w4 * 2 + o, x = it.pxi * kTileW + j;
@@ -179,6 +198,21 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
                 const float t = v[e] * a.slope;
                 asm("v_max_f32 %0, %1, %2" : "=v"(v[e]) : "v"(v[e]), "v"(t));
             }
+        }
+        if (TAIL) {
+            half8_t bf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bf[e] = (half_t)v[e];            // k = 8*hh + e  <->  channel nb*32 + 16*gp + perm(hh, e)
+            Gacc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tailw[nb * 2 + gp], bf, Gacc[o], 0, 0, 0);
+            if ((s8 & 3) == 3) {     // row o complete: lane (j, hh) holds taps 4*hh .. 4*hh+3 in regs 0..3 and tap 8 + 4*hh in reg 4
+                const unsigned tix = (unsigned)(it.b * Ho + y * r + si) * (unsigned)Wo + (unsigned)(x * r + sj);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a.tplanes[ok ? (unsigned)(4 * hh + k) * tplane + tix : ttrash] = Gacc[o][k];
+                a.tplanes[(ok & (hh == 0)) ? 8u * tplane + tix : ttrash] = Gacc[o][4];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) Gacc[o][e] = 0.f;
+            }
+            return;
         }
         // 32-bit element offset (the launcher guarantees the output tensor has < 2^32 elements): cheap enough that the
         // compiler keeps the predicated-off lanes on a v_cndmask instead of branching around the address arithmetic
@@ -308,6 +342,7 @@ hipError_t conv3x3_sp_init()
     if ((e = set_limit<0>()) != hipSuccess) return e;
     if ((e = set_limit<1>()) != hipSuccess) return e;
     if ((e = set_limit<2>()) != hipSuccess) return e;
+    if ((e = set_limit<3>()) != hipSuccess) return e;
     return hipSuccess;
 }
 
@@ -317,14 +352,16 @@ bool launch_conv3x3_sp(const ConvArgs& a, hipStream_t s)
     if ((a.acc_mode != 0 && !(a.dbg & 64)) || a.slope > 1.f) return false;
     if ((long long)a.B * a.H * a.r * a.W * a.r * a.out_cs >= (1ll << 32) - 4096) return false;   // 32-bit store offsets
     if (a.scale != 1.f || !a.bias) return false;           // the engine folds ScaleLayer into the weights and always passes a bias vector
-    const bool act = a.slope != 1.f, res = a.res != nullptr;
-    if (act && res) return false;
-    const int epi = res ? 2 : (act ? 1 : 0);
+    const bool act = a.slope != 1.f, res = a.res != nullptr, tail = a.tplanes != nullptr;
+    if ((act || tail) && res) return false;
+    if (tail && 9ll * a.B * a.H * a.r * a.W * a.r >= (1ll << 32) - 4096) return false;
+    const int epi = tail ? 3 : (res ? 2 : (act ? 1 : 0));
     const int blocks = a.nchunks * ((a.G + 7) / 8) * 8;
     const dim3 grid(blocks), blk(256);
     switch (epi) {
         case 0: conv3x3_sp_kernel<0><<<grid, blk, LDS_BYTES, s>>>(a); break;
         case 1: conv3x3_sp_kernel<1><<<grid, blk, LDS_BYTES, s>>>(a); break;
+        case 3: conv3x3_sp_kernel<3><<<grid, blk, LDS_BYTES, s>>>(a); break;
         default: conv3x3_sp_kernel<2><<<grid, blk, LDS_BYTES, s>>>(a); break;
     }
     return true;

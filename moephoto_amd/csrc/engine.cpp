@@ -307,6 +307,18 @@ static int build_device_weights(moe_net& n, int precision)
             }
         n.small[key] = o; n.small[key + ".lo"] = ol;
         n.scalars["tail_taps"] = (float)taps;
+        if (taps == 9) {   // A fragments for the fused tail (conv3x3_sp EPI 3): slice i = 16 channels, lane row = tap, k = (hh, e)
+            const size_t of = bb.take(4 * 512 * 2);
+            for (int i = 0; i < 4; ++i)
+                for (int l = 0; l < 64; ++l)
+                    for (int e8 = 0; e8 < 8; ++e8) {
+                        const int tap = l & 31, hh = l >> 5;
+                        const int ch = i * 16 + (e8 < 4 ? 4 * hh + e8 : 8 + 4 * hh + (e8 - 4));
+                        const float v = (tap < 9 && ch < C) ? W.data[(size_t)ch * taps + tap] : 0.f;
+                        bb.at<half_t>(of)[(i * 64 + l) * 8 + e8] = (half_t)v;
+                    }
+            n.small[key + ".frag"] = of;
+        }
     };
     n.small["zero"] = bb.take(1024);
     n.small["trash"] = bb.take(4096);
@@ -388,6 +400,12 @@ static int build_device_weights(moe_net& n, int precision)
 // =====================================================================================================
 namespace {
 
+static int conv_impl()   // MOE_CONV_IMPL = sp (default) | pp | v1
+{
+    static const int impl = [] { const char* e = getenv("MOE_CONV_IMPL"); return !e ? 2 : (!strcmp(e, "v1") ? 0 : (!strcmp(e, "pp") ? 1 : 2)); }();
+    return impl;
+}
+
 struct Fwd {
     moe_net& n;
     hipStream_t s;
@@ -421,10 +439,11 @@ struct Fwd {
     }
 
     // one convolution layer: in [B][H][W][64*nseg] -> out [B][H*r][W*r][r>1 ? 64 : 64*nchunks]
-    void conv(const std::string& key, const Act& in, const Act& out, const Act* res, int H, int W, const half_t* plane_w = nullptr,
-              const half_t* plane_w_lo = nullptr)
+    // returns false only when asked for the fused tail (tplanes != nullptr) and the fused kernel cannot take the layer
+    bool conv(const std::string& key, const Act& in, const Act& out, const Act* res, int H, int W, const half_t* plane_w = nullptr,
+              const half_t* plane_w_lo = nullptr, const half_t* tail_w = nullptr, float* tplanes = nullptr)
     {
-        if (dry()) return;
+        if (dry()) return true;
         const ConvLayer& L = n.convs[n.conv_index.at(key)];
         const int out_cs = L.r > 1 ? 64 : 64 * L.nchunks;
         if (direct) {
@@ -437,7 +456,7 @@ struct Fwd {
             d.slope = L.slope; d.scale = L.scale;
             if (L.per_plane) { d.w = (const float*)plane_w; d.w_batch_stride = (long long)L.cout * L.cin; }
             launch_conv_direct(d, s);
-            return;
+            return true;
         }
         ConvArgs a{};
         a.in = in.hi; a.out = out.hi; a.res = res ? res->hi : nullptr;
@@ -457,11 +476,15 @@ struct Fwd {
         a.slope = L.slope; a.scale = L.scale;
         static const int dbg = [] { const char* e = getenv("MOE_DBG"); return e ? atoi(e) : 0; }();
         a.dbg = dbg;
+        a.tail_w = tail_w; a.tplanes = tplanes;
         // MOE_CONV_IMPL = sp (default: software-pipelined epilogue) | pp (two-group ping-pong) | v1 (generic kernel)
-        static const int impl = [] { const char* e = getenv("MOE_CONV_IMPL"); return !e ? 2 : (!strcmp(e, "v1") ? 0 : (!strcmp(e, "pp") ? 1 : 2)); }();
+        const int impl = conv_impl();
         const bool pp = L.taps == 9 && L.nseg == 1 && !L.per_plane && impl != 0;
+        if (tplanes && !(pp && impl == 2 && !x3)) return false;
+        bool fused_ok = true;
         auto launch = [&](const ConvArgs& ca) {
             if (pp && impl == 2 && launch_conv3x3_sp(ca, s)) return;
+            if (ca.tplanes) { fused_ok = false; return; }
             if (pp) launch_conv3x3_pp(ca, s);
             else launch_conv_mfma(ca, L.taps, L.nseg, s);
         };
@@ -477,7 +500,7 @@ struct Fwd {
                 (void)hipMemcpy(host.data(), tr, nb, hipMemcpyDeviceToHost);
                 if (FILE* f = fopen("/tmp/moe_trace.bin", "wb")) { fwrite(host.data(), 1, nb, f); fclose(f); }
                 (void)hipFree(tr);
-                return;
+                return true;
             }
         }
         if (!x3) {
@@ -495,7 +518,7 @@ struct Fwd {
                 n.prof_used += 1;
                 n.prof_flops += 2.0 * (double)B * H * W * L.cout * L.cin * L.taps;   // algorithmic (real channel counts)
             }
-            return;
+            return fused_ok;
         }
         // hi/lo split: (w_lo * a_hi) -> acc32,  += (w_hi * a_lo),  then (w_hi * a_hi) + acc32/2048 and the epilogue
         a.acc32 = acc32;
@@ -505,6 +528,7 @@ struct Fwd {
         launch(p2);
         ConvArgs p3 = a; p3.acc_mode = 3; p3.out_lo = out.lo; p3.res_lo = res ? res->lo : nullptr;
         launch(p3);
+        return true;
     }
 };
 
@@ -521,6 +545,21 @@ size_t acc32_need(const moe_net& n, int B, int h, int w)
         rr *= n.r;
     }
     return best;
+}
+
+bool can_fuse_tail(const moe_net& n, const Fwd& f, int B, int h, int w)
+{
+    static const bool off = [] { const char* e = getenv("MOE_FUSE_TAIL"); return e && !strcmp(e, "0"); }();
+    if (off || f.x3 || f.direct || n.debug || conv_impl() != 2 || n.stages < 1) return false;
+    if (!(n.arch == MOE_ARCH_NET2X || n.arch == MOE_ARCH_NET3X || n.arch == MOE_ARCH_NET4X)) return false;
+    long long sc = 1;
+    for (int s = 0; s < n.stages; ++s) sc *= n.r;
+    if (9ll * B * h * sc * w * sc >= (1ll << 32) - 4096) return false;
+    for (const char* br : {"u", "convt_R1"}) {
+        const auto it = n.conv_index.find(std::string(br) + ".up" + std::to_string(n.stages - 1));
+        if (it == n.conv_index.end() || n.convs[it->second].slope > 1.f) return false;
+    }
+    return true;
 }
 
 int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, long long sH, long long sW, const long long* x_off_dev,
@@ -567,18 +606,37 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         if (n.arch == MOE_ARCH_NETDN) { tail(&Bb, &A, h, w, false); return MOE_OK; }
         // two upsampler branches: R on the trunk output, U on the stem output (models.py:117-123)
         Act fin[2];
+        float* tp[2] = {nullptr, nullptr};
+        const bool fuse = can_fuse_tail(n, f, B, h, w);      // last upsampler conv + 64->1 tail conv in one kernel
         int H = h, W = w;
         for (int br = 0; br < 2; ++br) {
             Act cur = br == 0 ? Bb : A;
             H = h; W = w;
             for (int st = 0; st < n.stages; ++st) {
+                const std::string key = std::string(br == 0 ? "convt_R1" : "u") + ".up" + std::to_string(st);
+                if (fuse && st == n.stages - 1) {
+                    tp[br] = (float*)f.ar.take((size_t)9 * B * H * n.r * W * n.r * 4 + 4096);
+                    const half_t* frag = f.dry() ? nullptr : f.small<half_t>(br == 0 ? "tail_r.frag" : "tail_u.frag");
+                    if (!f.conv(key, cur, Act{}, nullptr, H, W, nullptr, nullptr, frag, f.dry() ? (float*)16 : tp[br]))
+                        return fail(MOE_EINVAL, "fused tail kernel rejected layer %s", key.c_str());
+                    H *= n.r; W *= n.r;
+                    continue;
+                }
                 Act nxt = f.act((long long)B * H * n.r * W * n.r);
-                f.conv(std::string(br == 0 ? "convt_R1" : "u") + ".up" + std::to_string(st), cur, nxt, nullptr, H, W);
+                f.conv(key, cur, nxt, nullptr, H, W);
                 H *= n.r; W *= n.r;
                 f.tap(std::string(br == 0 ? "r" : "u") + ".up" + std::to_string(st), nxt, H, W, 64, 64);
                 cur = nxt;
             }
             fin[br] = cur;
+        }
+        if (fuse) {
+            if (!f.dry()) {
+                TapSumArgs t{};
+                t.t0 = tp[0]; t.t1 = tp[1]; t.y = y; t.y_dtype = y_dtype; t.y_off = y_off_dev; t.B = B; t.H = H; t.W = W;
+                launch_tapsum(t, s);
+            }
+            return MOE_OK;
         }
         tail(&fin[0], &fin[1], H, W, false);
         return MOE_OK;

@@ -155,6 +155,34 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Fused-tail gather: the last upsampler conv wrote, per HR pixel q and tap t, G[t][q] = sum_c Wt[t][c] * act[c][q]; the 3x3 tail
+// conv (zero padded) is then  y[p] = sum_t G[t][p + off_t]  over the in-image neighbours, summed over both branches.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tapsum_kernel(TapSumArgs a)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y, b = blockIdx.z;
+    if (x >= a.W) return;
+    const long long plane = (long long)a.B * a.H * a.W;
+    const long long base = ((long long)b * a.H + y) * a.W + x;
+    float acc = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int yy = y + dy - 1, xx = x + dx - 1;
+            if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+                const long long o = (long long)(dy * 3 + dx) * plane + base + (long long)(dy - 1) * a.W + (dx - 1);
+                acc += a.t0[o];
+                if (a.t1) acc += a.t1[o];
+            }
+        }
+    const long long yo = (a.y_off ? a.y_off[b] : (long long)b * a.H * a.W) + (long long)y * a.W + x;
+    if (a.y_dtype == MOE_F16) ((half_t*)a.y)[yo] = (half_t)acc;
+    else ((float*)a.y)[yo] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Global average pool partial sums (AdaptiveAvgPool2d(1): models.py:190,274): in [B][HW][C] -> [B][nslab][C].
 // Deterministic two-stage reduction (the second stage lives in the gate kernels).
 // ---------------------------------------------------------------------------------------------------
@@ -397,6 +425,11 @@ void launch_tail(const TailArgs& a, hipStream_t s)
     const int blocks = ((a.W + 31) / 32) * ((a.H + 7) / 8) * a.B;
     if (a.taps == 9) hipLaunchKernelGGL((tail_kernel<9>), dim3(blocks), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((tail_kernel<1>), dim3(blocks), dim3(256), 0, s, a);
+}
+
+void launch_tapsum(const TapSumArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(tapsum_kernel, dim3((a.W + 255) / 256, a.H, a.B), dim3(256), 0, s, a);
 }
 
 void launch_pool_partial(const half_t* in, const half_t* in_lo, float* partial, int B, long long HW, int C, int nslab, hipStream_t s)
