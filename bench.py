@@ -61,7 +61,8 @@ def main():
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    local = int(os.environ.get('MOE_FORCE_DEVICE', os.environ.get('LOCAL_RANK', '0')))   # MOE_FORCE_DEVICE: test mode, ranks share a GPU
+    backend = os.environ.get('MOE_DIST_BACKEND', 'nccl')                                     # 'gloo' only for that test mode
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node {}'.format(args.gpus))
@@ -71,7 +72,10 @@ def main():
     dev = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     # ---- model through the plugin table, from a zoo-format file -------------------------------------
     config.deviceId, config.fp16, config.crop_sr, config.tilesPerBatch = local, True, CROP, args.tiles_per_batch
@@ -117,7 +121,7 @@ def main():
     prof = model.get_profile()
     model.set_profile(None)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == 'nccl' else None)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3

@@ -67,8 +67,14 @@ class TileExchange(object):
             seg = [] if src == self.rank else self._segments(src, self.rank, frames)
             recv_split.append(sum(self.off[k + 1] - self.off[k] for _, k in seg))
         send = torch.cat(send_parts) if send_parts else any_pool.new_empty(0)
-        recv = any_pool.new_empty(sum(recv_split))
-        dist.all_to_all_single(recv, send, recv_split, send_split, group=self.group)
+        if send.is_cuda and dist.get_backend(self.group) == 'gloo':
+            # test mode (several ranks sharing one GPU, MOE_DIST_BACKEND=gloo): stage through the host
+            recv_h = torch.empty(sum(recv_split), dtype=send.dtype)
+            dist.all_to_all_single(recv_h, send.cpu(), recv_split, send_split, group=self.group)
+            recv = recv_h.to(send.device)
+        else:
+            recv = any_pool.new_empty(sum(recv_split))
+            dist.all_to_all_single(recv, send, recv_split, send_split, group=self.group)
         pos = 0
         for src in range(self.world):
             if src == self.rank:
@@ -86,6 +92,8 @@ def broadcast_state_dict(sd, src=0, device=None, group=None):
     meta = [[(k, tuple(v.shape)) for k, v in sd.items()]] if rank == src else [None]
     dist.broadcast_object_list(meta, src=src, group=group)
     total = sum(int(torch.Size(s).numel()) for _, s in meta[0])
+    if dist.get_backend(group) == 'gloo':
+        device = None
     flat = torch.empty(total, dtype=torch.float32, device=device)
     if rank == src:
         flat.copy_(torch.cat([v.reshape(-1).float() for v in sd.values()]))

@@ -1,0 +1,34 @@
+#!/usr/bin/env python
+"""Two ranks sharing ONE GPU (MOE_DIST_BACKEND=gloo MOE_FORCE_DEVICE=0): the tile-parallel path of dist.run_frames
+(sharded moe_run_plan_ex -> all-to-all of tile results -> moe_stitch) must reproduce the single-process doCrop bit for bit."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'tests')):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+import golden_defs as gd  # noqa: E402
+from moephoto_amd import imageProcess as ip, runSR  # noqa: E402
+from moephoto_amd.config import config  # noqa: E402
+from moephoto_amd.dist import run_frames  # noqa: E402
+from moephoto_amd.weights import load_state_dict_file, save_state_dict_file  # noqa: E402
+
+dist.init_process_group('gloo')
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.cuda.set_device(0)
+config.deviceId, config.fp16, config.crop_sr, config.modelRoot = 0, True, 64, gd.ZOO
+path = '/tmp/moe_chk_a4_{}.pth'.format(rank)
+save_state_dict_file(gd.synth_state_dict('a4', load_state_dict_file), path)
+runSR.mode_switch['a4'] = (path, runSR.mode_switch['a4'][1])
+opt = runSR.getOpt({'op': 'SR', 'model': 'a', 'scale': 4, 'ensemble': 0})
+frames = [torch.from_numpy(gd.natural_image(50 + f, (3, 150, 200))).cuda().half() for f in range(3)]
+out = run_frames(opt, frames, out_dtype=torch.float16)
+torch.cuda.synchronize()
+assert sorted(out) == [f for f in range(3) if f % world == rank], sorted(out)
+for f, y in out.items():
+    want = ip.doCrop(opt, frames[f])
+    assert torch.equal(y, want), (f, float((y.float() - want.float()).abs().max()))
+dist.barrier()
+print('RANK', rank, 'OK frames', sorted(out))
