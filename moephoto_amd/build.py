@@ -37,6 +37,7 @@ def build_lib(force=False, verbose=False):
     for src in SOURCES:
         obj = os.path.join(HERE, '_obj', os.path.splitext(src)[0] + '.o')
         cmd = [hipcc(), '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-x', 'hip', '-c', os.path.join(CSRC, src), '-o', obj]
+        cmd += os.environ.get('MOE_HIPCC_FLAGS', '').split()      # experiments only, e.g. -DMOE_NO_SGB
         if verbose:
             print(' '.join(cmd))
         subprocess.check_call(cmd)

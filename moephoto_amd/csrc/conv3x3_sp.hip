@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         for (int e = 0; e < 16; ++e) Gacc[o][e] = 0.f;
     const unsigned tplane = (unsigned)a.B * Ho * Wo;                   // elements per tap plane
     const unsigned ttrash = 9u * tplane + lane;                          // slack behind the nine planes
-    auto drain_slice = [&](float16_t (&ac)[2][2], const Item& it, int s8, bool live) {
+    auto drain_slice = [&](float16_t (&ac)[2][2], const Item& it, int s8, bool live, const half4_t (*resv)[2] = nullptr) {
         const int o = s8 >> 2, nb = (s8 >> 1) & 1, gp = s8 & 1;
         const int y = it.pyi * kTileH + w4 * 2 + o, x = it.pxi * kTileW + j;
         const bool ok = (y < a.H) & (x < a.W) & live;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         if (RES) {
 #pragma unroll
             for (int g2 = 0; g2 < 2; ++g2) {
-                const half4_t rv = *(const half4_t*)(a.res + (ok ? opix + g2 * 8 + hh * 4 : trash_off));
+                const half4_t rv = resv ? resv[s8][g2] : *(const half4_t*)(a.res + (ok ? opix + g2 * 8 + hh * 4 : trash_off));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[g2 * 4 + e] += (float)rv[e];
             }
@@ -247,6 +247,20 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         const char* abuf = pbuf + (p & 1) * PATCH_BYTES;
         char* nbuf = pbuf + ((p + 1) & 1) * PATCH_BYTES;
         MOE_STAMP(0)
+        // residual of the tile being drained: all 16 loads go out first, ahead of this iteration's DMA pieces in the in-order
+        // vmcnt queue, so the drain slices never wait on memory
+        half4_t resv[8][2];
+        if (RES) {
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) {
+                const int o = s8 >> 2, nb = (s8 >> 1) & 1, gp = s8 & 1;
+                const int y = itp.pyi * kTileH + w4 * 2 + o, x = itp.pxi * kTileW + j;
+                const bool ok = (y < a.H) & (x < a.W) & drain;
+                const unsigned opix = ((unsigned)(itp.b * Ho + y * r + si) * (unsigned)Wo + (unsigned)(x * r + sj)) * (unsigned)a.out_cs + (unsigned)(cout0 + nb * 32 + gp * 16);
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) resv[s8][g2] = *(const half4_t*)(a.res + (ok ? opix + g2 * 8 + hh * 4 : trash_off));
+            }
+        }
         half8_t wf[2][3][2], af[2][4];
 #define MOE_LOAD_STEP(S, BUF)                                                                              \
     {                                                                                                      \
@@ -282,19 +296,36 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
                             cur[o][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cb][dy][nb], af[cb][pr], cur[o][nb], 0, 0, 0);
                     }
                 }
-            if (s < 8) drain_slice(prev, itp, s, drain);
+            if (s < 8) drain_slice(prev, itp, s, drain, RES ? resv : nullptr);
             // pin the issue order: the ten LDS reads of the next step go out behind the first five MFMAs (their latency
             // then hides under the other seven), the two DMA pieces and the store sit in the middle, and every MFMA is
             // followed by up to five VALU instructions of the drain / address arithmetic (what fits in a 32-cycle shadow)
+#ifndef MOE_NO_SGB
+#ifndef SGB_VALU_A
+#define SGB_VALU_A 3
+#endif
+#ifndef SGB_VALU_B
+#define SGB_VALU_B 5
+#endif
+#ifndef SGB_DSR_SLOTS
+#define SGB_DSR_SLOTS 5
+#endif
+#ifndef SGB_DMA_AT
+#define SGB_DMA_AT 5
+#endif
+#ifndef SGB_ST_AT
+#define SGB_ST_AT 8
+#endif
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (i < 5 && s + 1 < 12) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                if (i < 5) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                else __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-                if ((i == 5 || i == 6) && s <= 5) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                if (i == 8 && s < 8) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+                if (i < SGB_DSR_SLOTS && s + 1 < 12) __builtin_amdgcn_sched_group_barrier(0x100, 10 / SGB_DSR_SLOTS, 0);
+                if (i < SGB_DSR_SLOTS) __builtin_amdgcn_sched_group_barrier(0x002, SGB_VALU_A, 0);
+                else __builtin_amdgcn_sched_group_barrier(0x002, SGB_VALU_B, 0);
+                if ((i == SGB_DMA_AT || i == SGB_DMA_AT + 1) && s <= 5) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if (i == SGB_ST_AT && s < 8) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
             }
+#endif
         }
 #undef MOE_LOAD_STEP
         reset_acc(prev);
