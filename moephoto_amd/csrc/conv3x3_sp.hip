@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         for (int e = 0; e < 16; ++e) Gacc[o][e] = 0.f;
     const unsigned tplane = (unsigned)a.B * Ho * Wo;                   // elements per tap plane
     const unsigned ttrash = 9u * tplane + lane;                          // slack behind the nine planes
-    auto drain_slice = [&](float16_t (&ac)[2][2], const Item& it, int s8, bool live, const half4_t (*resv)[2] = nullptr) {
+    auto drain_slice = [&](float16_t (&ac)[2][2], const Item& it, int s8, bool live, const uint4* resw = nullptr) {
         const int o = s8 >> 2, nb = (s8 >> 1) & 1, gp = s8 & 1;
         const int y = it.pyi * kTileH + w4 * 2 + o, x = it.pxi * kTileW + j;
         const bool ok = (y < a.H) & (x < a.W) & live;
@@ -218,12 +218,15 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         // compiler keeps the predicated-off lanes on a v_cndmask instead of branching around the address arithmetic
         const unsigned opix = ((unsigned)(it.b * Ho + y * r + si) * (unsigned)Wo + (unsigned)(x * r + sj)) * (unsigned)a.out_cs + (unsigned)(cout0 + nb * 32 + gp * 16);
         if (RES) {
+            // the residual was fetched as one 16-byte access per lane in the STORE layout (lane (j,0): channels 16*gp..+7,
+            // lane (j,1): +8..+15); the same v_permlane32_swap pair that builds that layout also undoes it
+            const uint4 w = resw[s8];
+            const auto rx = __builtin_amdgcn_permlane32_swap(w.x, w.z, false, false);
+            const auto ry = __builtin_amdgcn_permlane32_swap(w.y, w.w, false, false);
+            const half4_t r0 = __builtin_bit_cast(half4_t, make_uint2(rx[0], ry[0]));
+            const half4_t r1 = __builtin_bit_cast(half4_t, make_uint2(rx[1], ry[1]));
 #pragma unroll
-            for (int g2 = 0; g2 < 2; ++g2) {
-                const half4_t rv = resv ? resv[s8][g2] : *(const half4_t*)(a.res + (ok ? opix + g2 * 8 + hh * 4 : trash_off));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[g2 * 4 + e] += (float)rv[e];
-            }
+            for (int e = 0; e < 4; ++e) { v[e] += (float)r0[e]; v[4 + e] += (float)r1[e]; }
         }
         // fp16, then one v_permlane32_swap per register: lane (j,0) gets channels 16*gp .. +7, lane (j,1) 16*gp+8 .. +15
         half4_t h0, h1;
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         MOE_STAMP(0)
         // residual of the tile being drained: all 16 loads go out first, ahead of this iteration's DMA pieces in the in-order
         // vmcnt queue, so the drain slices never wait on memory
-        half4_t resv[8][2];
+        uint4 resw[8];
         if (RES) {
 #pragma unroll
             for (int s8 = 0; s8 < 8; ++s8) {
@@ -257,8 +260,7 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
                 const int y = itp.pyi * kTileH + w4 * 2 + o, x = itp.pxi * kTileW + j;
                 const bool ok = (y < a.H) & (x < a.W) & drain;
                 const unsigned opix = ((unsigned)(itp.b * Ho + y * r + si) * (unsigned)Wo + (unsigned)(x * r + sj)) * (unsigned)a.out_cs + (unsigned)(cout0 + nb * 32 + gp * 16);
-#pragma unroll
-                for (int g2 = 0; g2 < 2; ++g2) resv[s8][g2] = *(const half4_t*)(a.res + (ok ? opix + g2 * 8 + hh * 4 : trash_off));
+                resw[s8] = *(const uint4*)(a.res + (ok ? opix + hh * 8 : trash_off));
             }
         }
         half8_t wf[2][3][2], af[2][4];
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
                             cur[o][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cb][dy][nb], af[cb][pr], cur[o][nb], 0, 0, 0);
                     }
                 }
-            if (s < 8) drain_slice(prev, itp, s, drain, RES ? resv : nullptr);
+            if (s < 8) drain_slice(prev, itp, s, drain, resw);
             // pin the issue order: the ten LDS reads of the next step go out behind the first five MFMAs (their latency
             // then hides under the other seven), the two DMA pieces and the store sit in the middle, and every MFMA is
             // followed by up to five VALU instructions of the drain / address arithmetic (what fits in a 32-cycle shadow)
@@ -349,12 +351,24 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
     {   // drain the last tile (patch K-1): it sits in A when K is odd, in B when K is even
         const Item itp = it_prev;
         const bool live = !(a.dbg & 4);
+        uint4 resw[8];
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+            resw[s8] = make_uint4(0, 0, 0, 0);
+            if (RES) {
+                const int o = s8 >> 2, nb = (s8 >> 1) & 1, gp = s8 & 1;
+                const int y = itp.pyi * kTileH + w4 * 2 + o, x = itp.pxi * kTileW + j;
+                const bool ok = (y < a.H) & (x < a.W) & live;
+                const unsigned opix = ((unsigned)(itp.b * Ho + y * r + si) * (unsigned)Wo + (unsigned)(x * r + sj)) * (unsigned)a.out_cs + (unsigned)(cout0 + nb * 32 + gp * 16);
+                resw[s8] = *(const uint4*)(a.res + (ok ? opix + hh * 8 : trash_off));
+            }
+        }
         if (K & 1) {
 #pragma unroll
-            for (int s8 = 0; s8 < 8; ++s8) drain_slice(accA, itp, s8, live);
+            for (int s8 = 0; s8 < 8; ++s8) drain_slice(accA, itp, s8, live, resw);
         } else {
 #pragma unroll
-            for (int s8 = 0; s8 < 8; ++s8) drain_slice(accB, itp, s8, live);
+            for (int s8 = 0; s8 < 8; ++s8) drain_slice(accB, itp, s8, live, resw);
         }
     }
 }
