@@ -26,6 +26,7 @@ struct ConvArgs {
     const half_t* res;    // optional residual, same indexing as out (may alias out)
     const half_t* wpk;    // packed weight fragments [wbatch][chunk][frag][lane][8]
     const float* bias;    // [nchunks*64] in packed output-channel order, or nullptr
+    const float* bias_img; // [nchunks][256] fp32: the chunk's 64 biases then zeros (1-KiB LDS-DMA piece of conv3x3_sp)
     const half_t* zero;   // >= 256 B of zeros (out-of-image taps are redirected here)
     half_t* trash;        // >= 1 KiB write-only scratch (predicated-off stores of the branch-free epilogue land here)
     // FP16X3 (hi/lo split operands): partial products are combined through an fp32 side buffer

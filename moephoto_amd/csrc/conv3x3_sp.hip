@@ -82,6 +82,7 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
     if (K <= 0) return;
 
     const half_t* const zsrc = a.zero + (lane & 7) * 8;
+    const half_t* const bias_src = (const half_t*)(a.bias_img + chunk * 256) + lane * 8;   // 1-KiB image: 64 fp32 biases, then zeros
     // launch-invariant per-lane source offsets of this wave's 11 DMA pieces (elements, relative to the patch origin)
     int poff[NDMA_W];
 #pragma unroll
@@ -119,6 +120,10 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         const bool ok = ((unsigned)(ps.y0 + r) < (unsigned)a.H) & ((unsigned)(ps.x0 + c) < (unsigned)a.W) & (q < NPIX) & live;
         const half_t* src = ps.base + poff[i];
         src = ok ? src : zsrc;
+        // piece 43 is pure padding (q >= 340 for every lane): it carries this chunk's bias image instead, so the bias sits in
+        // LDS behind each patch buffer and the accumulator reset needs no global load (vmcnt is in-order: a load issued
+        // behind in-flight DMA pieces would stall the wave for a full DMA latency)
+        if (i == NDMA_W - 1) src = (w4 == 3) ? bias_src : src;
         dma16(src, dstbuf + n * 1024);
     };
 
@@ -148,15 +153,15 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
     const int cout0 = (r > 1) ? 0 : chunk * kCB;                   // first output channel of this chunk in `out`
     const int Wo = a.W * r, Ho = a.H * r;
 
-    // accumulators start from the bias (engine passes a zero vector when the layer has none): lane (j, hh) register
-    // e of tile [o][nb] is channel nb*32 + 8*(e>>2) + 4*hh + (e&3); the 256-byte vector stays L1/L2 resident
-    const float* const bias_lane = a.bias + chunk * kCB + hh * 4;
+    // accumulators start from the bias (an all-zero image when the layer has none): lane (j, hh) register e of tile [o][nb]
+    // is channel nb*32 + 8*(e>>2) + 4*hh + (e&3)
+    const char* const bias_lds = pbuf + (NDMA_W * 4 - 1) * 1024 + hh * 16;     // padding piece of patch buffer 0
     auto reset_acc = [&](float16_t (&ac)[2][2]) {
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                const float4_t b4 = *(const float4_t*)(bias_lane + nb * 32 + g4 * 8);
+                const float4_t b4 = *(const float4_t*)(bias_lds + (nb * 32 + g4 * 8) * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { ac[0][nb][g4 * 4 + e] = b4[e]; ac[1][nb][g4 * 4 + e] = b4[e]; }
             }
@@ -396,7 +401,7 @@ bool launch_conv3x3_sp(const ConvArgs& a, hipStream_t s)
 {
     if ((a.acc_mode != 0 && !(a.dbg & 64)) || a.slope > 1.f) return false;
     if ((long long)a.B * a.H * a.r * a.W * a.r * a.out_cs >= (1ll << 32) - 4096) return false;   // 32-bit store offsets
-    if (a.scale != 1.f || !a.bias) return false;           // the engine folds ScaleLayer into the weights and always passes a bias vector
+    if (a.scale != 1.f || !a.bias_img) return false;           // the engine folds ScaleLayer into the weights and always passes a bias vector
     const bool act = a.slope != 1.f, res = a.res != nullptr, tail = a.tplanes != nullptr;
     if ((act || tail) && res) return false;
     if (tail && 9ll * a.B * a.H * a.r * a.W * a.r >= (1ll << 32) - 4096) return false;

@@ -53,7 +53,7 @@ struct ConvLayer {               // one MFMA convolution
     int cin = 64, cout = 64, k = 3;
     float slope = 1.f, scale = 1.f;
     bool per_plane = false;      // SEDN trans: weights rebuilt per plane by the SE kernel
-    size_t w_hi = 0, w_lo = 0, bias = 0, w_plain = 0, bias_plain = 0, w_pk32 = 0;   // offsets into the device blob
+    size_t w_hi = 0, w_lo = 0, bias = 0, bias_img = 0, w_plain = 0, bias_plain = 0, w_pk32 = 0;   // offsets into the device blob
     bool has_bias = false;
     int nfrag() const { return nseg * taps * 8; }
 };
@@ -245,11 +245,13 @@ void pack_conv(const Param& W, const Param* bias, int r, ConvLayer& L, BlobBuild
                 }
         }
     L.has_bias = bias != nullptr;
+    L.bias_img = bb.take((size_t)L.nchunks * 256 * 4);        // zero-filled; the biases are written below
     if (bias) {
         L.bias = bb.take((size_t)L.nchunks * 64 * 4);
         for (int np = 0; np < L.nchunks * 64; ++np) {
             const int oc = orig_cout(np, cout, r);
             bb.at<float>(L.bias)[np] = oc >= 0 ? bias->data[oc] * fold : 0.f;
+            bb.at<float>(L.bias_img)[(np / 64) * 256 + (np % 64)] = bb.at<float>(L.bias)[np];
         }
     }
     if (want_plain) {
@@ -463,6 +465,7 @@ struct Fwd {
         a.wpk = L.per_plane ? plane_w : blob<half_t>(L.w_hi);
         a.bias = L.has_bias ? blob<float>(L.bias) : nullptr;
         a.zero = small<half_t>("zero");
+        a.bias_img = blob<float>(L.bias_img);
         a.trash = small<half_t>("trash");
         if (!a.bias) a.bias = small<float>("zero_bias");   // kernels initialise their accumulators from the bias vector
         a.w_batch_stride = L.per_plane ? (long long)L.nchunks * L.nfrag() * 512 : 0;
