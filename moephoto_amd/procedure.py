@@ -1,0 +1,64 @@
+"""Pipeline builder for the SR / DN steps -- the callers of the hot path (python/procedure.py:46-73,109-136,156-201).
+
+`genProcess(steps)` turns a MoePhoto step list such as
+
+    [{'op': 'file'}, {'op': 'DN', 'model': 'lite5', 'strength': 1.0}, {'op': 'SR', 'model': 'a', 'scale': 2}]
+
+into one callable: image in (HWC uint8/uint16 numpy array, or a file when the first step is 'file') -> image out, with
+everything between the upload (toTorch) and the download (toOutput) resident on the device: DN through RGBFilter
+(python/procedure.py:52-55), SR through runSR.sr (:63-73), output = toFloat -> toOutput (:128-136).  The progress/ETA
+nodes of the reference are observability only and are not reproduced; `nodes` lists the resolved
+steps.  Ops other than file / DN / SR / output belong to other model families and raise.
+"""
+from functools import reduce
+
+from . import runDN, runSR
+from .config import config
+from .imageProcess import RGBFilter, apply, readFile, toFloat, toOutput, toTorch, writeFile
+
+stepOpts = dict(SR={'toInt': ['scale', 'ensemble'], 'getOpt': runSR}, DN={'toFloat': ['strength'], 'getOpt': runDN})
+
+
+def convertValues(T, o, keys):
+    for key in keys:
+        if key in o:
+            o[key] = T(o[key])
+
+
+class Context(object):
+    imageMode = 'RGB'
+    palette = None
+
+
+def genProcess(steps, bitDepth=8, outFile=None):
+    steps = [dict(s) for s in steps]
+    ctx = Context()
+    funcs, nodes = [], []
+    has_file = bool(steps) and steps[0]['op'] == 'file'
+    if has_file:
+        funcs.append(readFile(context=ctx))
+    funcs.append(toTorch(bitDepth, config.dtype(), config.device()))
+    for opt in steps:
+        op = opt['op']
+        if op in ('file', 'output'):
+            continue
+        if op not in stepOpts:
+            raise NotImplementedError('op "{}" is not part of the SR/DN hot path this engine implements'.format(op))
+        so = stepOpts[op]
+        convertValues(int, opt, so.get('toInt', []))
+        convertValues(float, opt, so.get('toFloat', []))
+        o = so['getOpt'].getOpt(opt)
+        if o is None:
+            raise ValueError('unknown model for step {}'.format(opt))
+        opt['opt'] = o
+        if op == 'SR':
+            if not opt['scale'] > 1:
+                raise TypeError('Invalid scale setting for SR.')
+            funcs.append(runSR.sr(o))
+        else:
+            funcs.append(RGBFilter(o))
+        nodes.append(dict(op=op, model=opt.get('model'), scale=opt.get('scale', 1)))
+    funcs += [toFloat, toOutput(bitDepth)]
+    if has_file and outFile is not None:
+        funcs.append(lambda im: writeFile(im, outFile, ctx))
+    return (lambda im: reduce(apply, funcs, im)), nodes

@@ -148,6 +148,23 @@ def test_ragged_and_tiny_tiles(dev):
     assert np.abs(y.float().cpu().numpy() - want).max() <= 2.5e-3                 # + fp16 rounding of the output
 
 
+def test_config5_tile_size_vs_independent_device_kernel(dev):
+    """BASELINE config 5 uses 512-px tiles (2048x2048 output per plane).  A CPU oracle run at that size takes minutes, so the
+    MFMA path (software-pipelined convs, fused tail) is checked against the engine's independent scalar device convolution
+    (MOE_PREC_DEBUG_DIRECT: plain OIHW fp32 weights, pixel shuffle by formula, separate tail kernel) on one full 512x512 tile,
+    and the top-left 96x96 corner of the same tile against the CPU oracle of that corner's receptive field."""
+    sd = gd.state_dict_for('a4', load_state_dict_file)
+    x = gd.natural_image(21, (3, 512, 512))[:, None]
+    xd = torch.from_numpy(x).to(dev)
+    y_fast = module_for('a4', 'fp16')(xd)[-1]
+    y_ref = module_for('a4', 'debug_direct')(xd)[-1]
+    assert y_fast.shape == (3, 1, 2048, 2048)
+    assert float((y_fast - y_ref).abs().max()) <= 2e-3            # both carry fp16 activation rounding; weights fp16 vs fp32
+    # corner: outputs within 96 px of the top-left only depend on inputs within 96 + 40 px (17 conv layers + margin)
+    want = onets.forward('net4x', sd, np.ascontiguousarray(x[:, :, :136, :136])).numpy()[:, :, :384, :384]
+    assert np.abs(y_fast[:, :, :384, :384].cpu().numpy() - want).max() <= TOL_FP16_SR
+
+
 STITCH_ONLY = [os.path.basename(p)[:-4] for p in sorted(glob.glob(os.path.join(G, 'stitch_only', '*.npz')))]
 
 
@@ -268,6 +285,36 @@ def test_e2e_uint8_config1(dev):
     assert np.array_equal(out, oio.to_output(oio.to_hwc(y.float().cpu().numpy())))  # the quantiser itself is exact
     v = torch.tensor([[[0.998, 0.5, -0.2, 1.7, 0.00390625, 0.0039]]], device=dev)
     assert ip.toOutput(8)(v).reshape(-1).tolist() == [255, 128, 0, 255, 1, 0]
+
+
+def test_step_chain_dn_then_sr_config3(dev, tmp_path):
+    """BASELINE config 3 in miniature: denoise (dn_lite5, pad 7) then x2 SR (a2, pad 5) as one device-resident chain built by
+    procedure.genProcess from a MoePhoto step list, uint8 PNG file in -> uint8 out; against the oracle chain."""
+    from PIL import Image
+    from moephoto_amd import imageProcess as ip, procedure
+    from moephoto_amd.config import config
+    config.modelRoot, config.crop_sr, config.crop_dn, config.fp16, config.deviceId = gd.ZOO, 64, 64, False, 0
+    ip.modelCache.clear()
+    img = gd.to_u8(gd.natural_image(33, (3, 120, 150)))
+    src = tmp_path / 'in.png'
+    Image.fromarray(img).save(src)
+    process, nodes = procedure.genProcess([{'op': 'file'}, {'op': 'DN', 'model': 'lite5', 'strength': '0.8'},
+                                           {'op': 'SR', 'model': 'a', 'scale': '2', 'ensemble': 0}])
+    assert [n['op'] for n in nodes] == ['DN', 'SR']
+    out = process(str(src))
+    assert out.dtype == np.uint8 and out.shape == (240, 300, 3)
+    x = oio.to_float_image(img)
+    sd_dn, sd_sr = gd.state_dict_for('dn_lite5', load_state_dict_file), gd.state_dict_for('a2', load_state_dict_file)
+    pl = oplanner.prepare((3, 120, 150), 1 << 40, 1e-3, 7, 1, 8, 64)
+    d = ostitch.do_crop(x, pl, 1, onets.model_fn('netdn', sd_dn))
+    d = np.float32(0.8) * d + np.float32(1 - 0.8) * x
+    pl = oplanner.prepare((3, 120, 150), 1 << 40, 1e-3, 5, 2, 8, 64)
+    y = ostitch.do_crop(d, pl, 2, onets.model_fn('net2x', sd_sr))
+    want = oio.to_output(oio.to_hwc(y))
+    diff = np.abs(out.astype(np.int32) - want.astype(np.int32))
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.1          # 1.5e-3 * 256 < 1 grey level
+    with pytest.raises(NotImplementedError):
+        procedure.genProcess([{'op': 'slomo', 'sf': 2}])
 
 
 def test_dropin_protocol_reference_loop(dev):
