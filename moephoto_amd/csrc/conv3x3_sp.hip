@@ -17,6 +17,10 @@
 // conv_mfma.hip / conv3x3_pp.hip; wave tile = 2 output rows x 32 pixels x 64 output channels.
 #include "common.h"
 
+#ifndef MOE_ABL
+#define MOE_ABL 0
+#endif
+
 namespace {
 
 constexpr int PW = kTileW + 2, PH = kTileH + 2, NPIX = PW * PH;   // 34 x 10 halo'd patch
@@ -57,10 +61,11 @@ struct PatchSrc { const half_t* base; int y0, x0; };
 //                             planar).  A small gather kernel then adds the 9 shifted taps of both branches: the 64-channel
 //                             HR tensor (1.6 GB per 12 planes of 1024x1024, written once and read back) never exists.
 // The bias (upsampler convs) costs nothing here: the accumulators are initialised with it instead of zero.
-// timing trace (MOE_DBG & 64): acc32 doubles as a [wg<8][iter<32][wave<4][slot<4] table of s_memtime stamps
+// timing trace (MOE_DBG & 64): acc32 doubles as a [wg<8][iter<32][wave<4][slot<16] table of s_memtime stamps
+// (slots 0..3: iteration start / body end / after vmcnt wait / after barrier; built with -DMOE_STEP_STAMPS also 4+s: end of k-step s)
 #define MOE_STAMP(SLOT)                                                                                 \
     if ((a.dbg & 64) && a.acc32 && bid < 8 && p < 32 && lane == 0)                                        \
-        ((unsigned long long*)a.acc32)[((bid * 32 + p) * 4 + w4) * 4 + (SLOT)] = __builtin_amdgcn_s_memtime();
+        ((unsigned long long*)a.acc32)[((bid * 32 + p) * 4 + w4) * 16 + (SLOT)] = __builtin_amdgcn_s_memtime();
 
 template <int EPI>
 __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
@@ -197,6 +202,11 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = ac[o][nb][gp * 8 + e];     // channels nb*32 + 16*gp + {0..3 | 8..11} + 4*hh
+        if (MOE_ABL & 4) {         // ablation: accumulator reads only
+#pragma unroll
+            for (int e = 0; e < 8; ++e) asm volatile("" ::"v"(v[e]));
+            return;
+        }
         if (ACT) {                 // slope <= 1 (negative slopes included): PReLU(x) = max(x, slope*x)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {      // plain v_max_f32: fmaxf would add a canonicalising v_max per operand
@@ -211,9 +221,14 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
             Gacc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tailw[nb * 2 + gp], bf, Gacc[o], 0, 0, 0);
             if ((s8 & 3) == 3) {     // row o complete: lane (j, hh) holds taps 4*hh .. 4*hh+3 in regs 0..3 and tap 8 + 4*hh in reg 4
                 const unsigned tix = (unsigned)(it.b * Ho + y * r + si) * (unsigned)Wo + (unsigned)(x * r + sj);
+                if (MOE_ABL & 8) {
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) asm volatile("" ::"v"(Gacc[o][k]));
+                } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) a.tplanes[ok ? (unsigned)(4 * hh + k) * tplane + tix : ttrash] = Gacc[o][k];
                 a.tplanes[(ok & (hh == 0)) ? 8u * tplane + tix : ttrash] = Gacc[o][4];
+                }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) Gacc[o][e] = 0.f;
             }
@@ -240,6 +255,19 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         const uint2 u0 = __builtin_bit_cast(uint2, h0), u1 = __builtin_bit_cast(uint2, h1);
         const auto sx = __builtin_amdgcn_permlane32_swap(u0.x, u1.x, false, false);
         const auto sy = __builtin_amdgcn_permlane32_swap(u0.y, u1.y, false, false);
+        if (MOE_ABL & 8) {
+            asm volatile("" ::"v"(sx[0]), "v"(sy[0]), "v"(sx[1]), "v"(sy[1]));
+            return;
+        }
+        if (MOE_ABL & 16) {        // ablation: every store goes to the (L2-resident) slack
+            *(uint4*)(a.out + trash_off) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+            return;
+        }
+        if (MOE_ABL & 32) {        // ablation: same footprint, but each store instruction writes 1 KiB contiguously
+            const unsigned lin = ((unsigned)(it.b * Ho + y * r) * (unsigned)Wo + (unsigned)(it.pxi * kTileW * r)) * (unsigned)a.out_cs + (unsigned)((nb * 2 + gp) * 512 + lane * 8);
+            *(uint4*)(a.out + lin) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+            return;
+        }
         *(uint4*)(a.out + (ok ? opix + hh * 8 : trash_off)) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
     };
 
@@ -290,8 +318,10 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
 #undef MOE_CASE
                 default: break;
             }
-            if (s < 5) { issue_piece(ps, 2 * s, nbuf, fetch); issue_piece(ps, 2 * s + 1, nbuf, fetch); }
-            if (s == 5) issue_piece(ps, 10, nbuf, fetch);
+            if (!(MOE_ABL & 1)) {   // compile-time timing ablation (tools/ablate_sp.sh); 0 in the product build
+                if (s < 5) { issue_piece(ps, 2 * s, nbuf, fetch); issue_piece(ps, 2 * s + 1, nbuf, fetch); }
+                if (s == 5) issue_piece(ps, 10, nbuf, fetch);
+            }
 #pragma unroll
             for (int pr = 0; pr < 4; ++pr)
 #pragma unroll
@@ -303,7 +333,10 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
                             cur[o][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cb][dy][nb], af[cb][pr], cur[o][nb], 0, 0, 0);
                     }
                 }
-            if (s < 8) drain_slice(prev, itp, s, drain, resw);
+            if (!(MOE_ABL & 2) && s < 8) drain_slice(prev, itp, s, drain, resw);
+#ifdef MOE_STEP_STAMPS
+            MOE_STAMP(4 + s)
+#endif
             // pin the issue order: the ten LDS reads of the next step go out behind the first five MFMAs (their latency
             // then hides under the other seven), the two DMA pieces and the store sit in the middle, and every MFMA is
             // followed by up to five VALU instructions of the drain / address arithmetic (what fits in a 32-cycle shadow)
@@ -335,6 +368,12 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
 #endif
         }
 #undef MOE_LOAD_STEP
+        if (MOE_ABL & 2) {   // keep the MFMAs alive without a drain
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) asm volatile("" ::"a"(prev[o][nb]));
+        }
         reset_acc(prev);
         MOE_STAMP(1)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

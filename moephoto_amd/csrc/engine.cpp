@@ -493,7 +493,7 @@ struct Fwd {
         };
         if (!x3 && (dbg & 64) && pp && key == "convt_R1.up1") {   // timing trace of one launch -> /tmp/moe_trace.bin
             unsigned long long* tr = nullptr;
-            const size_t nb = 8 * 32 * 2 * 8 * 8;
+            const size_t nb = 8 * 32 * 4 * 16 * 8;
             if (hipMalloc((void**)&tr, nb) == hipSuccess) {
                 (void)hipMemsetAsync(tr, 0, nb, s);
                 ConvArgs t = a; t.acc32 = (float*)tr;
