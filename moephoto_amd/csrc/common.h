@@ -101,7 +101,8 @@ void launch_tail(const TailArgs& a, hipStream_t s);
 struct TapSumArgs {
     const float* t0; const float* t1;
     void* y; int y_dtype; const long long* y_off;
-    int B, H, W;
+    int B, H, W;   // HR size
+    int r;         // pixel-shuffle factor of the producing conv (2 or 3)
 };
 void launch_tapsum(const TapSumArgs& a, hipStream_t s);
 

@@ -193,8 +193,12 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
     for (int o = 0; o < 2; ++o)
 #pragma unroll
         for (int e = 0; e < 16; ++e) Gacc[o][e] = 0.f;
-    const unsigned tplane = (unsigned)a.B * Ho * Wo;                   // elements per tap plane
-    const unsigned ttrash = 9u * tplane + lane;                          // slack behind the nine planes
+    // tap planes: fp32 [tap 9][phase r*r][b][y][x] at the kernel's INPUT resolution (x contiguous): the HR image of each tap is
+    // kept as its r*r pixel-shuffle phases, because one workgroup (= one 64-channel chunk) produces exactly one phase
+    const unsigned lrplane = (unsigned)a.B * a.H * a.W;                  // elements per (tap, phase) plane
+    const unsigned ph = (unsigned)(si * r + sj);
+    const unsigned ttrash = 9u * (unsigned)(r * r) * lrplane + lane * 4;   // slack behind the planes (16 B per lane)
+    float tap8 = 0.f;                                                    // centre-bottom tap of row 0, parked until row 1 is done
     auto drain_slice = [&](float16_t (&ac)[2][2], const Item& it, int s8, bool live, const uint4* resw = nullptr) {
         const int o = s8 >> 2, nb = (s8 >> 1) & 1, gp = s8 & 1;
         const int y = it.pyi * kTileH + w4 * 2 + o, x = it.pxi * kTileW + j;
@@ -220,14 +224,47 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
             for (int e = 0; e < 8; ++e) bf[e] = (half_t)v[e];            // k = 8*hh + e  <->  channel nb*32 + 16*gp + perm(hh, e)
             Gacc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tailw[nb * 2 + gp], bf, Gacc[o], 0, 0, 0);
             if ((s8 & 3) == 3) {     // row o complete: lane (j, hh) holds taps 4*hh .. 4*hh+3 in regs 0..3 and tap 8 + 4*hh in reg 4
-                const unsigned tix = (unsigned)(it.b * Ho + y * r + si) * (unsigned)Wo + (unsigned)(x * r + sj);
+                // Store instructions are what this epilogue pays for (~110 cycles each beside the MFMAs, whatever their width),
+                // VALU work is free: so a 4x4 transpose inside each lane quad (two DPP exchange stages) turns the four
+                // one-float-per-lane tap registers into ONE 16-byte store: lane (4m+i, hh) ends up with tap 4hh+i of pixels 4m..4m+3.
+                auto xq = [](float v, bool far) {   // value of the quad partner: lane^1 (quad_perm [1,0,3,2]) or lane^2 ([2,3,0,1])
+                    const int u = __builtin_bit_cast(int, v);
+                    return __builtin_bit_cast(float, far ? __builtin_amdgcn_mov_dpp(u, 0x4E, 0xF, 0xF, true) : __builtin_amdgcn_mov_dpp(u, 0xB1, 0xF, 0xF, true));
+                };
+                const bool b0 = j & 1, b1 = j & 2;
+                float t[4], f[4];
+#pragma unroll
+                for (int k = 0; k < 4; k += 2) {
+                    const float p0 = xq(Gacc[o][k], false), p1 = xq(Gacc[o][k + 1], false);
+                    t[k] = b0 ? p1 : Gacc[o][k];
+                    t[k + 1] = b0 ? Gacc[o][k + 1] : p0;
+                }
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const float q0 = xq(t[c], true), q2 = xq(t[2 + c], true);
+                    f[c] = b1 ? q2 : t[c];
+                    f[2 + c] = b1 ? t[2 + c] : q0;
+                }
+                const unsigned xq0 = (unsigned)(it.pxi * kTileW + (j & ~3));
+                const bool okq = (y < a.H) & (xq0 < (unsigned)a.W) & live;        // W is a multiple of 4: a quad is all in or all out
+                const unsigned lrow = (unsigned)(it.b * a.H + y) * (unsigned)a.W;
+                const unsigned off = ((unsigned)(4 * hh + (j & 3)) * (unsigned)(r * r) + ph) * lrplane + lrow + xq0;
+                // tap 8 (register 4 of the hh == 0 lanes): row 0 waits in `tap8`; with row 1 done, one v_permlane32_swap puts row 1
+                // into the hh == 1 lanes and a single store covers both rows
+                float v8 = 0.f;
+                if (o == 0) tap8 = Gacc[0][4];
+                else {
+                    const float row1 = Gacc[1][4];   // (a bit_cast applied directly to the vector element picks element 0)
+                    v8 = __builtin_bit_cast(float, __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, tap8), __builtin_bit_cast(unsigned, row1), false, false)[0]);
+                }
+                const int y8 = it.pyi * kTileH + w4 * 2 + hh;
+                const bool ok8 = (y8 < a.H) & (x < a.W) & live;
+                const unsigned off8 = (8u * (unsigned)(r * r) + ph) * lrplane + (unsigned)(it.b * a.H + y8) * (unsigned)a.W + (unsigned)x;
                 if (MOE_ABL & 8) {
-#pragma unroll
-                    for (int k = 0; k < 5; ++k) asm volatile("" ::"v"(Gacc[o][k]));
+                    asm volatile("" ::"v"(f[0]), "v"(f[1]), "v"(f[2]), "v"(f[3]), "v"(v8));
                 } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) a.tplanes[ok ? (unsigned)(4 * hh + k) * tplane + tix : ttrash] = Gacc[o][k];
-                a.tplanes[(ok & (hh == 0)) ? 8u * tplane + tix : ttrash] = Gacc[o][4];
+                    *(float4*)(a.tplanes + (okq ? off : ttrash)) = make_float4(f[0], f[1], f[2], f[3]);
+                    if (o == 1) a.tplanes[ok8 ? off8 : ttrash] = v8;
                 }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) Gacc[o][e] = 0.f;
@@ -256,6 +293,10 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         const auto sx = __builtin_amdgcn_permlane32_swap(u0.x, u1.x, false, false);
         const auto sy = __builtin_amdgcn_permlane32_swap(u0.y, u1.y, false, false);
         if (MOE_ABL & 8) {
+            asm volatile("" ::"v"(sx[0]), "v"(sy[0]), "v"(sx[1]), "v"(sy[1]));
+            return;
+        }
+        if ((MOE_ABL & 64) && (s8 & 1)) {   // ablation: every other store dropped
             asm volatile("" ::"v"(sx[0]), "v"(sy[0]), "v"(sx[1]), "v"(sy[1]));
             return;
         }

@@ -491,7 +491,8 @@ struct Fwd {
             if (pp) launch_conv3x3_pp(ca, s);
             else launch_conv_mfma(ca, L.taps, L.nseg, s);
         };
-        if (!x3 && (dbg & 64) && pp && key == "convt_R1.up1") {   // timing trace of one launch -> /tmp/moe_trace.bin
+        static const std::string trace_key = [] { const char* e = getenv("MOE_TRACE_KEY"); return std::string(e ? e : "convt_R1.up1"); }();
+        if (!x3 && (dbg & 64) && pp && key == trace_key) {   // timing trace of one launch -> /tmp/moe_trace.bin
             unsigned long long* tr = nullptr;
             const size_t nb = 8 * 32 * 4 * 16 * 8;
             if (hipMalloc((void**)&tr, nb) == hipSuccess) {
@@ -636,7 +637,7 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         if (fuse) {
             if (!f.dry()) {
                 TapSumArgs t{};
-                t.t0 = tp[0]; t.t1 = tp[1]; t.y = y; t.y_dtype = y_dtype; t.y_off = y_off_dev; t.B = B; t.H = H; t.W = W;
+                t.t0 = tp[0]; t.t1 = tp[1]; t.y = y; t.y_dtype = y_dtype; t.y_off = y_off_dev; t.B = B; t.H = H; t.W = W; t.r = n.r;
                 launch_tapsum(t, s);
             }
             return MOE_OK;

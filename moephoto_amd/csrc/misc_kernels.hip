@@ -157,14 +157,16 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a)
 // ---------------------------------------------------------------------------------------------------
 // Fused-tail gather: the last upsampler conv wrote, per HR pixel q and tap t, G[t][q] = sum_c Wt[t][c] * act[c][q]; the 3x3 tail
 // conv (zero padded) is then  y[p] = sum_t G[t][p + off_t]  over the in-image neighbours, summed over both branches.
+// G is stored as [tap][phase (Y%r)*r + X%r][b][Y/r][X/r] (conv3x3_sp.hip: one workgroup produces one pixel-shuffle phase).
 // ---------------------------------------------------------------------------------------------------
+template <int R>
 __global__ __launch_bounds__(256) void tapsum_kernel(TapSumArgs a)
 {
     const int x = blockIdx.x * 256 + threadIdx.x;
     const int y = blockIdx.y, b = blockIdx.z;
     if (x >= a.W) return;
-    const long long plane = (long long)a.B * a.H * a.W;
-    const long long base = ((long long)b * a.H + y) * a.W + x;
+    const int h = a.H / R, w = a.W / R;
+    const long long lrplane = (long long)a.B * h * w;
     float acc = 0.f;
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
@@ -172,7 +174,8 @@ __global__ __launch_bounds__(256) void tapsum_kernel(TapSumArgs a)
         for (int dx = 0; dx < 3; ++dx) {
             const int yy = y + dy - 1, xx = x + dx - 1;
             if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
-                const long long o = (long long)(dy * 3 + dx) * plane + base + (long long)(dy - 1) * a.W + (dx - 1);
+                const int ph = (yy % R) * R + (xx % R);
+                const long long o = ((long long)(dy * 3 + dx) * (R * R) + ph) * lrplane + ((long long)b * h + yy / R) * w + xx / R;
                 acc += a.t0[o];
                 if (a.t1) acc += a.t1[o];
             }
@@ -429,7 +432,9 @@ void launch_tail(const TailArgs& a, hipStream_t s)
 
 void launch_tapsum(const TapSumArgs& a, hipStream_t s)
 {
-    hipLaunchKernelGGL(tapsum_kernel, dim3((a.W + 255) / 256, a.H, a.B), dim3(256), 0, s, a);
+    const dim3 grid((a.W + 255) / 256, a.H, a.B);
+    if (a.r == 3) tapsum_kernel<3><<<grid, dim3(256), 0, s>>>(a);
+    else tapsum_kernel<2><<<grid, dim3(256), 0, s>>>(a);
 }
 
 void launch_pool_partial(const half_t* in, const half_t* in_lo, float* partial, int B, long long HW, int C, int nslab, hipStream_t s)
