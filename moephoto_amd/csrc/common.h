@@ -103,6 +103,7 @@ struct TapSumArgs {
     void* y; int y_dtype; const long long* y_off;
     int B, H, W;   // HR size
     int r;         // pixel-shuffle factor of the producing conv (2 or 3)
+    int vec_ok;    // r == 2 and every output row start is 16-byte aligned: the 8-outputs-per-thread kernel may be used
 };
 void launch_tapsum(const TapSumArgs& a, hipStream_t s);
 

@@ -414,6 +414,7 @@ struct Fwd {
     int B, h, w;
     Arena ar;
     bool x3, direct;
+    bool y_vec = false;
     float* acc32 = nullptr;
     size_t acc32_elems = 0;
     bool dry() const { return ar.base == nullptr; }
@@ -638,6 +639,7 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
             if (!f.dry()) {
                 TapSumArgs t{};
                 t.t0 = tp[0]; t.t1 = tp[1]; t.y = y; t.y_dtype = y_dtype; t.y_off = y_off_dev; t.B = B; t.H = H; t.W = W; t.r = n.r;
+                t.vec_ok = n.r == 2 && f.y_vec && W % 8 == 0;
                 launch_tapsum(t, s);
             }
             return MOE_OK;
@@ -737,7 +739,7 @@ size_t workspace_need(moe_net& n, int B, int h, int w)
 }
 
 int forward_dev(moe_net& n, const void* x, int x_dtype, int B, int h, int w, long long sB, long long sH, long long sW,
-                const long long* x_off_dev, void* y, int y_dtype, const long long* y_off_dev, hipStream_t s)
+                const long long* x_off_dev, void* y, int y_dtype, const long long* y_off_dev, hipStream_t s, bool y_off_mult8 = true)
 {
     if (!n.finalized) return fail(MOE_ESTATE, "moe_net_forward: net is not finalized (load_state_dict + to(device) first)");
     if (B < 1 || h < 1 || w < 1) return fail(MOE_EINVAL, "moe_net_forward: bad shape B=%d h=%d w=%d", B, h, w);
@@ -754,6 +756,7 @@ int forward_dev(moe_net& n, const void* x, int x_dtype, int B, int h, int w, lon
         n.ws_bytes = need;
     }
     Fwd f{n, s, B, h, w, Arena{n.ws, 0}, n.precision == MOE_PREC_FP16X3, n.precision == MOE_PREC_DEBUG_DIRECT};
+    f.y_vec = y_off_mult8 && ((uintptr_t)y % 16 == 0);   // every output plane starts 16-byte aligned: wide stores allowed
     int rc = run_forward(n, f, x, x_dtype, sB, sH, sW, x_off_dev, y, y_dtype, y_off_dev);
     if (rc) return rc;
     hipError_t e = hipGetLastError();
@@ -802,6 +805,8 @@ static int plan_device_tables(const Plan& p, int device, int C, int64_t sC, int6
         d.group_count.push_back(cnt);
     }
     if (xo.empty()) { xo.push_back(0); yo.push_back(0); }
+    d.y_mult8 = true;
+    for (long long v : yo) d.y_mult8 = d.y_mult8 && (v % 8 == 0);
     // tile_off scaled to C planes (C may differ from the planning shape's channel count, e.g. alpha stripped)
     std::vector<long long> toff(nt);
     for (size_t k = 0; k < nt; ++k) toff[k] = p.tile_off[k] / p.C * C;
@@ -960,7 +965,9 @@ int moe_net_forward(moe_net* n, const void* x, int x_dtype, int B, int h, int w,
         if (x_off) { xo = (long long*)tmp; HIP_TRY(hipMemcpy(xo, x_off, (size_t)B * 8, hipMemcpyHostToDevice)); }
         if (y_off) { yo = (long long*)tmp + B; HIP_TRY(hipMemcpy(yo, y_off, (size_t)B * 8, hipMemcpyHostToDevice)); }
     }
-    int rc = forward_dev(*n, x, x_dtype, B, h, w, sB, sH, sW, xo, y, y_dtype, yo, s);
+    bool mult8 = true;
+    if (y_off) for (int i = 0; i < B; ++i) mult8 = mult8 && (y_off[i] % 8 == 0);
+    int rc = forward_dev(*n, x, x_dtype, B, h, w, sB, sH, sW, xo, y, y_dtype, yo, s, mult8);
     if (tmp) { (void)hipStreamSynchronize(s); (void)hipFree(tmp); }
     return rc;
 }
@@ -1133,7 +1140,7 @@ int moe_run_plan_ex(moe_net* n, const moe_plan* pl, const void* img, int img_dty
         for (int t0 = 0; t0 < nt; t0 += per) {
             const int cnt = std::min(per, nt - t0);
             const long long slot = (long long)(d->group_first[gi] + t0) * C;
-            rc = forward_dev(*n, img, img_dtype, cnt * C, g.th, g.tw, 0, sH, sW, d->x_off + slot, pool, MOE_F32, d->y_off + slot, s);
+            rc = forward_dev(*n, img, img_dtype, cnt * C, g.th, g.tw, 0, sH, sW, d->x_off + slot, pool, MOE_F32, d->y_off + slot, s, d->y_mult8);
             if (rc) return rc;
         }
     }

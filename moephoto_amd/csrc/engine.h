@@ -26,6 +26,7 @@ struct PlanDeviceCache {       // device-side tables of a plan for one (layout, 
     int C = 0;
     int64_t sC = 0, sH = 0, sW = 0;
     int shard_index = 0, shard_count = 1;
+    bool y_mult8 = false;      // every y_off entry is a multiple of 8 elements (16-byte aligned output planes)
     std::vector<int> group_first, group_count;   // per plan group: first slot / number of this shard's tiles
     void* blob = nullptr;      // one allocation: all tables below
     long long* x_off = nullptr;    // [ngroups-concatenated tiles][C]

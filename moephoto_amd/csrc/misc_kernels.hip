@@ -185,6 +185,62 @@ __global__ __launch_bounds__(256) void tapsum_kernel(TapSumArgs a)
     else ((float*)a.y)[yo] = acc;
 }
 
+// R = 2 specialisation: one thread makes 8 consecutive outputs of one HR row from 16-byte loads.  With x0 = 4*xq, the outputs
+// X = 2*x0 + e (e = 0..7) of tap column dx read HR columns 2*x0 + e + dx - 1: for each column phase sj that is the aligned
+// quad [x0, x0+4) of the phase plane, shifted by one element for (dx = 0, sj = 1) and (dx = 2, sj = 0) -- those two take one
+// extra scalar load.  Same summation order per output as the generic kernel (taps ascending, branch 0 then 1).
+__global__ __launch_bounds__(256) void tapsum2_kernel(TapSumArgs a)
+{
+    const int h = a.H >> 1, w = a.W >> 1, nq = w >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)a.B * a.H * nq) return;
+    const int xq = (int)(idx % nq);
+    const int y = (int)((idx / nq) % a.H), b = (int)(idx / ((long long)nq * a.H));
+    const int x0 = xq * 4;
+    const long long lrplane = (long long)a.B * h * w;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int yy = y + dy - 1;
+        if (yy < 0 || yy >= a.H) continue;
+        const int si = yy & 1;
+        const long long row = ((long long)b * h + (yy >> 1)) * w + x0;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const long long p0 = ((long long)(dy * 3 + dx) * 4 + si * 2) * lrplane + row, p1 = p0 + lrplane;   // sj = 0 / 1 planes
+#pragma unroll
+            for (int br = 0; br < 2; ++br) {
+                const float* t = br ? a.t1 : a.t0;
+                if (!t) continue;
+                const float4 q0 = *(const float4*)(t + p0), q1 = *(const float4*)(t + p1);
+                if (dx == 1) {
+                    acc[0] += q0.x; acc[1] += q1.x; acc[2] += q0.y; acc[3] += q1.y;
+                    acc[4] += q0.z; acc[5] += q1.z; acc[6] += q0.w; acc[7] += q1.w;
+                } else if (dx == 0) {      // even outputs read plane sj=1 one element to the left
+                    const float l = x0 > 0 ? t[p1 - 1] : 0.f;
+                    acc[0] += l;    acc[1] += q0.x; acc[2] += q1.x; acc[3] += q0.y;
+                    acc[4] += q1.y; acc[5] += q0.z; acc[6] += q1.z; acc[7] += q0.w;
+                } else {                   // odd outputs read plane sj=0 one element to the right
+                    const float rr = x0 + 4 < w ? t[p0 + 4] : 0.f;
+                    acc[0] += q1.x; acc[1] += q0.y; acc[2] += q1.y; acc[3] += q0.z;
+                    acc[4] += q1.z; acc[5] += q0.w; acc[6] += q1.w; acc[7] += rr;
+                }
+            }
+        }
+    }
+    const long long yo = (a.y_off ? a.y_off[b] : (long long)b * a.H * a.W) + (long long)y * a.W + 2 * x0;
+    if (a.y_dtype == MOE_F16) {
+        half8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)acc[e];
+        *(half8_t*)((half_t*)a.y + yo) = o;
+    } else {
+        float* yp = (float*)a.y + yo;
+        *(float4*)yp = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *(float4*)(yp + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Global average pool partial sums (AdaptiveAvgPool2d(1): models.py:190,274): in [B][HW][C] -> [B][nslab][C].
 // Deterministic two-stage reduction (the second stage lives in the gate kernels).
@@ -434,7 +490,10 @@ void launch_tapsum(const TapSumArgs& a, hipStream_t s)
 {
     const dim3 grid((a.W + 255) / 256, a.H, a.B);
     if (a.r == 3) tapsum_kernel<3><<<grid, dim3(256), 0, s>>>(a);
-    else tapsum_kernel<2><<<grid, dim3(256), 0, s>>>(a);
+    else if (a.vec_ok) {
+        const long long n = (long long)a.B * a.H * (a.W / 8);
+        tapsum2_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(a);
+    } else tapsum_kernel<2><<<grid, dim3(256), 0, s>>>(a);
 }
 
 void launch_pool_partial(const half_t* in, const half_t* in_lo, float* partial, int B, long long HW, int C, int nslab, hipStream_t s)
