@@ -14,7 +14,9 @@ __device__ __forceinline__ float ld1(const void* p, long long i) { return (float
 // ---------------------------------------------------------------------------------------------------
 // Stem: PReLU(conv 1->64) (models.py:112,117 conv_input+relu; SEDN :219,223; lite 1x1 MoeNet_lite2.py:28,40).
 // fp32 weights and arithmetic (the stem's weights are the single most sensitive ones to fp16 rounding).
-// One thread = one pixel x 8 channels -> one 16-byte store; 8 consecutive threads write one 128-B line.
+// One thread = 8 channels x 4 consecutive pixels of a row: its 72 weights sit in registers, the 3 x 6 input window is loaded
+// once (18 loads for 288 FMAs), and it issues four 16-byte stores; 8 consecutive threads (the 8 channel groups of the same
+// pixels) write whole 128-B lines.  The kernel is VALU-bound otherwise (one pixel per thread: ~200 instructions for 72 FMAs).
 // ---------------------------------------------------------------------------------------------------
 template <typename TIN, int TAPS>
 __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
@@ -22,38 +24,58 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
     __shared__ float w[TAPS * 64];
     for (int i = threadIdx.x; i < TAPS * 64; i += 256) w[i] = a.w[i];
     __syncthreads();
+    constexpr int PX = 4;
+    const int nq = (a.W + PX - 1) / PX;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long npix = (long long)a.B * a.H * a.W;
-    const long long p = idx >> 3;
-    if (p >= npix) return;
+    const long long q = idx >> 3;                        // (b, y, x-quad)
+    if (q >= (long long)a.B * a.H * nq) return;
     const int cg = (int)(idx & 7) * 8;
-    const int x = (int)(p % a.W);
-    const long long t = p / a.W;
+    const int x0 = (int)(q % nq) * PX;
+    const long long t = q / nq;
     const int y = (int)(t % a.H);
     const int b = (int)(t / a.H);
     const TIN* xp = (const TIN*)a.x + (a.x_off ? a.x_off[b] : (long long)b * a.sB);
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     constexpr int KD = (TAPS == 9) ? 3 : 1, PAD = (TAPS == 9) ? 1 : 0;
+    float wr[TAPS][8];
 #pragma unroll
-    for (int dy = 0; dy < KD; ++dy)
+    for (int k = 0; k < TAPS; ++k) {
+        const float4 w0 = *(const float4*)(w + k * 64 + cg), w1 = *(const float4*)(w + k * 64 + cg + 4);
+        wr[k][0] = w0.x; wr[k][1] = w0.y; wr[k][2] = w0.z; wr[k][3] = w0.w;
+        wr[k][4] = w1.x; wr[k][5] = w1.y; wr[k][6] = w1.z; wr[k][7] = w1.w;
+    }
+    float v[KD][PX + 2 * PAD];
 #pragma unroll
-        for (int dx = 0; dx < KD; ++dx) {
-            const int yy = y + dy - PAD, xx = x + dx - PAD;
-            float v = 0.f;
-            if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) v = (float)xp[yy * a.sH + xx * a.sW];
-            const float* wt = w + (dy * KD + dx) * 64 + cg;
+    for (int dy = 0; dy < KD; ++dy) {
+        const int yy = y + dy - PAD;
+        const bool rok = yy >= 0 && yy < a.H;
+        const TIN* rp = xp + (long long)yy * a.sH;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += v * wt[e];
+        for (int c = 0; c < PX + 2 * PAD; ++c) {
+            const int xx = x0 + c - PAD;
+            v[dy][c] = (rok && xx >= 0 && xx < a.W) ? (float)rp[(long long)xx * a.sW] : 0.f;
         }
-    half8_t o;
+    }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (half_t)prelu(acc[e], a.slope);
-    *(half8_t*)(a.out + p * 64 + cg) = o;
-    if (a.out_lo) {
-        half8_t l;
+    for (int e4 = 0; e4 < PX; ++e4) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) l[e] = (half_t)((prelu(acc[e], a.slope) - (float)o[e]) * 2048.f);
-        *(half8_t*)(a.out_lo + p * 64 + cg) = l;
+        for (int dy = 0; dy < KD; ++dy)       // same accumulation order as one pixel per thread: taps ascending
+#pragma unroll
+            for (int dx = 0; dx < KD; ++dx)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += v[dy][e4 + dx] * wr[dy * KD + dx][e];
+        if (x0 + e4 >= a.W) continue;
+        const long long p = ((long long)b * a.H + y) * a.W + x0 + e4;
+        half8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)prelu(acc[e], a.slope);
+        *(half8_t*)(a.out + p * 64 + cg) = o;
+        if (a.out_lo) {
+            half8_t l;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) l[e] = (half_t)((prelu(acc[e], a.slope) - (float)o[e]) * 2048.f);
+            *(half8_t*)(a.out_lo + p * 64 + cg) = l;
+        }
     }
 }
 
@@ -468,7 +490,7 @@ __global__ void nhwc_to_nchw_kernel(const half_t* in, const half_t* in_lo, float
 
 void launch_stem(const StemArgs& a, hipStream_t s)
 {
-    const long long n = (long long)a.B * a.H * a.W * 8;
+    const long long n = (long long)a.B * a.H * ((a.W + 3) / 4) * 8;
     const int blocks = (int)((n + 255) / 256);
     if (a.taps == 9) {
         if (a.x_dtype == MOE_F16) hipLaunchKernelGGL((stem_kernel<half_t, 9>), dim3(blocks), dim3(256), 0, s, a);
