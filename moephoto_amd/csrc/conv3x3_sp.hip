@@ -132,14 +132,28 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         dma16(src, dstbuf + n * 1024);
     };
 
-    {   // prologue: weights + the first patch
+    {   // prologue: weights + the first patch.  Every workgroup of a chunk wants the same 72 KiB at the same moment: each starts
+        // at a different fragment (rotation by workgroup index) so that they do not all queue on the same L2 channel
+        constexpr int p = 0;
+        MOE_STAMP(14)
         const half_t* wsrc = a.wpk + (long long)chunk * (WBYTES / 2);
-        for (int f = w4; f < NFRAG; f += 4) dma16(wsrc + f * 512 + lane * 8, wlds + f * 1024);
+#ifndef MOE_NO_WROT
+        const int rot = (bid >> 3) % (NFRAG / 4);
+#else
+        const int rot = 0;
+#endif
+        for (int k = 0; k < NFRAG / 4; ++k) {
+            int fk = k + rot;
+            fk -= fk >= NFRAG / 4 ? NFRAG / 4 : 0;
+            const int f = fk * 4 + w4;
+            dma16(wsrc + f * 512 + lane * 8, wlds + f * 1024);
+        }
         const PatchSrc ps = patch_src(decode(g, a.px, a.py));
 #pragma unroll
         for (int i = 0; i < NDMA_W; ++i) issue_piece(ps, i, pbuf);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        MOE_STAMP(15)
     }
 
     // LDS read addressing: pixel (row, col) at (row*34 + col)*128, 16-B slot s stored at slot s ^ ((col>>1)&7)
@@ -312,6 +326,21 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         *(uint4*)(a.out + (ok ? opix + hh * 8 : trash_off)) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
     };
 
+    // residual of the tile being MULTIPLIED (drained one iteration later): slice k is fetched in k-step k+1, right after the
+    // drain of the previous tile released its registers, so every load has eleven k-steps to land (issued at the start of the
+    // draining iteration they stalled its first slice for a full memory latency)
+    uint4 resw[8];
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) resw[s8] = make_uint4(0, 0, 0, 0);
+    auto fetch_res = [&](const Item& it, int s8) {
+        const int o = s8 >> 2, nb = (s8 >> 1) & 1, gp = s8 & 1;
+        const int y = it.pyi * kTileH + w4 * 2 + o, x = it.pxi * kTileW + j;
+        const bool ok = (y < a.H) & (x < a.W);
+        const unsigned opix = ((unsigned)(it.b * Ho + y * r + si) * (unsigned)Wo + (unsigned)(x * r + sj)) * (unsigned)a.out_cs + (unsigned)(cout0 + nb * 32 + gp * 16);
+        unsigned off = ok ? opix + hh * 8 : trash_off;
+        asm volatile("" : "+v"(off));        // keep the select: the compiler otherwise turns it into two predicated loads behind branches
+        resw[s8] = *(const uint4*)(a.res + off);
+    };
     Item it_cur = decode(g, a.px, a.py), it_prev = it_cur, it_next = advance(it_cur);
     // iteration p (0 <= p < K): multiply patch p (buffer p&1) into `cur`; drain patch p-1 from `prev` (stores predicated
     // off for p == 0); fetch patch p+1 (source predicated to the zero page for the last one).  No branches inside: the
@@ -324,18 +353,9 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         const char* abuf = pbuf + (p & 1) * PATCH_BYTES;
         char* nbuf = pbuf + ((p + 1) & 1) * PATCH_BYTES;
         MOE_STAMP(0)
-        // residual of the tile being drained: all 16 loads go out first, ahead of this iteration's DMA pieces in the in-order
-        // vmcnt queue, so the drain slices never wait on memory
-        uint4 resw[8];
-        if (RES) {
+        if (RES) {   // pin the compiler's wait for the residual registers here, before this iteration issues any memory operation
 #pragma unroll
-            for (int s8 = 0; s8 < 8; ++s8) {
-                const int o = s8 >> 2, nb = (s8 >> 1) & 1, gp = s8 & 1;
-                const int y = itp.pyi * kTileH + w4 * 2 + o, x = itp.pxi * kTileW + j;
-                const bool ok = (y < a.H) & (x < a.W) & drain;
-                const unsigned opix = ((unsigned)(itp.b * Ho + y * r + si) * (unsigned)Wo + (unsigned)(x * r + sj)) * (unsigned)a.out_cs + (unsigned)(cout0 + nb * 32 + gp * 16);
-                resw[s8] = *(const uint4*)(a.res + (ok ? opix + hh * 8 : trash_off));
-            }
+            for (int s8 = 0; s8 < 8; ++s8) asm volatile("" : "+v"(resw[s8].x), "+v"(resw[s8].y), "+v"(resw[s8].z), "+v"(resw[s8].w));
         }
         half8_t wf[2][3][2], af[2][4];
 #define MOE_LOAD_STEP(S, BUF)                                                                              \
@@ -375,6 +395,7 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
                     }
                 }
             if (!(MOE_ABL & 2) && s < 8) drain_slice(prev, itp, s, drain, resw);
+            if (RES && s >= 1 && s <= 8) fetch_res(it_cur, s - 1);   // slice s-1's registers were consumed in the previous step
 #ifdef MOE_STEP_STAMPS
             MOE_STAMP(4 + s)
 #endif
@@ -404,6 +425,7 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
                 if (i < SGB_DSR_SLOTS) __builtin_amdgcn_sched_group_barrier(0x002, SGB_VALU_A, 0);
                 else __builtin_amdgcn_sched_group_barrier(0x002, SGB_VALU_B, 0);
                 if ((i == SGB_DMA_AT || i == SGB_DMA_AT + 1) && s <= 5) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if (RES && i == SGB_DMA_AT + 2 && s >= 1 && s <= 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 if (i == SGB_ST_AT && s < 8) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
             }
 #endif
@@ -419,7 +441,10 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         MOE_STAMP(1)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         MOE_STAMP(2)
-        __syncthreads();
+        // bare s_barrier: __syncthreads() carries a workgroup fence, for which the compiler drains vmcnt to 0 -- that would wait for
+        // every store acknowledgement and for the residual loads just issued.  Nothing here communicates through global memory;
+        // the LDS side is ordered by the explicit vmcnt wait above (DMA landed) and by the MFMAs having consumed every ds_read.
+        __builtin_amdgcn_s_barrier();
         MOE_STAMP(3)
         it_prev = it_cur; it_cur = it_next; it_next = advance(it_next);
     };
@@ -436,18 +461,7 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
     {   // drain the last tile (patch K-1): it sits in A when K is odd, in B when K is even
         const Item itp = it_prev;
         const bool live = !(a.dbg & 4);
-        uint4 resw[8];
-#pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8) {
-            resw[s8] = make_uint4(0, 0, 0, 0);
-            if (RES) {
-                const int o = s8 >> 2, nb = (s8 >> 1) & 1, gp = s8 & 1;
-                const int y = itp.pyi * kTileH + w4 * 2 + o, x = itp.pxi * kTileW + j;
-                const bool ok = (y < a.H) & (x < a.W) & live;
-                const unsigned opix = ((unsigned)(itp.b * Ho + y * r + si) * (unsigned)Wo + (unsigned)(x * r + sj)) * (unsigned)a.out_cs + (unsigned)(cout0 + nb * 32 + gp * 16);
-                resw[s8] = *(const uint4*)(a.res + (ok ? opix + hh * 8 : trash_off));
-            }
-        }
+        // (its residual was fetched in steps 8..11 of the last iteration)
         if (K & 1) {
 #pragma unroll
             for (int s8 = 0; s8 < 8; ++s8) drain_slice(accA, itp, s8, live, resw);

@@ -9,3 +9,6 @@ for wg in (0, 3, 5):
         if a[:, 4:].any():
             st = np.concatenate([a[:, :1], a[:, 4:16]], axis=1)
             print('      per-step cycles (steps 0..11):', ' '.join(str(int(v)) for v in np.median(np.diff(st, axis=1), axis=0)))
+pro = t[:, 0, :, 15] - t[:, 0, :, 14]
+if pro.any():
+    print('prologue cycles per wg (wave 0):', ' '.join(str(int(v)) for v in pro[:, 0]))
