@@ -362,6 +362,26 @@ def toOutput(bitDepth):
 toOutput8 = toOutput(8)
 
 
+def toNumPy(bitDepth):
+    """python/imageProcess.py:216-229: (raw frame bytes, height, width) -> (H,W,3) array (the video path's `buffer` source;
+    ffmpeg delivers bgr24 / bgr48le).  The reference widens to fp32 here and divides in toTorch; the integer view is kept
+    instead and `toTorch` does the division on the device -- same values, one host copy less."""
+    dtype = np.uint8 if bitDepth <= 8 else np.uint16
+
+    def f(args):
+        buffer, height, width = args
+        if not buffer:
+            return None
+        return np.frombuffer(buffer, dtype=dtype).reshape((height, width, 3))
+    return f
+
+
+def toBuffer(bitDepth):
+    """python/imageProcess.py:231-236: quantised (H,W,C) array -> raw bytes for the encoder pipe."""
+    dtype = np.uint8 if bitDepth <= 8 else np.uint16
+    return lambda im: np.ascontiguousarray(im, dtype=dtype).tobytes() if im is not None else None
+
+
 def readFile(nodes=[], context=None):
     from PIL import Image
 

@@ -4,7 +4,8 @@
 
     [{'op': 'file'}, {'op': 'DN', 'model': 'lite5', 'strength': 1.0}, {'op': 'SR', 'model': 'a', 'scale': 2}]
 
-into one callable: image in (HWC uint8/uint16 numpy array, or a file when the first step is 'file') -> image out, with
+into one callable: image in (HWC uint8/uint16 numpy array, a file when the first step is 'file', or a raw video frame
+`(bytes, height, width)` when it is {'op': 'buffer', 'bitDepth': 16} -- python/video.py:23, procedure.py:141-142) -> image out, with
 everything between the upload (toTorch) and the download (toOutput) resident on the device: DN through RGBFilter
 (python/procedure.py:52-55), SR through runSR.sr (:63-73), output = toFloat -> toOutput (:128-136).  The progress/ETA
 nodes of the reference are observability only and are not reproduced; `nodes` lists the resolved
@@ -14,7 +15,7 @@ from functools import reduce
 
 from . import runDN, runSR
 from .config import config
-from .imageProcess import RGBFilter, apply, readFile, toFloat, toOutput, toTorch, writeFile
+from .imageProcess import RGBFilter, apply, readFile, toBuffer, toFloat, toNumPy, toOutput, toTorch, writeFile
 
 stepOpts = dict(SR={'toInt': ['scale', 'ensemble'], 'getOpt': runSR}, DN={'toFloat': ['strength'], 'getOpt': runDN})
 
@@ -35,12 +36,16 @@ def genProcess(steps, bitDepth=8, outFile=None):
     ctx = Context()
     funcs, nodes = [], []
     has_file = bool(steps) and steps[0]['op'] == 'file'
+    has_buffer = bool(steps) and steps[0]['op'] == 'buffer'
     if has_file:
         funcs.append(readFile(context=ctx))
+    if has_buffer:     # video frames: raw bgr24 / bgr48le in, the same out (channel order is irrelevant: planes are independent)
+        bitDepth = int(steps[0].get('bitDepth', 16))
+        funcs.append(toNumPy(bitDepth))
     funcs.append(toTorch(bitDepth, config.dtype(), config.device()))
     for opt in steps:
         op = opt['op']
-        if op in ('file', 'output'):
+        if op in ('file', 'buffer', 'output'):
             continue
         if op not in stepOpts:
             raise NotImplementedError('op "{}" is not part of the SR/DN hot path this engine implements'.format(op))
@@ -61,4 +66,29 @@ def genProcess(steps, bitDepth=8, outFile=None):
     funcs += [toFloat, toOutput(bitDepth)]
     if has_file and outFile is not None:
         funcs.append(lambda im: writeFile(im, outFile, ctx))
+    if has_buffer:
+        funcs.append(toBuffer(bitDepth))
+        run = lambda im: reduce(apply, funcs, im)
+        return (lambda frame: [] if not frame[0] else [run(frame)]), nodes     # a list of buffers per frame (procedure.py:122-125)
     return (lambda im: reduce(apply, funcs, im)), nodes
+
+
+def runFrames(process, read, write, width, height, bitDepth=16, start=0, stop=-1):
+    """The per-frame loop of SR_vid (python/video.py:349-360) without the ffmpeg plumbing: `read(nbytes)` yields raw frames of
+    width*height*3 samples, every frame from `start` on goes through `process` (a genProcess 'buffer' pipeline) and each
+    returned buffer is handed to `write`.  Returns the number of frames written."""
+    frameBytes = width * height * 3 * (1 if bitDepth <= 8 else 2)
+    i = n = 0
+    while stop < 0 or i <= stop:
+        raw = read(frameBytes)
+        if len(raw) == 0:
+            break
+        if len(raw) != frameBytes:
+            raise ValueError('short frame: {} of {} bytes'.format(len(raw), frameBytes))
+        if i >= start:
+            for buf in process((raw, height, width)):
+                if buf:
+                    write(buf)
+                    n += 1
+        i += 1
+    return n

@@ -317,6 +317,30 @@ def test_step_chain_dn_then_sr_config3(dev, tmp_path):
         procedure.genProcess([{'op': 'slomo', 'sf': 2}])
 
 
+def test_video_frame_buffer_chain_16bit(dev):
+    """The video path's contract (python/video.py:23,349-360; procedure.py:141-142): a raw bgr48le frame goes through
+    toNumPy -> toTorch(16) -> SR -> toFloat -> toOutput(16) -> toBuffer and comes back as raw 16-bit samples."""
+    from moephoto_amd import imageProcess as ip, procedure
+    from moephoto_amd.config import config
+    config.modelRoot, config.crop_sr, config.fp16, config.deviceId = gd.ZOO, 64, False, 0
+    ip.modelCache.clear()
+    h, w = 72, 88
+    img16 = (gd.natural_image(21, (3, h, w)).transpose(1, 2, 0) * 65535.0).astype(np.uint16)
+    process, nodes = procedure.genProcess([{'op': 'buffer', 'bitDepth': 16}, {'op': 'SR', 'model': 'a', 'scale': 2, 'ensemble': 0}], bitDepth=16)
+    assert [n['op'] for n in nodes] == ['SR']
+    out = []
+    assert procedure.runFrames(process, __import__('io').BytesIO(img16.tobytes() * 2).read, out.append, w, h, bitDepth=16) == 2
+    assert out[0] == out[1] and len(out[0]) == 2 * h * 2 * w * 3 * 2
+    got = np.frombuffer(out[0], np.uint16).reshape(2 * h, 2 * w, 3)
+    x = oio.to_float_image(img16, 16)
+    pl = oplanner.prepare((3, h, w), 1 << 40, 1e-3, 5, 2, 8, 64)
+    y = ostitch.do_crop(x, pl, 2, onets.model_fn('net2x', gd.state_dict_for('a2', load_state_dict_file)))
+    want = oio.to_output(oio.to_hwc(y), 16).astype(np.int64)
+    diff = np.abs(got.astype(np.int64) - want)
+    assert diff.max() <= TOL_FP16_SR * 65536 + 1, diff.max()       # 1.5e-3 in 16-bit levels
+    assert process((b'', h, w)) == []
+
+
 def test_dropin_protocol_reference_loop(dev):
     """The reference's own doCrop loop (imageProcess.py:157-172) restated here with torch ops, calling the
     engine-backed module exactly like Option.__call__ does: per tile, on a slice view, list result."""

@@ -174,3 +174,30 @@ def test_build_entry_and_oracle_build():
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and 'built' in out.stdout, out.stderr[-2000:]
     assert os.path.exists(_lib.LIB_PATH) and os.path.exists(os.path.join(ROOT, 'oracle', '_build', 'libconvref.so'))
+
+
+def test_video_buffer_edges_and_frame_loop():
+    """toNumPy / toBuffer (python/imageProcess.py:216-236) and the per-frame loop of SR_vid (python/video.py:349-360):
+    raw bgr48le frames in, raw frames out, `start` frames skipped, short reads rejected."""
+    import io
+    from moephoto_amd import imageProcess as ip, procedure
+    h, w = 4, 6
+    rng = np.random.default_rng(7)
+    frames = [rng.integers(0, 65536, (h, w, 3), dtype=np.uint16) for _ in range(3)]
+    raw = b''.join(f.tobytes() for f in frames)
+    a = ip.toNumPy(16)((frames[1].tobytes(), h, w))
+    assert a.dtype == np.uint16 and a.shape == (h, w, 3) and np.array_equal(a, frames[1])
+    assert ip.toNumPy(16)((b'', h, w)) is None
+    assert ip.toNumPy(8)((bytes(range(72)), h, w)).dtype == np.uint8
+    assert ip.toBuffer(16)(frames[2]) == frames[2].tobytes() and ip.toBuffer(8)(None) is None
+    seen, out = [], []
+
+    def process(frame):          # stand-in for a genProcess 'buffer' pipeline: doubles every sample
+        seen.append(frame[1:])
+        return [ip.toBuffer(16)(ip.toNumPy(16)(frame) // 2)]
+    n = procedure.runFrames(process, io.BytesIO(raw).read, out.append, w, h, bitDepth=16, start=1)
+    assert n == 2 and seen == [(h, w), (h, w)]
+    assert np.array_equal(np.frombuffer(out[1], np.uint16).reshape(h, w, 3), frames[2] // 2)
+    assert procedure.runFrames(process, io.BytesIO(raw).read, out.append, w, h, bitDepth=16, stop=0) == 1
+    with pytest.raises(ValueError):
+        procedure.runFrames(process, io.BytesIO(raw[:-5]).read, out.append, w, h, bitDepth=16)
