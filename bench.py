@@ -142,7 +142,7 @@ def main():
     }
     if prof['launches'] > 0:
         ach = prof['flops'] / (prof['total_ms'] / 1e3) / 1e12
-        res['roofline'] = {'bound': 'mfma', 'kernel': 'conv_mfma_kernel<9,1> (3x3 64->256 @2x res, +bias +PixelShuffle(2) +PReLU epilogue)',
+        res['roofline'] = {'bound': 'mfma', 'kernel': 'conv3x3_sp_kernel<3> (3x3 64->256 @2x res, +bias +PixelShuffle(2) +PReLU, fused 64->1 tail taps)',
                            'achieved': round(ach, 1), 'peak': PEAK_FP16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP16_TFLOPS, 4),
                            'launches': prof['launches'], 'avg_launch_ms': round(prof['total_ms'] / prof['launches'], 4),
                            'gflop_per_launch': round(prof['flops'] / prof['launches'] / 1e9, 2), 'traffic': _pmc_traffic()}
