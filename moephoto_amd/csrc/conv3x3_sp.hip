@@ -87,7 +87,6 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
     if (K <= 0) return;
 
     const half_t* const zsrc = a.zero + (lane & 7) * 8;
-    const half_t* const bias_src = (const half_t*)(a.bias_img + chunk * 256) + lane * 8;   // 1-KiB image: 64 fp32 biases, then zeros
     // launch-invariant per-lane source offsets of this wave's 11 DMA pieces (elements, relative to the patch origin)
     int poff[NDMA_W];
 #pragma unroll
@@ -125,10 +124,6 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         const bool ok = ((unsigned)(ps.y0 + r) < (unsigned)a.H) & ((unsigned)(ps.x0 + c) < (unsigned)a.W) & (q < NPIX) & live;
         const half_t* src = ps.base + poff[i];
         src = ok ? src : zsrc;
-        // piece 43 is pure padding (q >= 340 for every lane): it carries this chunk's bias image instead, so the bias sits in
-        // LDS behind each patch buffer and the accumulator reset needs no global load (vmcnt is in-order: a load issued
-        // behind in-flight DMA pieces would stall the wave for a full DMA latency)
-        if (i == NDMA_W - 1) src = (w4 == 3) ? bias_src : src;
         dma16(src, dstbuf + n * 1024);
     };
 
@@ -172,25 +167,28 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
     const int cout0 = (r > 1) ? 0 : chunk * kCB;                   // first output channel of this chunk in `out`
     const int Wo = a.W * r, Ho = a.H * r;
 
-    // accumulators start from the bias (an all-zero image when the layer has none): lane (j, hh) register e of tile [o][nb]
-    // is channel nb*32 + 8*(e>>2) + 4*hh + (e&3)
-    const char* const bias_lds = pbuf + (NDMA_W * 4 - 1) * 1024 + hh * 16;     // padding piece of patch buffer 0
-    auto reset_acc = [&](float16_t (&ac)[2][2]) {
+    // The bias (an all-zero image when the layer has none) is the C operand of the FIRST MFMA of every accumulator in an
+    // iteration, so accumulators are never reset: lane (j, hh) register e of tile [o][nb] is channel nb*32 + 8*(e>>2) + 4*hh + (e&3)
+    float16_t biasv[2];
+    {
+        const float* bsrc = a.bias_img + chunk * 256 + hh * 4;
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                const float4_t b4 = *(const float4_t*)(bias_lds + (nb * 32 + g4 * 8) * 4);
+                const float4_t b4 = *(const float4_t*)(bsrc + nb * 32 + g4 * 8);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { ac[0][nb][g4 * 4 + e] = b4[e]; ac[1][nb][g4 * 4 + e] = b4[e]; }
+                for (int e = 0; e < 4; ++e) biasv[nb][g4 * 4 + e] = b4[e];
             }
-    };
+    }
     // predicated-off lanes read/write the 1-KiB slack every activation buffer carries behind its last element
     const unsigned trash_off = (unsigned)a.B * Ho * Wo * a.out_cs + lane * 8;
 
     float16_t accA[2][2], accB[2][2];
-    reset_acc(accA);
-    reset_acc(accB);
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) { accA[o][nb] = biasv[nb]; accB[o][nb] = biasv[nb]; }   // (iteration 0 drains B with its stores off)
 
     // One eighth (index s8 = (o, nb, gp)) of the epilogue of a finished tile held in `ac`.  Branch-free: lanes outside the
     // image (or a disabled slice) store to a trash line and read their residual from the zero page.
@@ -390,8 +388,8 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
                     const int o = pr - dy;
                     if (o >= 0 && o < 2) {
 #pragma unroll
-                        for (int nb = 0; nb < 2; ++nb)
-                            cur[o][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cb][dy][nb], af[cb][pr], cur[o][nb], 0, 0, 0);
+                        for (int nb = 0; nb < 2; ++nb)     // (s, dy) == (0, 0) is the first product of accumulator [o][nb]
+                            cur[o][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cb][dy][nb], af[cb][pr], (s == 0 && dy == 0) ? biasv[nb] : cur[o][nb], 0, 0, 0);
                     }
                 }
             if (!(MOE_ABL & 2) && s < 8) drain_slice(prev, itp, s, drain, resw);
@@ -437,7 +435,6 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) asm volatile("" ::"a"(prev[o][nb]));
         }
-        reset_acc(prev);
         MOE_STAMP(1)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         MOE_STAMP(2)
