@@ -93,7 +93,7 @@ def main():
     # ---- input frames, resident in HBM ------------------------------------------------------------------
     nframes = world
     frames_np = [gd.natural_image(1000 + f, FRAME) for f in range(nframes)]
-    frames = [torch.from_numpy(a).to(dev).half() for a in frames_np]
+    frames = list(torch.stack([torch.from_numpy(a) for a in frames_np]).to(dev).half().unbind(0))   # slices of one tensor
     plan = ip._plan_for(opt, frames[0].shape)
     assert plan.n_tiles == 40, plan.n_tiles
 

@@ -140,6 +140,15 @@ int moe_run_plan(moe_net* net, const moe_plan* plan, const void* img, int img_dt
 int moe_run_plan_ex(moe_net* net, const moe_plan* plan, const void* img, int img_dtype, int64_t sC, int64_t sH, int64_t sW,
                     void* out, int out_dtype, int max_tiles_per_batch, float* pool, int shard_index, int shard_count,
                     int do_stitch, void* stream);
+
+/* Multi-frame, owner-sharded form of the tile loop (the multi-GPU step of moephoto_amd/dist.py; the reference runs frames one
+ * after the other through doCrop, python/video.py:349-360 -> python/imageProcess.py:157-172).  `imgs` holds n_frames equally
+ * shaped padded images, frame f at imgs + f*frame_stride elements; frame f's raw tile results go to pools + f*pool_stride
+ * (fp32 elements, >= moe_plan_pool_elems each).  Only pairs with (f * n_tiles + k) % owner_count == owner_index are
+ * computed; same-shaped tiles of different frames share launches.  No stitch: exchange, then moe_stitch per frame. */
+int moe_run_plan_frames(moe_net* net, const moe_plan* plan, const void* imgs, int img_dtype, int64_t frame_stride,
+                        int64_t sC, int64_t sH, int64_t sW, int n_frames, float* pools, int64_t pool_stride,
+                        int owner_index, int owner_count, int max_tiles_per_batch, void* stream);
 /* elements of the fp32 tile pool for C planes, and the element offset of every tile inside it (default layout:
  * tile k = C contiguous planes of its HR extent, tiles in raster order) */
 int64_t moe_plan_pool_elems(const moe_plan* plan, int C);

@@ -61,6 +61,7 @@ def lib():
         'moe_stitch': (c_int, [c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_vp]),
         'moe_run_plan': (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_vp, c_int, c_int, c_vp]),
         'moe_run_plan_ex': (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp]),
+        'moe_run_plan_frames': (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_i64, c_int, c_vp, c_i64, c_int, c_int, c_int, c_vp]),
         'moe_to_float': (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp]),
         'moe_to_output': (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp]),
     }
@@ -77,7 +78,7 @@ EXPORTS = ['moe_last_error', 'moe_abi_version', 'moe_device_count', 'moe_net_cre
            'moe_net_num_params', 'moe_net_param_info', 'moe_net_set_param', 'moe_net_finalize', 'moe_net_workspace_bytes',
            'moe_net_forward', 'moe_net_set_profile', 'moe_net_get_profile', 'moe_net_set_debug', 'moe_net_debug_tap', 'moe_plan_create', 'moe_plan_destroy', 'moe_plan_info',
            'moe_plan_tiles', 'moe_plan_ramp', 'moe_plan_pool_elems', 'moe_plan_tile_offsets', 'moe_stitch', 'moe_run_plan',
-           'moe_run_plan_ex', 'moe_to_float', 'moe_to_output']
+           'moe_run_plan_ex', 'moe_run_plan_frames', 'moe_to_float', 'moe_to_output']
 
 
 def check(rc):

@@ -1035,6 +1035,7 @@ void moe_plan_destroy(moe_plan* p)
 {
     if (!p) return;
     for (auto& d : p->p.dev) if (d->blob) (void)hipFree(d->blob);
+    for (auto& d : p->p.fdev) if (d->blob) (void)hipFree(d->blob);
     if (p->p.pool) (void)hipFree(p->p.pool);
     delete p;
 }
@@ -1150,6 +1151,83 @@ int moe_run_plan_ex(moe_net* n, const moe_plan* pl, const void* img, int img_dty
         launch_stitch(a, s);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(MOE_EHIP, "stitch launch failed: %s", hipGetErrorString(e));
+    }
+    return MOE_OK;
+}
+
+int moe_run_plan_frames(moe_net* n, const moe_plan* pl, const void* imgs, int img_dtype, int64_t frame_stride,
+                        int64_t sC, int64_t sH, int64_t sW, int n_frames, float* pools, int64_t pool_stride,
+                        int owner_index, int owner_count, int max_tiles, void* stream)
+{
+    if (!n || !pl || !imgs || !pools || n_frames < 1) return fail(MOE_EINVAL, "moe_run_plan_frames: bad argument");
+    if (!n->finalized) return fail(MOE_ESTATE, "moe_run_plan_frames: net is not finalized");
+    const Plan& p = pl->p;
+    if (p.sc != n->scale) return fail(MOE_EINVAL, "moe_run_plan_frames: plan scale %d != net scale %d", p.sc, n->scale);
+    if (owner_count < 1) { owner_count = 1; owner_index = 0; }
+    if (owner_index < 0 || owner_index >= owner_count) return fail(MOE_EINVAL, "moe_run_plan_frames: owner %d of %d", owner_index, owner_count);
+    if (pool_stride < (int64_t)p.pool_elems_per_plane_set) return fail(MOE_EINVAL, "moe_run_plan_frames: pool stride smaller than one frame's pool");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(n->device));
+    const int C = p.C;
+    FramesDeviceCache* d = nullptr;
+    for (auto& up : p.fdev) {
+        FramesDeviceCache& c = *up;
+        if (c.blob && c.device == n->device && c.C == C && c.sC == sC && c.sH == sH && c.sW == sW && c.frame_stride == frame_stride &&
+            c.pool_stride == pool_stride && c.n_frames == n_frames && c.owner_index == owner_index && c.owner_count == owner_count) { d = &c; break; }
+    }
+    if (!d) {
+        if (p.fdev.size() >= 8) {
+            HIP_TRY(hipStreamSynchronize(s));
+            if (p.fdev.front()->blob) (void)hipFree(p.fdev.front()->blob);
+            p.fdev.erase(p.fdev.begin());
+        }
+        p.fdev.push_back(std::make_unique<FramesDeviceCache>());
+        d = p.fdev.back().get();
+        const long long nt = (long long)p.tiles.size();
+        std::vector<long long> xo, yo;
+        int slot = 0;
+        for (const auto& g : p.groups) {      // same-shaped tiles of ALL frames share launches
+            d->group_first.push_back(slot);
+            int cnt = 0;
+            const long long plane = (long long)(g.th * p.sc) * (g.tw * p.sc);
+            for (int f = 0; f < n_frames; ++f)
+                for (int k : g.tiles) {
+                    if ((f * nt + k) % owner_count != owner_index) continue;
+                    const TileRect& t = p.tiles[k];
+                    for (int c = 0; c < C; ++c) {
+                        xo.push_back((long long)f * frame_stride + (long long)c * sC + (long long)t.top * sH + (long long)t.left * sW);
+                        yo.push_back((long long)f * pool_stride + p.tile_off[k] + (long long)c * plane);
+                    }
+                    ++slot; ++cnt;
+                }
+            d->group_count.push_back(cnt);
+        }
+        if (xo.empty()) { xo.push_back(0); yo.push_back(0); }
+        d->y_mult8 = true;
+        for (long long v : yo) d->y_mult8 = d->y_mult8 && (v % 8 == 0);
+        HIP_TRY(hipMalloc(&d->blob, xo.size() * 16));
+        d->x_off = (long long*)d->blob; d->y_off = d->x_off + xo.size();
+        HIP_TRY(hipMemcpy(d->x_off, xo.data(), xo.size() * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d->y_off, yo.data(), yo.size() * 8, hipMemcpyHostToDevice));
+        d->device = n->device; d->C = C; d->sC = sC; d->sH = sH; d->sW = sW; d->frame_stride = frame_stride; d->pool_stride = pool_stride;
+        d->n_frames = n_frames; d->owner_index = owner_index; d->owner_count = owner_count;
+    }
+    if (max_tiles <= 0) {
+        max_tiles = 4;
+        if (const char* e = getenv("MOE_TILES_PER_BATCH")) { const int v = atoi(e); if (v > 0) max_tiles = v; }
+    }
+    for (size_t gi = 0; gi < p.groups.size(); ++gi) {
+        const auto& g = p.groups[gi];
+        const int nt = d->group_count[gi];
+        if (nt < 1) continue;
+        const long long px = (long long)g.th * g.tw;
+        const int per = (int)std::max<long long>(1, std::min<long long>(nt, (long long)max_tiles * 65536 / std::max<long long>(px, 1)));
+        for (int t0 = 0; t0 < nt; t0 += per) {
+            const int cnt = std::min(per, nt - t0);
+            const long long slot = (long long)(d->group_first[gi] + t0) * C;
+            int rc = forward_dev(*n, imgs, img_dtype, cnt * C, g.th, g.tw, 0, sH, sW, d->x_off + slot, pools, MOE_F32, d->y_off + slot, s, d->y_mult8);
+            if (rc) return rc;
+        }
     }
     return MOE_OK;
 }

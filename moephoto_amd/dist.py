@@ -121,16 +121,23 @@ def run_frames(opt, frames, group=None, out_dtype=None, max_tiles_per_batch=0):
     L = _lib.lib()
     dev = x0.device
     stream = torch.cuda.current_stream(dev).cuda_stream
-    pools, padded = {}, []
-    for f, x in enumerate(frames):
-        xp = plan.padImage(x)
-        padded.append(xp)
-        pool = torch.empty(ex.pool_elems, dtype=torch.float32, device=dev)
-        pools[f] = pool
-        si, sc = ex.shard_of(f)
-        sC, sH, sW = xp.stride()
-        _lib.check(L.moe_run_plan_ex(model._h, plan._h, xp.data_ptr(), _DT[xp.dtype], sC, sH, sW, None, _lib.F32,
-                                     int(max_tiles_per_batch), ctypes.c_void_p(pool.data_ptr()), si, sc, 0, stream))
+    padded = [plan.padImage(x) for x in frames]
+    # one launch set for ALL frames: same-shaped tiles of different frames share batches (a rank owns only n_tiles/world tiles
+    # of each frame -- run frame by frame they would go out as many small, inefficient launches)
+    esz = padded[0].element_size()
+    gap = [(p.data_ptr() - padded[0].data_ptr()) // esz for p in padded]
+    fstride = gap[1] if len(padded) > 1 else 0
+    same = all(p.stride() == padded[0].stride() and p.dtype == padded[0].dtype for p in padded)
+    if not (same and all(g == f * fstride for f, g in enumerate(gap)) and (len(padded) == 1 or fstride > 0)):
+        stacked = torch.stack(padded)            # frames are not slices of one tensor: gather them once
+        padded = list(stacked.unbind(0))
+        fstride = stacked.stride(0)
+    all_pools = torch.empty((len(frames), ex.pool_elems), dtype=torch.float32, device=dev)
+    pools = {f: all_pools[f] for f in range(len(frames))}
+    sC, sH, sW = padded[0].stride()
+    _lib.check(L.moe_run_plan_frames(model._h, plan._h, padded[0].data_ptr(), _DT[padded[0].dtype], int(fstride), sC, sH, sW,
+                                     len(frames), ctypes.c_void_p(all_pools.data_ptr()), int(ex.pool_elems), rank, world,
+                                     int(max_tiles_per_batch), stream))
     mine = ex.exchange(pools)
     out = {}
     odt = out_dtype if out_dtype is not None else x0.dtype

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Two ranks sharing ONE GPU (MOE_DIST_BACKEND=gloo MOE_FORCE_DEVICE=0): the tile-parallel path of dist.run_frames
-(sharded moe_run_plan_ex -> all-to-all of tile results -> moe_stitch) must reproduce the single-process doCrop bit for bit."""
+(owner-sharded moe_run_plan_frames -> all-to-all of tile results -> moe_stitch) must reproduce the single-process doCrop bit for bit."""
 import os
 import sys
 
@@ -30,5 +30,11 @@ assert sorted(out) == [f for f in range(3) if f % world == rank], sorted(out)
 for f, y in out.items():
     want = ip.doCrop(opt, frames[f])
     assert torch.equal(y, want), (f, float((y.float() - want.float()).abs().max()))
+# frames that are slices of one tensor take the no-copy path of run_frames
+allf = torch.stack(frames)
+out2 = run_frames(opt, list(allf.unbind(0)), out_dtype=torch.float16)
+torch.cuda.synchronize()
+for f, y in out2.items():
+    assert torch.equal(y, out[f]), f
 dist.barrier()
 print('RANK', rank, 'OK frames', sorted(out))
