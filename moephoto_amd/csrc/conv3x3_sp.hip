@@ -236,8 +236,8 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
             for (int e = 0; e < 8; ++e) bf[e] = (half_t)v[e];            // k = 8*hh + e  <->  channel nb*32 + 16*gp + perm(hh, e)
             Gacc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tailw[nb * 2 + gp], bf, Gacc[o], 0, 0, 0);
             if ((s8 & 3) == 3) {     // row o complete: lane (j, hh) holds taps 4*hh .. 4*hh+3 in regs 0..3 and tap 8 + 4*hh in reg 4
-                // Store instructions are what this epilogue pays for (~110 cycles each beside the MFMAs, whatever their width),
-                // VALU work is free: so a 4x4 transpose inside each lane quad (two DPP exchange stages) turns the four
+                // 4-byte-per-lane stores are what this epilogue paid for (~110 cycles each beside the MFMAs; 16-byte ones are nearly
+                // free) while VALU work hides: so a 4x4 transpose inside each lane quad (two DPP exchange stages) turns the four
                 // one-float-per-lane tap registers into ONE 16-byte store: lane (4m+i, hh) ends up with tap 4hh+i of pixels 4m..4m+3.
                 auto xq = [](float v, bool far) {   // value of the quad partner: lane^1 (quad_perm [1,0,3,2]) or lane^2 ([2,3,0,1])
                     const int u = __builtin_bit_cast(int, v);
