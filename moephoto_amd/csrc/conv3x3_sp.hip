@@ -63,8 +63,13 @@ struct PatchSrc { const half_t* base; int y0, x0; };
 // The bias (upsampler convs) costs nothing here: the accumulators are initialised with it instead of zero.
 // timing trace (MOE_DBG & 64): acc32 doubles as a [wg<8][iter<32][wave<4][slot<16] table of s_memtime stamps
 // (slots 0..3: iteration start / body end / after vmcnt wait / after barrier; built with -DMOE_STEP_STAMPS also 4+s: end of k-step s)
+#ifdef MOE_STAMP_MIN          /* only the iteration-start stamp: the period without the cost of the other stamps */
+#define MOE_STAMP_ON(SLOT) ((SLOT) == 0)
+#else
+#define MOE_STAMP_ON(SLOT) true
+#endif
 #define MOE_STAMP(SLOT)                                                                                 \
-    if ((a.dbg & 64) && a.acc32 && bid < 8 && p < 32 && lane == 0)                                        \
+    if (MOE_STAMP_ON(SLOT) && (a.dbg & 64) && a.acc32 && bid < 8 && p < 32 && lane == 0)                   \
         ((unsigned long long*)a.acc32)[((bid * 32 + p) * 4 + w4) * 16 + (SLOT)] = __builtin_amdgcn_s_memtime();
 
 template <int EPI>
@@ -193,6 +198,13 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
     // One eighth (index s8 = (o, nb, gp)) of the epilogue of a finished tile held in `ac`.  Branch-free: lanes outside the
     // image (or a disabled slice) store to a trash line and read their residual from the zero page.
     constexpr bool ACT = (EPI == 1) || (EPI == 3), RES = (EPI == 2), TAIL = (EPI == 3);
+#ifndef MOE_DRAIN0_TAIL
+#define MOE_DRAIN0_TAIL 0
+#endif
+#ifndef MOE_DRAIN0
+#define MOE_DRAIN0 0
+#endif
+    constexpr int DRAIN0 = TAIL ? MOE_DRAIN0_TAIL : MOE_DRAIN0;   // first of the eight k-steps that carry a slice of the previous tile's epilogue
     // fused tail: A fragments of the 64->1 conv for the four 16-channel k-slices, rows = taps (9 of 32 used)
     half8_t tailw[4];
 #pragma unroll
@@ -356,6 +368,9 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
             for (int s8 = 0; s8 < 8; ++s8) asm volatile("" : "+v"(resw[s8].x), "+v"(resw[s8].y), "+v"(resw[s8].z), "+v"(resw[s8].w));
         }
         half8_t wf[2][3][2], af[2][4];
+// the ten reads of a k-step in the order its MFMAs consume them (input row pr, then the weights of the tap row it meets first):
+// LDS returns in order, so the first MFMAs of the step wait for two reads instead of seven
+#ifdef MOE_LOAD_ORDER_WA      /* weights first, then the four input rows */
 #define MOE_LOAD_STEP(S, BUF)                                                                              \
     {                                                                                                      \
         constexpr int dx_ = (S) / 4, ks_ = (S) % 4;                                                        \
@@ -366,7 +381,26 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         _Pragma("unroll") for (int pr = 0; pr < 4; ++pr)                                                   \
             af[BUF][pr] = *(const half8_t*)(ap_ + pr * (PW * 128));                                        \
     }
+#else
+#define MOE_LOAD_STEP(S, BUF)                                                                              \
+    {                                                                                                      \
+        constexpr int dx_ = (S) / 4, ks_ = (S) % 4;                                                        \
+        const char* ap_ = abuf + Ad[dx_] + ((ks_ << 5) ^ Zd[dx_]);                                         \
+        _Pragma("unroll") for (int pr = 0; pr < 4; ++pr) {                                                 \
+            af[BUF][pr] = *(const half8_t*)(ap_ + pr * (PW * 128));                                        \
+            if (pr < 3) {                                                                                  \
+                _Pragma("unroll") for (int nb = 0; nb < 2; ++nb)                                           \
+                    wf[BUF][pr][nb] = *(const half8_t*)(wl + ((((pr * 3 + dx_) * 4 + ks_) * 2 + nb) << 10)); \
+            }                                                                                              \
+        }                                                                                                  \
+    }
+#endif
         MOE_LOAD_STEP(0, 0)
+#if !defined(MOE_NO_SGB) && !defined(MOE_NO_FIRST10)
+        // the first ten reads get a group of their own in front of the first MFMA slot: left to itself the solver may hand them the
+        // read slots of k-step 0, and then every step's reads slide into the step that consumes them (no prefetch distance at all)
+        __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+#endif
 #pragma unroll
         for (int s = 0; s < 12; ++s) {
             const int cb = s & 1;
@@ -392,8 +426,8 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
                             cur[o][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cb][dy][nb], af[cb][pr], (s == 0 && dy == 0) ? biasv[nb] : cur[o][nb], 0, 0, 0);
                     }
                 }
-            if (!(MOE_ABL & 2) && s < 8) drain_slice(prev, itp, s, drain, resw);
-            if (RES && s >= 1 && s <= 8) fetch_res(it_cur, s - 1);   // slice s-1's registers were consumed in the previous step
+            if (!(MOE_ABL & 2) && s >= DRAIN0 && s < DRAIN0 + 8) drain_slice(prev, itp, s - DRAIN0, drain, resw);
+            if (RES && s >= DRAIN0 + 1 && s <= DRAIN0 + 8) fetch_res(it_cur, s - DRAIN0 - 1);   // slice s-1's registers were consumed in the previous step
 #ifdef MOE_STEP_STAMPS
             MOE_STAMP(4 + s)
 #endif
@@ -423,9 +457,24 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
                 if (i < SGB_DSR_SLOTS) __builtin_amdgcn_sched_group_barrier(0x002, SGB_VALU_A, 0);
                 else __builtin_amdgcn_sched_group_barrier(0x002, SGB_VALU_B, 0);
                 if ((i == SGB_DMA_AT || i == SGB_DMA_AT + 1) && s <= 5) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                if (RES && i == SGB_DMA_AT + 2 && s >= 1 && s <= 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                if (i == SGB_ST_AT && s < 8) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+                if (RES && i == SGB_DMA_AT + 2 && s >= DRAIN0 + 1 && s <= DRAIN0 + 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if (i == SGB_ST_AT && s >= DRAIN0 && s < DRAIN0 + 8) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
             }
+            // the fused tail adds a 13th MFMA to k-steps 0..7: without a slot of its own it takes the next step's first MFMA slot
+            // and every later group slides by one, until the LDS reads land right in front of their consumers
+            if (TAIL && s >= DRAIN0 && s < DRAIN0 + 8) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, SGB_VALU_B, 0);
+            }
+            // Fused-tail variant: nothing moves across a k-step boundary.  Its 13th MFMA per step makes the solver's slot pattern drift
+            // until LDS reads sit right in front of their consumers (38-46 of 120 reads with < 6 MFMAs of distance; 14 with the
+            // fence; 7650 -> 6850 cycles per tile, -4 % wall).  The other variants schedule as well or better as one region
+            // (tools/seq_view.py shows the compiled pattern; the residual variant gains only when HBM-bound at B = 48).
+#if defined(MOE_STEP_FENCE_ALL)
+            __builtin_amdgcn_sched_barrier(0);
+#elif !defined(MOE_STEP_FENCE_NONE)
+            if (TAIL) __builtin_amdgcn_sched_barrier(0);
+#endif
 #endif
         }
 #undef MOE_LOAD_STEP

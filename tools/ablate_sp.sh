@@ -18,7 +18,7 @@ else
     cp $f moephoto_amd/libmoephoto_amd.so
     echo "== $(basename $f)"
     if [ "$1" = trace ]; then   # cycle counts (s_memtime) are immune to the DVFS effect of the ablated data
-      for k in ${TRACE_KEYS:-convt_R1.up1}; do echo "  key $k"; MOE_TRACE_KEY=$k MOE_DBG=64 PROF_ITER=1 python tools/prof_workload.py > /dev/null 2>&1; python tools/show_trace_sp.py | head -1; done
+      for k in ${TRACE_KEYS:-convt_R1.up1}; do echo "  key $k"; MOE_TRACE_KEY=$k MOE_DBG=64 PROF_ITER=1 PROF_B=${TRACE_B:-12} python tools/prof_workload.py > /dev/null 2>&1; python tools/show_trace_sp.py | head -1; done
     else
       python tools/gpu_diag.py layers 2>&1 | grep -E "B=12 layers \*(c1_|up0|up1)"
     fi

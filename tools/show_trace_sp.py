@@ -1,12 +1,23 @@
+#!/usr/bin/env python
+"""Read /tmp/moe_trace.bin (MOE_DBG=64: s_memtime stamps [wg<8][iteration<32][wave<4][slot<16] of one conv3x3_sp launch) and
+print per-iteration medians: body / vmcnt wait / barrier / period, per-k-step cycles (build with -DMOE_STEP_STAMPS) and the
+prologue.  With -DMOE_STAMP_MIN only the period is meaningful (no stamp overhead inside the iteration)."""
 import numpy as np
-t = np.fromfile('/tmp/moe_trace.bin', dtype=np.uint64)[:8*32*4*16].reshape(8, 32, 4, 16).astype(np.int64)
+
+t = np.fromfile('/tmp/moe_trace.bin', dtype=np.uint64)[:8 * 32 * 4 * 16].reshape(8, 32, 4, 16).astype(np.int64)
 for wg in (0, 3, 5):
     for w in (0, 3):
-        a = t[wg, 2:30, w]
-        d = a - a[:, :1]
+        n = int((t[wg, :, w, 0] != 0).sum())          # iterations this workgroup actually ran (<= 32 recorded)
+        a = t[wg, min(2, max(0, n - 3)):max(n - 1, 1), w]
+        if len(a) < 2:
+            continue
         per = np.diff(a[:, 0])
-        print('wg', wg, 'wave', w, 'body={} vmwait={} barrier={}  period={}'.format(int(np.median(d[:, 1])), int(np.median(d[:, 2] - d[:, 1])), int(np.median(d[:, 3] - d[:, 2])), int(np.median(per))))
-        if a[:, 4:].any():
+        line = 'wg {} wave {} iters {:2d} period={}'.format(wg, w, n, int(np.median(per)))
+        if a[:, 1:4].any():
+            d = a - a[:, :1]
+            line += '  body={} vmwait={} barrier={}'.format(int(np.median(d[:, 1])), int(np.median(d[:, 2] - d[:, 1])), int(np.median(d[:, 3] - d[:, 2])))
+        print(line)
+        if a[:, 4:14].any():
             st = np.concatenate([a[:, :1], a[:, 4:16]], axis=1)
             print('      per-step cycles (steps 0..11):', ' '.join(str(int(v)) for v in np.median(np.diff(st, axis=1), axis=0)))
 pro = t[:, 0, :, 15] - t[:, 0, :, 14]
