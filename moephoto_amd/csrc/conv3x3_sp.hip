@@ -355,6 +355,7 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
     // iteration p (0 <= p < K): multiply patch p (buffer p&1) into `cur`; drain patch p-1 from `prev` (stores predicated
     // off for p == 0); fetch patch p+1 (source predicated to the zero page for the last one).  No branches inside: the
     // whole iteration is one scheduling region so the VALU/VMEM work lands in the shadow of the MFMAs.
+    half8_t wf[2][3][2], af[2][4];     // double-buffered MFMA operand fragments (k-step parity)
     auto iteration = [&](int p, float16_t (&cur)[2][2], float16_t (&prev)[2][2]) {
         const bool drain = (p >= 1) && !(a.dbg & 4);
         const bool fetch = (p + 1 < K) && !(a.dbg & 1);
@@ -367,25 +368,24 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
 #pragma unroll
             for (int s8 = 0; s8 < 8; ++s8) asm volatile("" : "+v"(resw[s8].x), "+v"(resw[s8].y), "+v"(resw[s8].z), "+v"(resw[s8].w));
         }
-        half8_t wf[2][3][2], af[2][4];
 // the ten reads of a k-step in the order its MFMAs consume them (input row pr, then the weights of the tap row it meets first):
 // LDS returns in order, so the first MFMAs of the step wait for two reads instead of seven
 #ifdef MOE_LOAD_ORDER_WA      /* weights first, then the four input rows */
-#define MOE_LOAD_STEP(S, BUF)                                                                              \
+#define MOE_LOAD_STEP(S, BUF, PB)                                                                            \
     {                                                                                                      \
         constexpr int dx_ = (S) / 4, ks_ = (S) % 4;                                                        \
         _Pragma("unroll") for (int dy = 0; dy < 3; ++dy)                                                   \
             _Pragma("unroll") for (int nb = 0; nb < 2; ++nb)                                               \
                 wf[BUF][dy][nb] = *(const half8_t*)(wl + ((((dy * 3 + dx_) * 4 + ks_) * 2 + nb) << 10));   \
-        const char* ap_ = abuf + Ad[dx_] + ((ks_ << 5) ^ Zd[dx_]);                                         \
+        const char* ap_ = (PB) + Ad[dx_] + ((ks_ << 5) ^ Zd[dx_]);                                         \
         _Pragma("unroll") for (int pr = 0; pr < 4; ++pr)                                                   \
             af[BUF][pr] = *(const half8_t*)(ap_ + pr * (PW * 128));                                        \
     }
 #else
-#define MOE_LOAD_STEP(S, BUF)                                                                              \
+#define MOE_LOAD_STEP(S, BUF, PB)                                                                            \
     {                                                                                                      \
         constexpr int dx_ = (S) / 4, ks_ = (S) % 4;                                                        \
-        const char* ap_ = abuf + Ad[dx_] + ((ks_ << 5) ^ Zd[dx_]);                                         \
+        const char* ap_ = (PB) + Ad[dx_] + ((ks_ << 5) ^ Zd[dx_]);                                         \
         _Pragma("unroll") for (int pr = 0; pr < 4; ++pr) {                                                 \
             af[BUF][pr] = *(const half8_t*)(ap_ + pr * (PW * 128));                                        \
             if (pr < 3) {                                                                                  \
@@ -395,22 +395,42 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         }                                                                                                  \
     }
 #endif
-        MOE_LOAD_STEP(0, 0)
+#ifndef MOE_LATE_BARRIER
+        // (the fragments of k-step 0 were read in k-step 11 of the previous iteration, behind the barrier -- see below)
+#else
+        MOE_LOAD_STEP(0, 0, abuf)
 #if !defined(MOE_NO_SGB) && !defined(MOE_NO_FIRST10)
         // the first ten reads get a group of their own in front of the first MFMA slot: left to itself the solver may hand them the
         // read slots of k-step 0, and then every step's reads slide into the step that consumes them (no prefetch distance at all)
         __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
 #endif
+#endif
 #pragma unroll
         for (int s = 0; s < 12; ++s) {
             const int cb = s & 1;
             switch (s + 1) {   // constant after unrolling
-#define MOE_CASE(N) case N: MOE_LOAD_STEP(N, ((N) & 1)) break;
+#define MOE_CASE(N) case N: MOE_LOAD_STEP(N, ((N) & 1), abuf) break;
                 MOE_CASE(1) MOE_CASE(2) MOE_CASE(3) MOE_CASE(4) MOE_CASE(5) MOE_CASE(6)
                 MOE_CASE(7) MOE_CASE(8) MOE_CASE(9) MOE_CASE(10) MOE_CASE(11)
 #undef MOE_CASE
                 default: break;
             }
+#ifndef MOE_LATE_BARRIER
+            if (s == 11) {
+                // The workgroup barrier sits HERE, not at the end of the iteration: k-step 11 already holds its operands in
+                // registers, so nobody reads the current patch buffer any more (the next iteration may overwrite it), and the
+                // DMA pieces of the next patch (issued in k-steps 0..5) have had five steps to land.  Behind the barrier the
+                // fragments of the NEXT iteration's k-step 0 are read while this step's twelve MFMAs run: no LDS round trip
+                // between the last MFMA of a tile and the first of the next.
+                MOE_STAMP(1)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                MOE_STAMP(2)
+                __builtin_amdgcn_s_barrier();      // bare: __syncthreads() carries a fence that drains vmcnt/lgkmcnt again
+                asm volatile("" ::: "memory");
+                MOE_STAMP(3)
+                MOE_LOAD_STEP(0, 0, nbuf)
+            }
+#endif
             if (!(MOE_ABL & 1)) {   // compile-time timing ablation (tools/ablate_sp.sh); 0 in the product build
                 if (s < 5) { issue_piece(ps, 2 * s, nbuf, fetch); issue_piece(ps, 2 * s + 1, nbuf, fetch); }
                 if (s == 5) issue_piece(ps, 10, nbuf, fetch);
@@ -453,7 +473,11 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#ifndef MOE_LATE_BARRIER
+                if (i < SGB_DSR_SLOTS) __builtin_amdgcn_sched_group_barrier(0x100, 10 / SGB_DSR_SLOTS, 0);
+#else
                 if (i < SGB_DSR_SLOTS && s + 1 < 12) __builtin_amdgcn_sched_group_barrier(0x100, 10 / SGB_DSR_SLOTS, 0);
+#endif
                 if (i < SGB_DSR_SLOTS) __builtin_amdgcn_sched_group_barrier(0x002, SGB_VALU_A, 0);
                 else __builtin_amdgcn_sched_group_barrier(0x002, SGB_VALU_B, 0);
                 if ((i == SGB_DMA_AT || i == SGB_DMA_AT + 1) && s <= 5) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
@@ -477,24 +501,29 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
 #endif
 #endif
         }
-#undef MOE_LOAD_STEP
         if (MOE_ABL & 2) {   // keep the MFMAs alive without a drain
 #pragma unroll
             for (int o = 0; o < 2; ++o)
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) asm volatile("" ::"a"(prev[o][nb]));
         }
+#ifdef MOE_LATE_BARRIER
         MOE_STAMP(1)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         MOE_STAMP(2)
-        // bare s_barrier: __syncthreads() carries a workgroup fence, for which the compiler drains vmcnt to 0 -- that would wait for
-        // every store acknowledgement and for the residual loads just issued.  Nothing here communicates through global memory;
-        // the LDS side is ordered by the explicit vmcnt wait above (DMA landed) and by the MFMAs having consumed every ds_read.
         __builtin_amdgcn_s_barrier();
         MOE_STAMP(3)
+#endif
         it_prev = it_cur; it_cur = it_next; it_next = advance(it_next);
     };
 
+#ifndef MOE_LATE_BARRIER
+    {
+        const char* abuf = pbuf;
+        MOE_LOAD_STEP(0, 0, abuf)      // k-step 0 of the first tile (every later one is read in k-step 11 of its predecessor)
+    }
+#endif
+#undef MOE_LOAD_STEP
     int p = 0;
     for (; p + 1 < K; p += 2) {
         iteration(p, accA, accB);
