@@ -229,6 +229,17 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
     const unsigned ph = (unsigned)(si * r + sj);
     const unsigned ttrash = 9u * (unsigned)(r * r) * lrplane + lane * 4;   // slack behind the planes (16 B per lane)
     float tap8 = 0.f;                                                    // centre-bottom tap of row 0, parked until row 1 is done
+    // Byte offset of this lane's 16 bytes of slice (o, nb, gp) of tile `it` in `out` (or `res`): everything but the lane term is
+    // wave-uniform (SALU), so a slice costs one v_add (SGPR operand) and one v_cndmask, and the access uses the SGPR-base +
+    // 32-bit-offset form.  Lanes outside the image (or a disabled slice) go to the slack behind the tensor.
+    const unsigned lane_ob = ((unsigned)(j * r) * (unsigned)a.out_cs + (unsigned)hh * 8u) * 2u;
+    const unsigned trash_ob = trash_off * 2u;
+    auto out_off = [&](const Item& it, int o, int nb, int gp, bool live) {
+        const int y = it.pyi * kTileH + w4 * 2 + o;
+        const unsigned srow = ((unsigned)(it.b * Ho + y * r + si) * (unsigned)Wo + (unsigned)(it.pxi * kTileW * r + sj)) * (unsigned)a.out_cs + (unsigned)(cout0 + nb * 32 + gp * 16);
+        const bool okx = it.pxi * kTileW + j < a.W, oky = (y < a.H) & live;
+        return (okx & oky) ? lane_ob + srow * 2u : trash_ob;
+    };
     auto drain_slice = [&](float16_t (&ac)[2][2], const Item& it, int s8, bool live, const uint4* resw = nullptr) {
         const int o = s8 >> 2, nb = (s8 >> 1) & 1, gp = s8 & 1;
         const int y = it.pyi * kTileH + w4 * 2 + o, x = it.pxi * kTileW + j;
@@ -309,9 +320,6 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
             }
             return;
         }
-        // 32-bit element offset (the launcher guarantees the output tensor has < 2^32 elements): cheap enough that the
-        // compiler keeps the predicated-off lanes on a v_cndmask instead of branching around the address arithmetic
-        const unsigned opix = ((unsigned)(it.b * Ho + y * r + si) * (unsigned)Wo + (unsigned)(x * r + sj)) * (unsigned)a.out_cs + (unsigned)(cout0 + nb * 32 + gp * 16);
         if (RES) {
             // the residual was fetched as one 16-byte access per lane in the STORE layout (lane (j,0): channels 16*gp..+7,
             // lane (j,1): +8..+15); the same v_permlane32_swap pair that builds that layout also undoes it
@@ -352,7 +360,7 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
             *(uint4*)(a.out + lin) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
             return;
         }
-        *(uint4*)(a.out + (ok ? opix + hh * 8 : trash_off)) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        *(uint4*)((char*)a.out + out_off(it, o, nb, gp, live)) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
     };
 
     // residual of the tile being MULTIPLIED (drained one iteration later): slice k is fetched in k-step k+1, right after the
@@ -362,13 +370,9 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
 #pragma unroll
     for (int s8 = 0; s8 < 8; ++s8) resw[s8] = make_uint4(0, 0, 0, 0);
     auto fetch_res = [&](const Item& it, int s8) {
-        const int o = s8 >> 2, nb = (s8 >> 1) & 1, gp = s8 & 1;
-        const int y = it.pyi * kTileH + w4 * 2 + o, x = it.pxi * kTileW + j;
-        const bool ok = (y < a.H) & (x < a.W);
-        const unsigned opix = ((unsigned)(it.b * Ho + y * r + si) * (unsigned)Wo + (unsigned)(x * r + sj)) * (unsigned)a.out_cs + (unsigned)(cout0 + nb * 32 + gp * 16);
-        unsigned off = ok ? opix + hh * 8 : trash_off;
+        unsigned off = out_off(it, s8 >> 2, (s8 >> 1) & 1, s8 & 1, true);
         asm volatile("" : "+v"(off));        // keep the select: the compiler otherwise turns it into two predicated loads behind branches
-        resw[s8] = *(const uint4*)(a.res + off);
+        resw[s8] = *(const uint4*)((const char*)a.res + off);
     };
     Item it_cur = decode(g, a.px, a.py), it_prev = it_cur, it_next = advance(it_cur);
     // iteration p (0 <= p < K): multiply patch p (buffer p&1) into `cur`; drain patch p-1 from `prev` (stores predicated
@@ -588,11 +592,11 @@ hipError_t conv3x3_sp_init()
 bool launch_conv3x3_sp(const ConvArgs& a, hipStream_t s)
 {
     if ((a.acc_mode != 0 && !(a.dbg & 64)) || a.slope > 1.f) return false;
-    if ((long long)a.B * a.H * a.r * a.W * a.r * a.out_cs >= (1ll << 32) - 4096) return false;   // 32-bit store offsets
+    if (2ll * a.B * a.H * a.r * a.W * a.r * a.out_cs >= (1ll << 32) - 8192) return false;   // 32-bit BYTE offsets for stores / residual loads
     if (a.scale != 1.f || !a.bias_img) return false;           // the engine folds ScaleLayer into the weights and always passes a bias vector
     const bool act = a.slope != 1.f, res = a.res != nullptr, tail = a.tplanes != nullptr;
     if ((act || tail) && res) return false;
-    if (tail && 9ll * a.B * a.H * a.r * a.W * a.r >= (1ll << 32) - 4096) return false;
+    if (tail && 36ll * a.B * a.H * a.r * a.W * a.r >= (1ll << 32) - 8192) return false;
     const int epi = tail ? 3 : (res ? 2 : (act ? 1 : 0));
     const int blocks = a.nchunks * ((a.G + 7) / 8) * 8;
     const dim3 grid(blocks), blk(256);
