@@ -234,13 +234,21 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
     // 32-bit-offset form.  Lanes outside the image (or a disabled slice) go to the slack behind the tensor.
     const unsigned lane_ob = ((unsigned)(j * r) * (unsigned)a.out_cs + (unsigned)hh * 8u) * 2u;
     const unsigned trash_ob = trash_off * 2u;
-    auto out_off = [&](const Item& it, int o, int nb, int gp, bool live) {
-        const int y = it.pyi * kTileH + w4 * 2 + o;
-        const unsigned srow = ((unsigned)(it.b * Ho + y * r + si) * (unsigned)Wo + (unsigned)(it.pxi * kTileW * r + sj)) * (unsigned)a.out_cs + (unsigned)(cout0 + nb * 32 + gp * 16);
-        const bool okx = it.pxi * kTileW + j < a.W, oky = (y < a.H) & live;
-        return (okx & oky) ? lane_ob + srow * 2u : trash_ob;
+    struct TileOut { unsigned s00; int y0; bool okx; };      // per tile: offset of its first row in `out`, that row's y, lane inside the image in x
+    const unsigned rstride = (unsigned)(r * Wo) * (unsigned)a.out_cs;      // elements between the wave's two output rows
+    auto tile_out = [&](const Item& it) {
+        TileOut t;
+        t.y0 = it.pyi * kTileH + w4 * 2;
+        t.s00 = ((unsigned)(it.b * Ho + t.y0 * r + si) * (unsigned)Wo + (unsigned)(it.pxi * kTileW * r + sj)) * (unsigned)a.out_cs + (unsigned)cout0;
+        t.okx = it.pxi * kTileW + j < a.W;
+        return t;
     };
-    auto drain_slice = [&](float16_t (&ac)[2][2], const Item& it, int s8, bool live, const uint4* resw = nullptr) {
+    auto out_off = [&](const TileOut& t, int o, int nb, int gp, bool live) {
+        const unsigned srow = t.s00 + (unsigned)o * rstride + (unsigned)(nb * 32 + gp * 16);
+        const bool oky = (t.y0 + o < a.H) & live;
+        return (t.okx & oky) ? lane_ob + srow * 2u : trash_ob;
+    };
+    auto drain_slice = [&](float16_t (&ac)[2][2], const Item& it, const TileOut& to, int s8, bool live, const uint4* resw = nullptr) {
         const int o = s8 >> 2, nb = (s8 >> 1) & 1, gp = s8 & 1;
         const int y = it.pyi * kTileH + w4 * 2 + o, x = it.pxi * kTileW + j;
         const bool ok = (y < a.H) & (x < a.W) & live;
@@ -360,7 +368,7 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
             *(uint4*)(a.out + lin) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
             return;
         }
-        *(uint4*)((char*)a.out + out_off(it, o, nb, gp, live)) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        *(uint4*)((char*)a.out + out_off(to, o, nb, gp, live)) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
     };
 
     // residual of the tile being MULTIPLIED (drained one iteration later): slice k is fetched in k-step k+1, right after the
@@ -369,8 +377,8 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
     uint4 resw[8];
 #pragma unroll
     for (int s8 = 0; s8 < 8; ++s8) resw[s8] = make_uint4(0, 0, 0, 0);
-    auto fetch_res = [&](const Item& it, int s8) {
-        unsigned off = out_off(it, s8 >> 2, (s8 >> 1) & 1, s8 & 1, true);
+    auto fetch_res = [&](const TileOut& to, int s8) {
+        unsigned off = out_off(to, s8 >> 2, (s8 >> 1) & 1, s8 & 1, true);
         asm volatile("" : "+v"(off));        // keep the select: the compiler otherwise turns it into two predicated loads behind branches
         resw[s8] = *(const uint4*)((const char*)a.res + off);
     };
@@ -383,6 +391,7 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         const bool drain = (p >= 1) && !(a.dbg & 4);
         const bool fetch = (p + 1 < K) && !(a.dbg & 1);
         const Item itp = it_prev;
+        const TileOut top = tile_out(itp), toc = tile_out(it_cur);     // addressing of the drained tile / of the residual being fetched
         const PatchSrc ps = patch_src(it_next);
         const char* abuf = pbuf + (p & 1) * PATCH_BYTES;
         char* nbuf = pbuf + ((p + 1) & 1) * PATCH_BYTES;
@@ -469,8 +478,8 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
                             cur[o][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cb][dy][nb], af[cb][pr], (s == 0 && dy == 0) ? biasv[nb] : cur[o][nb], 0, 0, 0);
                     }
                 }
-            if (!(MOE_ABL & 2) && s >= DRAIN0 && s < DRAIN0 + 8) drain_slice(prev, itp, s - DRAIN0, drain, resw);
-            if (RES && s >= DRAIN0 + 1 && s <= DRAIN0 + 8) fetch_res(it_cur, s - DRAIN0 - 1);   // slice s-1's registers were consumed in the previous step
+            if (!(MOE_ABL & 2) && s >= DRAIN0 && s < DRAIN0 + 8) drain_slice(prev, itp, top, s - DRAIN0, drain, resw);
+            if (RES && s >= DRAIN0 + 1 && s <= DRAIN0 + 8) fetch_res(toc, s - DRAIN0 - 1);   // slice s-1's registers were consumed in the previous step
 #ifdef MOE_STEP_STAMPS
             MOE_STAMP(4 + s)
 #endif
@@ -513,14 +522,12 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, SGB_VALU_B, 0);
             }
-            // Fused-tail variant: nothing moves across a k-step boundary.  Its 13th MFMA per step makes the solver's slot pattern drift
-            // until LDS reads sit right in front of their consumers (38-46 of 120 reads with < 6 MFMAs of distance; 14 with the
-            // fence; 7650 -> 6850 cycles per tile, -4 % wall).  The other variants schedule as well or better as one region
-            // (tools/seq_view.py shows the compiled pattern; the residual variant gains only when HBM-bound at B = 48).
-#if defined(MOE_STEP_FENCE_ALL)
+            // Nothing moves across a k-step boundary.  As ONE region the sched_group_barrier slot pattern drifts whenever the amount of
+            // filler work per step changes (a 13th MFMA in the fused-tail variant, fewer VALU after an epilogue diet ...) until the
+            // LDS reads sit right in front of their consumers: 39-83 of 100 reads with < 6 MFMAs of distance and +15 % cycles were
+            // seen; fenced, every step compiles to `wait, 5 x (MFMA, 2 reads), DMA/MFMA mix, 7 MFMAs` (tools/seq_view.py).
+#ifndef MOE_STEP_FENCE_NONE
             __builtin_amdgcn_sched_barrier(0);
-#elif !defined(MOE_STEP_FENCE_NONE)
-            if (TAIL) __builtin_amdgcn_sched_barrier(0);
 #endif
 #endif
         }
@@ -558,14 +565,15 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
     }
     {   // drain the last tile (patch K-1): it sits in A when K is odd, in B when K is even
         const Item itp = it_prev;
+        const TileOut top = tile_out(itp);
         const bool live = !(a.dbg & 4);
         // (its residual was fetched in steps 8..11 of the last iteration)
         if (K & 1) {
 #pragma unroll
-            for (int s8 = 0; s8 < 8; ++s8) drain_slice(accA, itp, s8, live, resw);
+            for (int s8 = 0; s8 < 8; ++s8) drain_slice(accA, itp, top, s8, live, resw);
         } else {
 #pragma unroll
-            for (int s8 = 0; s8 < 8; ++s8) drain_slice(accB, itp, s8, live, resw);
+            for (int s8 = 0; s8 < 8; ++s8) drain_slice(accB, itp, top, s8, live, resw);
         }
     }
 }
