@@ -559,6 +559,7 @@ bool can_fuse_tail(const moe_net& n, const Fwd& f, int B, int h, int w)
     if (!(n.arch == MOE_ARCH_NET2X || n.arch == MOE_ARCH_NET3X || n.arch == MOE_ARCH_NET4X)) return false;
     long long sc = 1;
     for (int s = 0; s < n.stages; ++s) sc *= n.r;
+    if ((w * (sc / n.r)) % 4 != 0) return false;            // the fused kernel stores tap planes four input columns at a time
     if (9ll * B * h * sc * w * sc >= (1ll << 32) - 4096) return false;
     for (const char* br : {"u", "convt_R1"}) {
         const auto it = n.conv_index.find(std::string(br) + ".up" + std::to_string(n.stages - 1));

@@ -139,6 +139,10 @@ def test_ragged_and_tiny_tiles(dev):
     x = gd.natural_image(9, (3, 40, 264))[:, None]
     y = mf(torch.from_numpy(x).to(dev))[-1].cpu().numpy()
     assert np.abs(y - onets.forward('net2x', sd, x).numpy()).max() <= 2e-3        # single-pass fp16 operands on a busy tile: 1.4e-3
+    for (h, w) in ((9, 35), (24, 52), (16, 42)):      # fused-tail kernel: widths that are odd / 4-aligned only / 2-aligned (fallback paths)
+        x = gd.natural_image(11, (3, h, w))[:, None]
+        y = mf(torch.from_numpy(x).to(dev))[-1].cpu().numpy()
+        assert np.abs(y - onets.forward('net2x', sd, x).numpy()).max() <= 2e-3, (h, w)
     m16 = module_for('a2', dtype=torch.float16)
     x = gd.natural_image(9, (4, 40, 48))[:, None]                                 # 4 planes: RGBA through SR
     x16 = torch.from_numpy(x).half()
