@@ -137,11 +137,7 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         constexpr int p = 0;
         MOE_STAMP(14)
         const half_t* wsrc = a.wpk + (long long)chunk * (WBYTES / 2);
-#ifndef MOE_NO_WROT
         const int rot = (bid >> 3) % (NFRAG / 4);
-#else
-        const int rot = 0;
-#endif
         for (int k = 0; k < NFRAG / 4; ++k) {
             int fk = k + rot;
             fk -= fk >= NFRAG / 4 ? NFRAG / 4 : 0;
@@ -198,13 +194,7 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
     // One eighth (index s8 = (o, nb, gp)) of the epilogue of a finished tile held in `ac`.  Branch-free: lanes outside the
     // image (or a disabled slice) store to a trash line and read their residual from the zero page.
     constexpr bool ACT = (EPI == 1) || (EPI == 3), RES = (EPI == 2), TAIL = (EPI == 3);
-#ifndef MOE_DRAIN0_TAIL
-#define MOE_DRAIN0_TAIL 0
-#endif
-#ifndef MOE_DRAIN0
-#define MOE_DRAIN0 0
-#endif
-    constexpr int DRAIN0 = TAIL ? MOE_DRAIN0_TAIL : MOE_DRAIN0;   // first of the eight k-steps that carry a slice of the previous tile's epilogue
+    constexpr int DRAIN0 = 0;      // first of the eight k-steps that carry a slice of the previous tile's epilogue
     unsigned slope2;               // {slope, slope} as packed halves
     {
         typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
@@ -402,18 +392,6 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         }
 // the ten reads of a k-step in the order its MFMAs consume them (input row pr, then the weights of the tap row it meets first):
 // LDS returns in order, so the first MFMAs of the step wait for two reads instead of seven
-#ifdef MOE_LOAD_ORDER_WA      /* weights first, then the four input rows */
-#define MOE_LOAD_STEP(S, BUF, PB)                                                                            \
-    {                                                                                                      \
-        constexpr int dx_ = (S) / 4, ks_ = (S) % 4;                                                        \
-        _Pragma("unroll") for (int dy = 0; dy < 3; ++dy)                                                   \
-            _Pragma("unroll") for (int nb = 0; nb < 2; ++nb)                                               \
-                wf[BUF][dy][nb] = *(const half8_t*)(wl + ((((dy * 3 + dx_) * 4 + ks_) * 2 + nb) << 10));   \
-        const char* ap_ = (PB) + Ad[dx_] + ((ks_ << 5) ^ Zd[dx_]);                                         \
-        _Pragma("unroll") for (int pr = 0; pr < 4; ++pr)                                                   \
-            af[BUF][pr] = *(const half8_t*)(ap_ + pr * (PW * 128));                                        \
-    }
-#else
 #define MOE_LOAD_STEP(S, BUF, PB)                                                                            \
     {                                                                                                      \
         constexpr int dx_ = (S) / 4, ks_ = (S) % 4;                                                        \
@@ -426,17 +404,7 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
             }                                                                                              \
         }                                                                                                  \
     }
-#endif
-#ifndef MOE_LATE_BARRIER
         // (the fragments of k-step 0 were read in k-step 11 of the previous iteration, behind the barrier -- see below)
-#else
-        MOE_LOAD_STEP(0, 0, abuf)
-#if !defined(MOE_NO_SGB) && !defined(MOE_NO_FIRST10)
-        // the first ten reads get a group of their own in front of the first MFMA slot: left to itself the solver may hand them the
-        // read slots of k-step 0, and then every step's reads slide into the step that consumes them (no prefetch distance at all)
-        __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
-#endif
-#endif
 #pragma unroll
         for (int s = 0; s < 12; ++s) {
             const int cb = s & 1;
@@ -447,7 +415,6 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
 #undef MOE_CASE
                 default: break;
             }
-#ifndef MOE_LATE_BARRIER
             if (s == 11) {
                 // The workgroup barrier sits HERE, not at the end of the iteration: k-step 11 already holds its operands in
                 // registers, so nobody reads the current patch buffer any more (the next iteration may overwrite it), and the
@@ -462,7 +429,6 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
                 MOE_STAMP(3)
                 MOE_LOAD_STEP(0, 0, nbuf)
             }
-#endif
             if (!(MOE_ABL & 1)) {   // compile-time timing ablation (tools/ablate_sp.sh); 0 in the product build
                 if (s < 5) { issue_piece(ps, 2 * s, nbuf, fetch); issue_piece(ps, 2 * s + 1, nbuf, fetch); }
                 if (s == 5) issue_piece(ps, 10, nbuf, fetch);
@@ -505,11 +471,7 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-#ifndef MOE_LATE_BARRIER
                 if (i < SGB_DSR_SLOTS) __builtin_amdgcn_sched_group_barrier(0x100, 10 / SGB_DSR_SLOTS, 0);
-#else
-                if (i < SGB_DSR_SLOTS && s + 1 < 12) __builtin_amdgcn_sched_group_barrier(0x100, 10 / SGB_DSR_SLOTS, 0);
-#endif
                 if (i < SGB_DSR_SLOTS) __builtin_amdgcn_sched_group_barrier(0x002, SGB_VALU_A, 0);
                 else __builtin_amdgcn_sched_group_barrier(0x002, SGB_VALU_B, 0);
                 if ((i == SGB_DMA_AT || i == SGB_DMA_AT + 1) && s <= 5) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
@@ -537,22 +499,13 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) asm volatile("" ::"a"(prev[o][nb]));
         }
-#ifdef MOE_LATE_BARRIER
-        MOE_STAMP(1)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        MOE_STAMP(2)
-        __builtin_amdgcn_s_barrier();
-        MOE_STAMP(3)
-#endif
         it_prev = it_cur; it_cur = it_next; it_next = advance(it_next);
     };
 
-#ifndef MOE_LATE_BARRIER
     {
         const char* abuf = pbuf;
         MOE_LOAD_STEP(0, 0, abuf)      // k-step 0 of the first tile (every later one is read in k-step 11 of its predecessor)
     }
-#endif
 #undef MOE_LOAD_STEP
     int p = 0;
     for (; p + 1 < K; p += 2) {
