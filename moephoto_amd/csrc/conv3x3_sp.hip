@@ -8,10 +8,13 @@
 // instructions issued in the shadow of its MFMAs (about 5 issue slots per 32-cycle v_mfma_f32_32x32x16_f16).  So:
 //
 //   * 4 waves per workgroup (one per SIMD, all 512 registers each), two accumulator sets per wave;
-//   * iteration p multiplies patch p into set A while draining set B (patch p-1): in each of the 12 k-steps, next to
-//     its 12 MFMAs and 10 ds_read_b128, the wave finishes one eighth of the previous tile (bias/scale/PReLU in fp32,
-//     fp16, v_permlane32_swap pair, one 16-byte store) and issues one 1-KiB DMA piece of patch p+1;
-//   * one workgroup barrier per patch.
+//   * iteration p multiplies patch p into set A while draining set B (patch p-1): in k-steps 0..7, next to its 12 MFMAs and
+//     10 ds_read_b128, the wave finishes one eighth of the previous tile (fp16 conversion, PReLU on packed halves or the
+//     fp32 residual add, v_permlane32_swap pair, one 16-byte store) and in k-steps 0..5 issues the DMA pieces of patch p+1;
+//   * the bias is the C operand of each accumulator's first MFMA (no reset); the one workgroup barrier per patch sits in
+//     k-step 11, behind which the first fragments of patch p+1 are read while that step's MFMAs run;
+//   * every k-step is its own scheduling region (sched_barrier) with a sched_group_barrier slot pattern inside: measured
+//     74 % MFMA occupancy in cycles (97 % for the bare MFMA/LDS stream); DESIGN.md section 4 has the cycle budget.
 //
 // GEMM view, LDS image (column-keyed XOR swizzle), weight fragment order and the fused epilogue are those of
 // conv_mfma.hip / conv3x3_pp.hip; wave tile = 2 output rows x 32 pixels x 64 output channels.
