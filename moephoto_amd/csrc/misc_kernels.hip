@@ -303,11 +303,14 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const half_t* in, con
 // SEDN squeeze-excite gate (models.py:198-208): g = sigmoid(W_up * lrelu(W_down * mean)); the gate multiplies the
 // 256 input channels of the following 1x1 `trans` conv, so it is folded into a per-plane copy of trans's packed
 // weights: W'[b][o][c] = W[o][c] * g[b][c]  (fp32 product, then fp16 -- the activations themselves stay untouched).
-// One block per plane.
+// kSeSplit blocks per plane: each recomputes the (tiny) gate and rescales its share of the weights.  The 256->16 squeeze runs
+// on all 256 threads (16 per hidden unit, fixed-order tree sum) -- as 16 serial 256-term dot products it was 45 us per launch.
 // ---------------------------------------------------------------------------------------------------
+constexpr int kSeSplit = 8;
 __global__ __launch_bounds__(256) void sedn_se_kernel(SednSeArgs a)
 {
     __shared__ float mean[256];
+    __shared__ float part[256];
     __shared__ float hid[16];
     __shared__ float gate[256];
     const int b = blockIdx.x, t = threadIdx.x;
@@ -315,9 +318,18 @@ __global__ __launch_bounds__(256) void sedn_se_kernel(SednSeArgs a)
     for (int k = 0; k < a.nslab; ++k) s += a.partial[((long long)b * a.nslab + k) * 256 + t];
     mean[t] = s / (float)a.HW;
     __syncthreads();
+    {
+        const int k = t >> 4, q = t & 15;            // hidden unit k, channels 16q .. 16q+15
+        float h = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) h += a.w_down[k * 256 + q * 16 + c] * mean[q * 16 + c];
+        part[t] = h;
+    }
+    __syncthreads();
     if (t < 16) {
         float h = 0.f;
-        for (int c = 0; c < 256; ++c) h += a.w_down[t * 256 + c] * mean[c];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) h += part[t * 16 + q];
         hid[t] = prelu(h, 0.2f);
     }
     __syncthreads();
@@ -328,15 +340,16 @@ __global__ __launch_bounds__(256) void sedn_se_kernel(SednSeArgs a)
         gate[t] = 1.f / (1.f + __expf(-u));
     }
     __syncthreads();
+    const int part_i = blockIdx.y;
     if (a.nfrag < 0) {   // MOE_PREC_DEBUG_DIRECT: plain fp32 [cout][256] weights, -nfrag elements
         const int total = -a.nfrag;
         float* o = (float*)a.trans_out;
-        for (int i = t; i < total; i += 256) o[(long long)b * total + i] = a.trans_pk32[i] * gate[i & 255];
+        for (int i = part_i * 256 + t; i < total; i += 256 * kSeSplit) o[(long long)b * total + i] = a.trans_pk32[i] * gate[i & 255];
         return;
     }
     // packed fragment element idx -> input channel:  frag f = (seg*4 + ks)*2 + nblk, lane l, e
     const int total = a.nfrag * 512;
-    for (int i = t; i < total; i += 256) {
+    for (int i = part_i * 256 + t; i < total; i += 256 * kSeSplit) {
         const int e = i & 7, l = (i >> 3) & 63, f = i >> 9;
         const int ks = (f >> 1) & 3, seg = f >> 3;
         const int cin = seg * 64 + ks * 16 + 8 * (l >> 5) + e;
@@ -525,7 +538,7 @@ void launch_pool_partial(const half_t* in, const half_t* in_lo, float* partial, 
 
 void launch_sedn_se(const SednSeArgs& a, hipStream_t s)
 {
-    hipLaunchKernelGGL(sedn_se_kernel, dim3(a.B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(sedn_se_kernel, dim3(a.B, kSeSplit), dim3(256), 0, s, a);
 }
 
 void launch_frm(const FrmArgs& a, hipStream_t s)

@@ -14,8 +14,9 @@ from moephoto_amd.weights import load_state_dict_file  # noqa: E402
 
 B = int(os.environ.get('PROF_B', '12'))
 ITER = int(os.environ.get('PROF_ITER', '2'))
-m = models.Net4x()
-m.load_state_dict({n: torch.from_numpy(v) for n, v in gd.synth_state_dict('a4', load_state_dict_file).items()})
+KEY = os.environ.get('PROF_MODEL', 'a4')     # a4 | a3 | a2
+m = {'a4': models.Net4x, 'a3': models.Net3x, 'a2': models.Net2x}[KEY]()
+m.load_state_dict({n: torch.from_numpy(v) for n, v in gd.state_dict_for(KEY, load_state_dict_file).items()})
 m.to(dtype=torch.float16, device='cuda:0')
 x = torch.from_numpy(gd.natural_image(1, (B, 256, 256))[:, None]).cuda().half()
 for _ in range(ITER):

@@ -26,8 +26,11 @@ cases = [('SR a2', lambda: runSR.getOpt({'model': 'a', 'scale': 2})), ('SR a3', 
          ('SR a4', lambda: runSR.getOpt({'model': 'a', 'scale': 4})), ('SR lite2', lambda: runSR.getOpt({'model': 'lite', 'scale': 2})),
          ('SR lite4', lambda: runSR.getOpt({'model': 'lite', 'scale': 4})), ('DN lite5', lambda: runDN.getOpt({'model': 'lite5'})),
          ('DN l25', lambda: runDN.getOpt({'model': '25'}))]
+only = os.environ.get('TM_ONLY')          # e.g. TM_ONLY='SR a3' TM_PREC=fp16 under rocprofv3
 for name, mk in cases:
-    for prec in ('fp16', 'fp16x3'):
+    if only and name != only:
+        continue
+    for prec in os.environ.get('TM_PREC', 'fp16,fp16x3').split(','):
         ip.modelCache.clear()
         opt = mk()
         opt.modelCached.set_precision(prec)
