@@ -427,11 +427,8 @@ __global__ __launch_bounds__(256) void frm_apply_kernel(FrmArgs a)
 //     v1 = ex + wH*(r-ex)  (row inside the tile's blend band, else r);   v = ex + wW*(v1-ex)  (column likewise)
 // with the same fp32 operation order as the reference, so the result is bit-identical to the sequential loop.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void stitch_kernel(StitchArgs a)
+__device__ __forceinline__ float stitch_pixel(const StitchArgs& a, int X, int Y, int c)
 {
-    const int X = blockIdx.x * 256 + threadIdx.x;
-    const int Y = blockIdx.y, c = blockIdx.z;
-    if (X >= a.out_w) return;
     const int i0 = a.row_first[Y], ni = a.row_cnt[Y];
     const int j0 = a.col_first[X], nj = a.col_cnt[X];
     float cur = 0.f;
@@ -447,9 +444,54 @@ __global__ __launch_bounds__(256) void stitch_kernel(StitchArgs a)
             cur = v;
         }
     }
+    return cur;
+}
+
+__global__ __launch_bounds__(256) void stitch_kernel(StitchArgs a)
+{
+    const int X = blockIdx.x * 256 + threadIdx.x;
+    const int Y = blockIdx.y, c = blockIdx.z;
+    if (X >= a.out_w) return;
+    const float cur = stitch_pixel(a, X, Y, c);
     const long long o = ((long long)c * a.out_h + Y) * a.out_w + X;
     if (a.out_dtype == MOE_F16) ((half_t*)a.out)[o] = (half_t)cur;
     else ((float*)a.out)[o] = cur;
+}
+
+// Four consecutive pixels per thread (out_w % 4 == 0).  Almost every quad lies inside one tile's solid region: then the fold is
+// the identity on that tile's value and the quad is one 16-byte load and one 8/16-byte store; the others take the exact
+// per-pixel fold above.  (One pixel per thread: 465 us per 8K frame; this: 350; eight rows per thread was slower again.)
+__global__ __launch_bounds__(256) void stitch4_kernel(StitchArgs a)
+{
+    const int X0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int Y = blockIdx.y, c = blockIdx.z;
+    if (X0 >= a.out_w) return;
+    float v[4];
+    const int i0 = a.row_first[Y], j0 = a.col_first[X0];
+    bool fast = a.row_cnt[Y] == 1 && a.col_cnt[X0] == 1 && a.col_cnt[X0 + 3] == 1 && a.col_first[X0 + 3] == j0;
+    if (fast) {
+        const int sy = a.row_tab[i0 * 4 + 1], oy = a.row_tab[i0 * 4 + 2], eh = a.row_tab[i0 * 4 + 3];
+        const int sx = a.col_tab[j0 * 4 + 1], ox = a.col_tab[j0 * 4 + 2], ew = a.col_tab[j0 * 4 + 3];
+        const long long o = a.tile_off[i0 * a.step_w + j0] + ((long long)c * eh + (Y - oy)) * ew + (X0 - ox);
+        fast = Y >= sy && X0 >= sx && (o & 3) == 0;
+        if (fast) {
+            const float4 q = *(const float4*)(a.tiles + o);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        }
+    }
+    if (!fast) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = stitch_pixel(a, X0 + e, Y, c);
+    }
+    const long long o = ((long long)c * a.out_h + Y) * a.out_w + X0;
+    if (a.out_dtype == MOE_F16) {
+        half4_t h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = (half_t)v[e];
+        *(half4_t*)((half_t*)a.out + o) = h;
+    } else {
+        *(float4*)((float*)a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -550,7 +592,8 @@ void launch_frm(const FrmArgs& a, hipStream_t s)
 
 void launch_stitch(const StitchArgs& a, hipStream_t s)
 {
-    hipLaunchKernelGGL(stitch_kernel, dim3((a.out_w + 255) / 256, a.out_h, a.C), dim3(256), 0, s, a);
+    if (a.out_w % 4 == 0 && ((uintptr_t)a.out & 15) == 0) hipLaunchKernelGGL(stitch4_kernel, dim3((a.out_w / 4 + 255) / 256, a.out_h, a.C), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(stitch_kernel, dim3((a.out_w + 255) / 256, a.out_h, a.C), dim3(256), 0, s, a);
 }
 
 void launch_to_float(const void* src, int src_dtype, float d, bool divide, int H, int W, int C, void* dst, int dst_dtype, hipStream_t s)
