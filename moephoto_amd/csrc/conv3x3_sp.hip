@@ -67,7 +67,7 @@ struct PatchSrc { const half_t* base; int y0, x0; };
 // timing trace (MOE_DBG & 64): acc32 doubles as a [wg<8][iter<32][wave<4][slot<16] table of s_memtime stamps
 // (slots 0..3: iteration start / body end / after vmcnt wait / after barrier; built with -DMOE_STEP_STAMPS also 4+s: end of k-step s)
 #ifdef MOE_STAMP_MIN          /* only the iteration-start stamp: the period without the cost of the other stamps */
-#define MOE_STAMP_ON(SLOT) ((SLOT) == 0)
+#define MOE_STAMP_ON(SLOT) ((SLOT) == 0 || (SLOT) >= 13)
 #else
 #define MOE_STAMP_ON(SLOT) true
 #endif
@@ -531,6 +531,11 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
 #pragma unroll
             for (int s8 = 0; s8 < 8; ++s8) drain_slice(accB, itp, top, s8, live, resw);
         }
+    }
+    {   // trace: end of the workgroup's work (slot 13 of iteration 0; slot 14 there is its start)
+        constexpr int p = 0;
+        if (a.dbg & 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MOE_STAMP(13)
     }
 }
 

@@ -23,3 +23,12 @@ for wg in (0, 3, 5):
 pro = t[:, 0, :, 15] - t[:, 0, :, 14]
 if pro.any():
     print('prologue cycles per wg (wave 0):', ' '.join(str(int(v)) for v in pro[:, 0]))
+import os
+if os.environ.get('TRACE_FIRST'):
+    for wg in (0, 5):
+        a = t[wg, :, 0, 0]
+        n = int((a != 0).sum())
+        print('wg', wg, 'iteration-start deltas:', ' '.join(str(int(v)) for v in np.diff(a[:n])[:14]), ' prologue', int(t[wg, 0, 0, 15] - t[wg, 0, 0, 14]), ' start->iter0', int(a[0] - t[wg, 0, 0, 14]))
+span = t[:, 0, 0, 13] - t[:, 0, 0, 14]
+if (t[:, 0, 0, 13] != 0).any():
+    print('workgroup start -> end cycles (wg 0..7, wave 0):', ' '.join(str(int(v)) for v in span))
