@@ -383,6 +383,43 @@ def test_dropin_protocol_reference_loop(dev):
     assert np.abs(out.cpu().numpy() - z['y']).max() <= TOL_FP16_SR
 
 
+def test_run_plan_frames_owner_sharding(dev):
+    """moe_run_plan_frames (the multi-GPU step of dist.run_frames): three frames in one call, tiles of different frames share
+    launches.  With one owner, and with the work split over three owners (each computing (f * n_tiles + k) % 3 == i), every
+    frame's pool and stitched result equal the frame-by-frame doCrop, bit for bit."""
+    import ctypes
+    from moephoto_amd import _lib, imageProcess as ip
+    opt = _opt_sr('a', 2, 64)
+    frames = torch.stack([torch.from_numpy(gd.natural_image(70 + f, (3, 150, 200))) for f in range(3)]).to(dev)
+    plan = ip._plan_for(opt, frames[0].shape)
+    L, model = _lib.lib(), opt.modelCached
+    stream = torch.cuda.current_stream().cuda_stream
+    pe = plan.pool_elems(3)
+    sC, sH, sW = frames[0].stride()
+
+    def run(owners):
+        pools = torch.zeros((3, pe), dtype=torch.float32, device=dev)
+        for i in range(owners):
+            _lib.check(L.moe_run_plan_frames(model._h, plan._h, frames.data_ptr(), _lib.F32, frames.stride(0), sC, sH, sW, 3,
+                                             ctypes.c_void_p(pools.data_ptr()), pe, i, owners, 3, stream))
+        outs = []
+        for f in range(3):
+            y = torch.empty((3, plan.outH, plan.outW), dtype=torch.float32, device=dev)
+            _lib.check(L.moe_stitch(plan._h, 0, pools[f].data_ptr(), None, 3, y.data_ptr(), _lib.F32, stream))
+            outs.append(y)
+        torch.cuda.synchronize()
+        return pools, outs
+    p1, o1 = run(1)
+    p3, o3 = run(3)
+    assert torch.equal(p1, p3)
+    for f in range(3):
+        want = ip.doCrop(opt, frames[f])
+        assert torch.equal(o1[f], want) and torch.equal(o3[f], want), f
+    with pytest.raises(RuntimeError):
+        _lib.check(L.moe_run_plan_frames(model._h, plan._h, frames.data_ptr(), _lib.F32, frames.stride(0), sC, sH, sW, 3,
+                                         ctypes.c_void_p(p1.data_ptr()), pe - 8, 0, 1, 3, stream))      # pool stride too small
+
+
 def test_full_size_properties_config2(dev):
     """BASELINE config 2 at full size (1080p -> 7680x4320, a4-synth, 256-px tiles, 40 tiles), checked through
     properties that do not need a full CPU run:
