@@ -31,9 +31,12 @@ struct ConvArgs {
     half_t* trash;        // >= 1 KiB write-only scratch (predicated-off stores of the branch-free epilogue land here)
     // FP16X3 (hi/lo split operands): partial products are combined through an fp32 side buffer
     half_t* out_lo;       // low part of the output activation ((v - hi) * 2^11), or nullptr
+    const half_t* in_lo;  // acc_mode 4 only: low part of the input activation (same layout as `in`)
     const half_t* res_lo; // low part of the residual, or nullptr
     float* acc32;         // [B][H][W][nchunks*64] fp32 partial sums (pre-shuffle coordinates)
-    int acc_mode;         // 0: none, 1: store acc, 2: acc32 += acc, 3: acc += acc32 * 2^-11 then epilogue
+    int acc_mode;         // 0: none, 1: store acc, 2: acc32 += acc, 3: acc += acc32 * 2^-11 then epilogue,
+                          // 4: all three split-precision products in ONE launch (1x1 convs, conv_mfma_kernel<1,3>): K segments
+                          //    (w_lo, in), (w_hi, in_lo), (w_hi, in); the accumulator is scaled by 2^-11 after the second
     long long w_batch_stride;  // halfs between per-plane weight sets (0: shared)
     int B, H, W;
     int in_cs, out_cs;    // channel strides of in / out, in halfs

@@ -96,7 +96,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
         const int pyi = t % a.py;
         const int b = t / a.py;
         const int y0 = pyi * kTileH - G::HALO, x0 = pxi * kTileW - G::HALO;
-        const half_t* base = a.in + ((long long)(b * a.H + y0) * a.W + x0) * a.in_cs + seg * kCB;
+        // acc_mode 4: the three K segments are (w_lo, in), (w_hi, in_lo), (w_hi, in) over the SAME 64 channels
+        const half_t* tensor = (a.acc_mode == 4) ? (seg == 1 ? a.in_lo : a.in) : a.in + seg * kCB;
+        const half_t* base = tensor + ((long long)(b * a.H + y0) * a.W + x0) * a.in_cs;
         char* dst = pbuf + buf * G::PATCH_BYTES;
 #pragma unroll
         for (int i = 0; i < G::NDMA_W; ++i) {
@@ -221,6 +223,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
         }
 #undef MOE_LOAD_STEP
 
+        if (a.acc_mode == 4 && seg == 1) {   // both low-order products are in: bring them to the scale of the main product
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[o][e] *= 0.00048828125f;
+        }
         // ---- epilogue (after the last K segment of the item) ---------------------------------------
         if (seg == NSEG - 1) {
             const int x = pxi * kTileW + j;
@@ -346,6 +354,7 @@ hipError_t conv_mfma_init()
     if ((e = set_lds_limit<9, 1>()) != hipSuccess) return e;
     if ((e = set_lds_limit<1, 1>()) != hipSuccess) return e;
     if ((e = set_lds_limit<1, 4>()) != hipSuccess) return e;
+    if ((e = set_lds_limit<1, 3>()) != hipSuccess) return e;
     if ((e = conv3x3_pp_init()) != hipSuccess) return e;
     if ((e = conv3x3_sp_init()) != hipSuccess) return e;
     int dev = 0;
@@ -365,6 +374,7 @@ void launch_conv_mfma(const ConvArgs& a, int taps, int nseg, hipStream_t s)
     if (taps == 9 && nseg == 1) launch_t<9, 1>(a, s);
     else if (taps == 1 && nseg == 1) launch_t<1, 1>(a, s);
     else if (taps == 1 && nseg == 4) launch_t<1, 4>(a, s);
+    else if (taps == 1 && nseg == 3) launch_t<1, 3>(a, s);     // acc_mode 4: the three split-precision products of a 64-channel 1x1 conv
 }
 
 void launch_conv_direct(const DirectConvArgs& a, hipStream_t s)

@@ -54,6 +54,8 @@ struct ConvLayer {               // one MFMA convolution
     float slope = 1.f, scale = 1.f;
     bool per_plane = false;      // SEDN trans: weights rebuilt per plane by the SE kernel
     size_t w_hi = 0, w_lo = 0, bias = 0, bias_img = 0, w_plain = 0, bias_plain = 0, w_pk32 = 0;   // offsets into the device blob
+    size_t w_x3 = 0;             // 1x1, one segment, split precision: [chunk][w_lo | w_hi | w_hi] for the single-launch path (acc_mode 4)
+    bool has_x3 = false;
     bool has_bias = false;
     int nfrag() const { return nseg * taps * 8; }
 };
@@ -244,6 +246,16 @@ void pack_conv(const Param& W, const Param* bias, int r, ConvLayer& L, BlobBuild
                     if (want_pk32) bb.at<float>(L.w_pk32)[idx] = v;
                 }
         }
+    if (want_lo && L.taps == 1 && L.nseg == 1) {
+        // single-launch split precision (conv_mfma_kernel<1,3>): per chunk the 8 fragments of w_lo, then those of w_hi twice
+        L.has_x3 = true;
+        L.w_x3 = bb.take(nel * 2 * 3);
+        const size_t per = (size_t)nfrag * 512;               // elements of one chunk
+        for (int chunk = 0; chunk < L.nchunks; ++chunk)
+            for (int seg3 = 0; seg3 < 3; ++seg3)
+                memcpy(bb.at<half_t>(L.w_x3) + ((size_t)chunk * 3 + seg3) * per,
+                       bb.at<half_t>(seg3 == 0 ? L.w_lo : L.w_hi) + (size_t)chunk * per, per * 2);
+    }
     L.has_bias = bias != nullptr;
     L.bias_img = bb.take((size_t)L.nchunks * 256 * 4);        // zero-filled; the biases are written below
     if (bias) {
@@ -528,6 +540,13 @@ struct Fwd {
                 n.prof_flops += 2.0 * (double)B * H * W * L.cout * L.cin * L.taps;   // algorithmic (real channel counts)
             }
             return fused_ok;
+        }
+        if (L.has_x3 && !pp) {
+            // 1x1 conv: all three products in one launch (K segments (w_lo, a_hi), (w_hi, a_lo), (w_hi, a_hi)); the activations are
+            // read once per product from L2/HBM and nothing goes through the fp32 side buffer (2.6x less traffic than three passes)
+            ConvArgs f4 = a; f4.wpk = blob<half_t>(L.w_x3); f4.acc_mode = 4; f4.in_lo = in.lo; f4.out_lo = out.lo; f4.res_lo = res ? res->lo : nullptr;
+            launch_conv_mfma(f4, 1, 3, s);
+            return true;
         }
         // hi/lo split: (w_lo * a_hi) -> acc32,  += (w_hi * a_lo),  then (w_hi * a_hi) + acc32/2048 and the epilogue
         a.acc32 = acc32;
