@@ -32,6 +32,10 @@ struct ConvArgs {
     // FP16X3 (hi/lo split operands): partial products are combined through an fp32 side buffer
     half_t* out_lo;       // low part of the output activation ((v - hi) * 2^11), or nullptr
     const half_t* in_lo;  // acc_mode 4 only: low part of the input activation (same layout as `in`)
+    // conv_mfma_kernel only: fused 1x1 tail (lite's last upsampler stage + its 48->1 conv).  The activated tile is not stored: each
+    // lane dots its 16 channels with tail1_w, the two 32-channel halves of the chunk go to two fp32 partial planes [2][B][Ho][Wo]
+    const float* tail1_w;  // [64] fp32 in output-channel order of the chunk, or nullptr
+    float* tail1_out;
     const half_t* res_lo; // low part of the residual, or nullptr
     float* acc32;         // [B][H][W][nchunks*64] fp32 partial sums (pre-shuffle coordinates)
     int acc_mode;         // 0: none, 1: store acc, 2: acc32 += acc, 3: acc += acc32 * 2^-11 then epilogue,
@@ -109,6 +113,14 @@ struct TapSumArgs {
     int vec_ok;    // r == 2 and every output row start is 16-byte aligned: the 8-outputs-per-thread kernel may be used
 };
 void launch_tapsum(const TapSumArgs& a, hipStream_t s);
+
+// y = sum of the four partial planes of the fused 1x1 tail (two branches x two channel halves), each [B][H][W] fp32
+struct Tail1SumArgs {
+    const float* p0; const float* p1;      // [2][B][H][W] per branch
+    void* y; int y_dtype; const long long* y_off;
+    int B, H, W;
+};
+void launch_tail1sum(const Tail1SumArgs& a, hipStream_t s);
 
 // per-plane channel sums: in [B][HW][C] fp16 -> partial [B][nslab][C] fp32
 void launch_pool_partial(const half_t* in, const half_t* in_lo, float* partial, int B, long long HW, int C, int nslab, hipStream_t s);

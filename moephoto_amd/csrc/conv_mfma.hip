@@ -134,6 +134,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
 
     const int j = lane & 31, hh = lane >> 5;
     float16_t acc[4];
+    float tw[4][4];                                      // fused 1x1 tail: this lane's 16 tail weights (channel wn*32 + hh*4 + 8*grp + e)
+#pragma unroll
+    for (int grp = 0; grp < 4; ++grp)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tw[grp][e] = a.tail1_w ? a.tail1_w[wn * 32 + hh * 4 + 8 * grp + e] : 0.f;
 
     for (int u = 0; u < my_units; ++u) {
         const int seg = u % NSEG;
@@ -243,6 +248,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
                 if (y < a.H && x < a.W) {
                     const long long opix = ((long long)(b * Ho + y * r + si) * Wo + (x * r + sj)) * a.out_cs;
                     const long long apix = ((long long)(b * a.H + y) * a.W + x) * (a.nchunks * kCB);
+                    float dot = 0.f;
 #pragma unroll
                     for (int grp = 0; grp < 4; ++grp) {
                         float4_t v = {acc[o][grp * 4 + 0], acc[o][grp * 4 + 1], acc[o][grp * 4 + 2], acc[o][grp * 4 + 3]};
@@ -256,6 +262,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
                         v = v * a.scale;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * a.slope;
+                        if (a.tail1_out) {       // fused 1x1 tail: the fp32 activation goes straight into the 48->1 dot product
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) dot += v[e] * tw[grp][e];
+                            continue;
+                        }
                         const long long oo = opix + cbase + grp * 8;
                         if (a.res) {
                             const half4_t rv = *(const half4_t*)(a.res + oo);
@@ -275,6 +286,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
                             for (int e = 0; e < 4; ++e) lv[e] = (half_t)((v[e] - (float)hv[e]) * 2048.f);
                             *(half4_t*)(a.out_lo + oo) = lv;
                         }
+                    }
+                    if (a.tail1_out) {           // lanes (j, 0) and (j, 1) hold the two 16-channel parts of this wave's 32 channels
+                        dot += __shfl_xor(dot, 32);
+                        if (hh == 0) a.tail1_out[(long long)wn * a.B * Ho * Wo + (long long)(b * Ho + y * r + si) * Wo + (x * r + sj)] = dot;
                     }
                 }
             }

@@ -400,6 +400,12 @@ static int build_device_weights(moe_net& n, int precision)
             }
         tail("tail_r", "convt_R1.weight");
         tail("tail_u", "convt_I1.weight");
+        for (const char* kv : {"tail_r", "tail_u"}) {     // fp32 copies for the fused 1x1 tail (conv_mfma_kernel, tail1_w)
+            const Param& W = *n.get(std::string(kv) == "tail_r" ? "convt_R1.weight" : "convt_I1.weight");
+            std::vector<float> t(64, 0.f);
+            for (int c = 0; c < (int)W.shape[1]; ++c) t[c] = W.data[c];
+            f32table(std::string(kv) + ".f32", t);
+        }
     }
 
     if (n.blob) { (void)hipFree(n.blob); n.blob = nullptr; }
@@ -456,7 +462,8 @@ struct Fwd {
     // one convolution layer: in [B][H][W][64*nseg] -> out [B][H*r][W*r][r>1 ? 64 : 64*nchunks]
     // returns false only when asked for the fused tail (tplanes != nullptr) and the fused kernel cannot take the layer
     bool conv(const std::string& key, const Act& in, const Act& out, const Act* res, int H, int W, const half_t* plane_w = nullptr,
-              const half_t* plane_w_lo = nullptr, const half_t* tail_w = nullptr, float* tplanes = nullptr)
+              const half_t* plane_w_lo = nullptr, const half_t* tail_w = nullptr, float* tplanes = nullptr,
+              const float* tail1_w = nullptr, float* tail1_out = nullptr)
     {
         if (dry()) return true;
         const ConvLayer& L = n.convs[n.conv_index.at(key)];
@@ -497,6 +504,7 @@ struct Fwd {
         static const int dbg = [] { const char* e = getenv("MOE_DBG"); return e ? atoi(e) : 0; }();
         a.dbg = dbg;
         a.tail_w = tail_w; a.tplanes = tplanes;
+        a.tail1_w = tail1_w; a.tail1_out = tail1_out;
         // MOE_CONV_IMPL = sp (default: software-pipelined epilogue) | pp (two-group ping-pong) | v1 (generic kernel)
         const int impl = conv_impl();
         const bool pp = L.taps == 9 && L.nseg == 1 && !L.per_plane && impl != 0;
@@ -738,17 +746,38 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         }
         Act fin[2];
         int H = h, W = w;
+        // The last upsampler stage and the 48->1 tail conv run as one kernel (the 64-channel HR tensor, 128 B per HR pixel written
+        // and read back per branch, never exists): the conv's epilogue dots its fp32 activations with the tail weights.
+        static const bool nofuse1 = [] { const char* e = getenv("MOE_FUSE_TAIL"); return e && !strcmp(e, "0"); }();
+        const bool fuse1 = !nofuse1 && !f.direct && !n.debug && n.stages >= 1;
+        float* part[2] = {nullptr, nullptr};
         for (int br = 0; br < 2; ++br) {
             Act cur = br == 0 ? Bb : A;
             H = h; W = w;
             for (int st = 0; st < n.stages; ++st) {
+                const std::string ckey = std::string(br == 0 ? "ures" : "uim") + ".up" + std::to_string(st);
+                if (fuse1 && st == n.stages - 1) {
+                    part[br] = (float*)f.ar.take((size_t)2 * B * H * 2 * W * 2 * 4);
+                    f.conv(ckey, cur, Act{}, nullptr, H, W, nullptr, nullptr, nullptr, nullptr,
+                           f.dry() ? nullptr : f.small<float>(br == 0 ? "tail_r.f32" : "tail_u.f32"), f.dry() ? (float*)16 : part[br]);
+                    H *= 2; W *= 2;
+                    continue;
+                }
                 Act nxt = f.act((long long)B * H * 2 * W * 2);
-                f.conv(std::string(br == 0 ? "ures" : "uim") + ".up" + std::to_string(st), cur, nxt, nullptr, H, W);
+                f.conv(ckey, cur, nxt, nullptr, H, W);
                 H *= 2; W *= 2;
                 f.tap(std::string(br == 0 ? "r" : "u") + ".up" + std::to_string(st), nxt, H, W, 64, 48);
                 cur = nxt;
             }
             fin[br] = cur;
+        }
+        if (fuse1) {
+            if (!f.dry()) {
+                Tail1SumArgs t{};
+                t.p0 = part[0]; t.p1 = part[1]; t.y = y; t.y_dtype = y_dtype; t.y_off = y_off_dev; t.B = B; t.H = H; t.W = W;
+                launch_tail1sum(t, s);
+            }
+            return MOE_OK;
         }
         tail(&fin[0], &fin[1], H, W, false);
     }

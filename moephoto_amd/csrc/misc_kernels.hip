@@ -263,6 +263,21 @@ __global__ __launch_bounds__(256) void tapsum2_kernel(TapSumArgs a)
     }
 }
 
+// Fused 1x1 tail (lite): y = sum of the four partial planes (two branches x two 32-channel halves), fixed order.
+__global__ __launch_bounds__(256) void tail1sum_kernel(Tail1SumArgs a)
+{
+    const long long hw = (long long)a.H * a.W, plane = (long long)a.B * hw;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= plane) return;
+    const int b = (int)(idx / hw);
+    const long long p = idx - (long long)b * hw;
+    float v = a.p0[idx] + a.p0[plane + idx];
+    if (a.p1) v += a.p1[idx] + a.p1[plane + idx];
+    const long long yo = (a.y_off ? a.y_off[b] : (long long)b * hw) + p;
+    if (a.y_dtype == MOE_F16) ((half_t*)a.y)[yo] = (half_t)v;
+    else ((float*)a.y)[yo] = v;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Global average pool partial sums (AdaptiveAvgPool2d(1): models.py:190,274): in [B][HW][C] -> [B][nslab][C].
 // Deterministic two-stage reduction (the second stage lives in the gate kernels).
@@ -571,6 +586,12 @@ void launch_tapsum(const TapSumArgs& a, hipStream_t s)
         const long long n = (long long)a.B * a.H * (a.W / 8);
         tapsum2_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(a);
     } else tapsum_kernel<2><<<grid, dim3(256), 0, s>>>(a);
+}
+
+void launch_tail1sum(const Tail1SumArgs& a, hipStream_t s)
+{
+    const long long n = (long long)a.B * a.H * a.W;
+    hipLaunchKernelGGL(tail1sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
 }
 
 void launch_pool_partial(const half_t* in, const half_t* in_lo, float* partial, int B, long long HW, int C, int nslab, hipStream_t s)
