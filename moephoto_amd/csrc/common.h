@@ -32,6 +32,7 @@ struct ConvArgs {
     // FP16X3 (hi/lo split operands): partial products are combined through an fp32 side buffer
     half_t* out_lo;       // low part of the output activation ((v - hi) * 2^11), or nullptr
     const half_t* in_lo;  // acc_mode 4 only: low part of the input activation (same layout as `in`)
+    const half_t* side16; // acc_mode 3 (conv3x3_pp): the two low-order products, already summed, as fp16 in the OUTPUT layout (replaces acc32)
     // conv_mfma_kernel only: fused 1x1 tail (lite's last upsampler stage + its 48->1 conv).  The activated tile is not stored: each
     // lane dots its 16 channels with tail1_w, the two 32-channel halves of the chunk go to two fp32 partial planes [2][B][Ho][Wo]
     const float* tail1_w;  // [64] fp32 in output-channel order of the chunk, or nullptr

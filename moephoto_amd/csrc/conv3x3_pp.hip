@@ -211,7 +211,25 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(ConvArgs a)
             const int cout0 = (r > 1) ? 0 : chunk * kCB;                   // first output channel of this chunk in `out`
             const int Wo = a.W * r, Ho = a.H * r;
             const int yb = it.pyi * kTileH + w4 * 2, x = it.pxi * kTileW + j;
-            if (MODE == 1 || MODE == 2 || MODE == 3) {
+            if (MODE == 3 && a.side16) {
+                // the low-order products were formed by two fp16-output launches of conv3x3_sp (sum in `side16`, output layout,
+                // scaled by 2^11): fp16 is plenty for a term that is 2^-11 of the result
+#pragma unroll
+                for (int o = 0; o < 2; ++o) {
+                    const int y = yb + o;
+                    if (y < a.H && x < a.W) {
+                        const long long spix = ((long long)(it.b * Ho + y * r + si) * Wo + (x * r + sj)) * a.out_cs + cout0 + hh * 4;
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                            for (int g4 = 0; g4 < 4; ++g4) {
+                                const half4_t sv = *(const half4_t*)(a.side16 + spix + nb * 32 + g4 * 8);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[o][nb][g4 * 4 + e] += (float)sv[e] * 0.00048828125f;
+                            }
+                    }
+                }
+            } else if (MODE == 1 || MODE == 2 || MODE == 3) {
                 // split-precision passes: fp32 partial sums through acc32 (accumulator layout, 16-B accesses)
 #pragma unroll
                 for (int o = 0; o < 2; ++o) {

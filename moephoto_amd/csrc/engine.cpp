@@ -337,6 +337,7 @@ static int build_device_weights(moe_net& n, int precision)
     n.small["zero"] = bb.take(1024);
     n.small["trash"] = bb.take(4096);
     n.small["zero_bias"] = bb.take(1024 * 4);      // up to 16 chunks of 64 fp32 zeros
+    n.small["zero_bias_img"] = bb.take(16 * 256 * 4);   // the same as 1-KiB-per-chunk images (conv3x3_sp)
 
     if (n.arch == MOE_ARCH_NET2X || n.arch == MOE_ARCH_NET3X || n.arch == MOE_ARCH_NET4X || n.arch == MOE_ARCH_NETDN) {
         stem("conv_input.weight");
@@ -435,6 +436,7 @@ struct Fwd {
     bool y_vec = false;
     float* acc32 = nullptr;
     size_t acc32_elems = 0;
+    half_t* side16 = nullptr;    // fp16 sum of the two low-order products of a 3x3 conv (split precision), output layout
     bool dry() const { return ar.base == nullptr; }
 
     Act act(long long pixels, int ch = 64)
@@ -556,6 +558,22 @@ struct Fwd {
             launch_conv_mfma(f4, 1, 3, s);
             return true;
         }
+        static const bool sp_low = [] { const char* e = getenv("MOE_X3_SP"); return !(e && !strcmp(e, "0")); }();
+        if (pp && impl == 2 && sp_low && L.nchunks <= 16) {
+            // 3x3 conv: the two low-order products run on the fast kernel as ordinary fp16-output convolutions --
+            //   side = conv(w_lo, a_hi)            (plain epilogue)
+            //   side = conv(w_hi, a_lo) + side     (residual epilogue, in place)
+            // both in units of 2^-11; the main pass adds side * 2^-11 before its epilogue.  fp16 is plenty for a term that small,
+            // and nothing goes through the fp32 side buffer (its read-modify-write traffic bounded the three-pass form).
+            ConvArgs q1 = a; q1.wpk = blob<half_t>(L.w_lo); q1.out = side16; q1.res = nullptr; q1.bias = small<float>("zero_bias");
+            q1.bias_img = small<float>("zero_bias_img"); q1.slope = 1.f; q1.scale = 1.f; q1.acc_mode = 0; q1.tail_w = nullptr; q1.tplanes = nullptr;
+            ConvArgs q2 = q1; q2.in = in.lo; q2.wpk = blob<half_t>(L.w_hi); q2.res = side16;
+            if (launch_conv3x3_sp(q1, s) && launch_conv3x3_sp(q2, s)) {
+                ConvArgs q3 = a; q3.acc_mode = 3; q3.side16 = side16; q3.out_lo = out.lo; q3.res_lo = res ? res->lo : nullptr;
+                launch_conv3x3_pp(q3, s);
+                return true;
+            }
+        }
         // hi/lo split: (w_lo * a_hi) -> acc32,  += (w_hi * a_lo),  then (w_hi * a_hi) + acc32/2048 and the epilogue
         a.acc32 = acc32;
         ConvArgs p1 = a; p1.wpk = L.per_plane ? plane_w_lo : blob<half_t>(L.w_lo); p1.acc_mode = 1; p1.res = nullptr; p1.bias = nullptr;
@@ -605,7 +623,11 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
     const int B = f.B, h = f.h, w = f.w;
     const long long P = (long long)B * h * w;
     hipStream_t s = f.s;
-    if (f.x3) { f.acc32_elems = acc32_need(n, B, h, w); f.acc32 = (float*)f.ar.take(f.acc32_elems * 4); }
+    if (f.x3) {
+        f.acc32_elems = acc32_need(n, B, h, w);
+        f.acc32 = (float*)f.ar.take(f.acc32_elems * 4);
+        f.side16 = (half_t*)f.ar.take(f.acc32_elems * 2 + 4096);
+    }
 
     auto stem = [&](const Act& out) {
         if (f.dry()) return;
