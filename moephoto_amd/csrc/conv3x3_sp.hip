@@ -196,7 +196,9 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
 
     // One eighth (index s8 = (o, nb, gp)) of the epilogue of a finished tile held in `ac`.  Branch-free: lanes outside the
     // image (or a disabled slice) store to a trash line and read their residual from the zero page.
-    constexpr bool ACT = (EPI == 1) || (EPI == 3), RES = (EPI == 2), TAIL = (EPI == 3);
+    //   4  split-precision FINAL pass: + side16 * 2^-11 (the two low-order products), PReLU in fp32, hi AND lo outputs
+    //   5  the same with the residual add (its low part was folded into side16 by the engine)
+    constexpr bool ACT = (EPI == 1) || (EPI == 3), RES = (EPI == 2) || (EPI == 5), TAIL = (EPI == 3), X3 = (EPI == 4) || (EPI == 5);
     constexpr int DRAIN0 = 0;      // first of the eight k-steps that carry a slice of the previous tile's epilogue
     unsigned slope2;               // {slope, slope} as packed halves
     {
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         const bool oky = (t.y0 + o < a.H) & live;
         return (t.okx & oky) ? lane_ob + srow * 2u : trash_ob;
     };
-    auto drain_slice = [&](float16_t (&ac)[2][2], const Item& it, const TileOut& to, int s8, bool live, const uint4* resw = nullptr) {
+    auto drain_slice = [&](float16_t (&ac)[2][2], const Item& it, const TileOut& to, int s8, bool live, const uint4* resw = nullptr, const uint4* sidew = nullptr) {
         const int o = s8 >> 2, nb = (s8 >> 1) & 1, gp = s8 & 1;
         const int y = it.pyi * kTileH + w4 * 2 + o, x = it.pxi * kTileW + j;
         const bool ok = (y < a.H) & (x < a.W) & live;
@@ -253,11 +255,27 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
             for (int e = 0; e < 8; ++e) asm volatile("" ::"v"(v[e]));
             return;
         }
+        if (X3) {                  // low-order products, fetched like a residual (16 bytes per lane in the store layout), in units of 2^-11
+            const uint4 w = sidew[s8];
+            const auto qx = __builtin_amdgcn_permlane32_swap(w.x, w.z, false, false);
+            const auto qy = __builtin_amdgcn_permlane32_swap(w.y, w.w, false, false);
+            const half4_t q0 = __builtin_bit_cast(half4_t, make_uint2(qx[0], qy[0]));
+            const half4_t q1 = __builtin_bit_cast(half4_t, make_uint2(qx[1], qy[1]));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += (float)q0[e] * 0.00048828125f; v[4 + e] += (float)q1[e] * 0.00048828125f; }
+            if (EPI == 4) {        // PReLU / plain (slope == 1) in fp32: the low output part needs the unrounded value
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float t = v[e] * a.slope;
+                    asm("v_max_f32 %0, %1, %2" : "=v"(v[e]) : "v"(v[e]), "v"(t));
+                }
+            }
+        }
         // fp16 first, PReLU on the packed halves: slope <= 1 (negative slopes included) => PReLU(x) = max(x, slope*x); two
         // v_pk_* per register pair instead of v_mul_f32 + v_max_f32 per value (-64 VALU per tile).  The negative branch is rounded
         // three times instead of once; on the goldens the end-to-end error is unchanged (a2 7.0e-4 -> 6.6e-4, a4 5.3e-4 -> 5.5e-4).
         unsigned hv[4];            // the eight values as four half2 registers (v[2k], v[2k+1])
-        if (!RES) {
+        if (!RES && !X3) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
@@ -334,11 +352,20 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         }
         // fp16, then one v_permlane32_swap per register: lane (j,0) gets channels 16*gp .. +7, lane (j,1) 16*gp+8 .. +15
         uint2 u0, u1;
-        if (RES) {
+        if (RES || X3) {
             half4_t h0, h1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { h0[e] = (half_t)v[e]; h1[e] = (half_t)v[4 + e]; }
             u0 = __builtin_bit_cast(uint2, h0); u1 = __builtin_bit_cast(uint2, h1);
+            if (X3) {              // low part of the output: (v - hi) * 2^11, same layout, second store
+                half4_t l0, l1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { l0[e] = (half_t)((v[e] - (float)h0[e]) * 2048.f); l1[e] = (half_t)((v[4 + e] - (float)h1[e]) * 2048.f); }
+                const uint2 m0 = __builtin_bit_cast(uint2, l0), m1 = __builtin_bit_cast(uint2, l1);
+                const auto lx = __builtin_amdgcn_permlane32_swap(m0.x, m1.x, false, false);
+                const auto ly = __builtin_amdgcn_permlane32_swap(m0.y, m1.y, false, false);
+                *(uint4*)((char*)a.out_lo + out_off(to, o, nb, gp, live)) = make_uint4(lx[0], ly[0], lx[1], ly[1]);
+            }
         } else {
             u0 = make_uint2(hv[0], hv[1]); u1 = make_uint2(hv[2], hv[3]);
         }
@@ -375,6 +402,14 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         asm volatile("" : "+v"(off));        // keep the select: the compiler otherwise turns it into two predicated loads behind branches
         resw[s8] = *(const uint4*)((const char*)a.res + off);
     };
+    uint4 sidew[8];                // split-precision final pass: the low-order addend of the tile being multiplied, fetched like the residual
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) sidew[s8] = make_uint4(0, 0, 0, 0);
+    auto fetch_side = [&](const TileOut& to, int s8) {
+        unsigned off = out_off(to, s8 >> 2, (s8 >> 1) & 1, s8 & 1, true);
+        asm volatile("" : "+v"(off));
+        sidew[s8] = *(const uint4*)((const char*)a.side16 + off);
+    };
     Item it_cur = decode(g, a.px, a.py), it_prev = it_cur, it_next = advance(it_cur);
     // iteration p (0 <= p < K): multiply patch p (buffer p&1) into `cur`; drain patch p-1 from `prev` (stores predicated
     // off for p == 0); fetch patch p+1 (source predicated to the zero page for the last one).  No branches inside: the
@@ -392,6 +427,10 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         if (RES) {   // pin the compiler's wait for the residual registers here, before this iteration issues any memory operation
 #pragma unroll
             for (int s8 = 0; s8 < 8; ++s8) asm volatile("" : "+v"(resw[s8].x), "+v"(resw[s8].y), "+v"(resw[s8].z), "+v"(resw[s8].w));
+        }
+        if (X3) {
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) asm volatile("" : "+v"(sidew[s8].x), "+v"(sidew[s8].y), "+v"(sidew[s8].z), "+v"(sidew[s8].w));
         }
 // the ten reads of a k-step in the order its MFMAs consume them (input row pr, then the weights of the tap row it meets first):
 // LDS returns in order, so the first MFMAs of the step wait for two reads instead of seven
@@ -447,8 +486,9 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
                             cur[o][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cb][dy][nb], af[cb][pr], (s == 0 && dy == 0) ? biasv[nb] : cur[o][nb], 0, 0, 0);
                     }
                 }
-            if (!(MOE_ABL & 2) && s >= DRAIN0 && s < DRAIN0 + 8) drain_slice(prev, itp, top, s - DRAIN0, drain, resw);
+            if (!(MOE_ABL & 2) && s >= DRAIN0 && s < DRAIN0 + 8) drain_slice(prev, itp, top, s - DRAIN0, drain, resw, sidew);
             if (RES && s >= DRAIN0 + 1 && s <= DRAIN0 + 8) fetch_res(toc, s - DRAIN0 - 1);   // slice s-1's registers were consumed in the previous step
+            if (X3 && s >= DRAIN0 + 1 && s <= DRAIN0 + 8) fetch_side(toc, s - DRAIN0 - 1);
 #ifdef MOE_STEP_STAMPS
             MOE_STAMP(4 + s)
 #endif
@@ -479,6 +519,8 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
                 else __builtin_amdgcn_sched_group_barrier(0x002, SGB_VALU_B, 0);
                 if ((i == SGB_DMA_AT || i == SGB_DMA_AT + 1) && s <= 5) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 if (RES && i == SGB_DMA_AT + 2 && s >= DRAIN0 + 1 && s <= DRAIN0 + 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if (X3 && i == SGB_DMA_AT + 3 && s >= DRAIN0 + 1 && s <= DRAIN0 + 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if (X3 && i == SGB_ST_AT + 1 && s >= DRAIN0 && s < DRAIN0 + 8) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
                 if (i == SGB_ST_AT && s >= DRAIN0 && s < DRAIN0 + 8) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
             }
             // the fused tail adds a 13th MFMA to k-steps 0..7: without a slot of its own it takes the next step's first MFMA slot
@@ -526,10 +568,10 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         // (its residual was fetched in steps 8..11 of the last iteration)
         if (K & 1) {
 #pragma unroll
-            for (int s8 = 0; s8 < 8; ++s8) drain_slice(accA, itp, top, s8, live, resw);
+            for (int s8 = 0; s8 < 8; ++s8) drain_slice(accA, itp, top, s8, live, resw, sidew);
         } else {
 #pragma unroll
-            for (int s8 = 0; s8 < 8; ++s8) drain_slice(accB, itp, top, s8, live, resw);
+            for (int s8 = 0; s8 < 8; ++s8) drain_slice(accB, itp, top, s8, live, resw, sidew);
         }
     }
     {   // trace: end of the workgroup's work (slot 13 of iteration 0; slot 14 there is its start)
@@ -554,25 +596,31 @@ hipError_t conv3x3_sp_init()
     if ((e = set_limit<1>()) != hipSuccess) return e;
     if ((e = set_limit<2>()) != hipSuccess) return e;
     if ((e = set_limit<3>()) != hipSuccess) return e;
+    if ((e = set_limit<4>()) != hipSuccess) return e;
+    if ((e = set_limit<5>()) != hipSuccess) return e;
     return hipSuccess;
 }
 
 // Returns false when the layer's epilogue is not one of the four compiled variants (caller uses another kernel).
 bool launch_conv3x3_sp(const ConvArgs& a, hipStream_t s)
 {
-    if ((a.acc_mode != 0 && !(a.dbg & 64)) || a.slope > 1.f) return false;
+    const bool x3 = a.acc_mode == 3 && a.side16 && a.out_lo;          // split-precision final pass (the low-order products are in side16)
+    if ((a.acc_mode != 0 && !x3 && !(a.dbg & 64)) || a.slope > 1.f) return false;
     if (2ll * a.B * a.H * a.r * a.W * a.r * a.out_cs >= (1ll << 32) - 8192) return false;   // 32-bit BYTE offsets for stores / residual loads
     if (a.scale != 1.f || !a.bias_img) return false;           // the engine folds ScaleLayer into the weights and always passes a bias vector
     const bool act = a.slope != 1.f, res = a.res != nullptr, tail = a.tplanes != nullptr;
     if ((act || tail) && res) return false;
+    if (x3 && (tail || a.res_lo)) return false;                        // (the engine folds res_lo into side16)
     if (tail && 36ll * a.B * a.H * a.r * a.W * a.r >= (1ll << 32) - 8192) return false;
-    const int epi = tail ? 3 : (res ? 2 : (act ? 1 : 0));
+    const int epi = x3 ? (res ? 5 : 4) : tail ? 3 : (res ? 2 : (act ? 1 : 0));
     const int blocks = a.nchunks * ((a.G + 7) / 8) * 8;
     const dim3 grid(blocks), blk(256);
     switch (epi) {
         case 0: conv3x3_sp_kernel<0><<<grid, blk, LDS_BYTES, s>>>(a); break;
         case 1: conv3x3_sp_kernel<1><<<grid, blk, LDS_BYTES, s>>>(a); break;
         case 3: conv3x3_sp_kernel<3><<<grid, blk, LDS_BYTES, s>>>(a); break;
+        case 4: conv3x3_sp_kernel<4><<<grid, blk, LDS_BYTES, s>>>(a); break;
+        case 5: conv3x3_sp_kernel<5><<<grid, blk, LDS_BYTES, s>>>(a); break;
         default: conv3x3_sp_kernel<2><<<grid, blk, LDS_BYTES, s>>>(a); break;
     }
     return true;

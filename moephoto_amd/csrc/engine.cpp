@@ -565,12 +565,13 @@ struct Fwd {
             //   side = conv(w_hi, a_lo) + side     (residual epilogue, in place)
             // both in units of 2^-11; the main pass adds side * 2^-11 before its epilogue.  fp16 is plenty for a term that small,
             // and nothing goes through the fp32 side buffer (its read-modify-write traffic bounded the three-pass form).
-            ConvArgs q1 = a; q1.wpk = blob<half_t>(L.w_lo); q1.out = side16; q1.res = nullptr; q1.bias = small<float>("zero_bias");
+            // (a residual's low part is in the same units: it rides along as the `residual` of the first low-order launch)
+            ConvArgs q1 = a; q1.wpk = blob<half_t>(L.w_lo); q1.out = side16; q1.res = (res && res->lo) ? res->lo : nullptr; q1.bias = small<float>("zero_bias");
             q1.bias_img = small<float>("zero_bias_img"); q1.slope = 1.f; q1.scale = 1.f; q1.acc_mode = 0; q1.tail_w = nullptr; q1.tplanes = nullptr;
             ConvArgs q2 = q1; q2.in = in.lo; q2.wpk = blob<half_t>(L.w_hi); q2.res = side16;
             if (launch_conv3x3_sp(q1, s) && launch_conv3x3_sp(q2, s)) {
-                ConvArgs q3 = a; q3.acc_mode = 3; q3.side16 = side16; q3.out_lo = out.lo; q3.res_lo = res ? res->lo : nullptr;
-                launch_conv3x3_pp(q3, s);
+                ConvArgs q3 = a; q3.acc_mode = 3; q3.side16 = side16; q3.out_lo = out.lo; q3.res_lo = nullptr;   // res_lo is inside side16
+                if (!launch_conv3x3_sp(q3, s)) launch_conv3x3_pp(q3, s);
                 return true;
             }
         }
