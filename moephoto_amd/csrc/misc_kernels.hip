@@ -2,6 +2,8 @@
 // squeeze-excite pooling / gates, tile stitch, and the uint8/uint16 <-> float image edges.
 // All of them stream NHWC fp16 activations with 16-byte accesses (8 lanes = one 128-B pixel line).
 #include "common.h"
+#include <cstdlib>
+#include <cstring>
 #include "../../include/moephoto_amd.h"
 
 namespace {
@@ -174,6 +176,83 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a)
             else ((float*)a.y)[yo] = v;
         }
     }
+}
+
+// 3x3 tail, second form: every 16 bytes of the input are loaded ONCE.  Block = 32 columns (30 outputs + 1 halo column per side) x 8
+// output rows; thread (column c, channel group cg) walks the 10 rows of its own column and accumulates, per output row, the three
+// per-dx partial sums S[dx] of its column (they belong to the outputs at columns c+1, c, c-1 for dx = 0, 1, 2).  The partials go through LDS once:
+// thread (c, o = cg) then adds S0[c-1] + S1[c] + S2[c+1] over the eight channel groups and stores one pixel.
+// (The first form loads every element three times -- once per dx -- and ran at 1.3-2 TB/s.)
+__global__ __launch_bounds__(256) void tail3_kernel(TailArgs a)
+{
+    __shared__ float part[3][8][32][9];          // [dx][output row][column][channel group], padded: 27.6 KB
+    const int cgi = threadIdx.x & 7, pc = threadIdx.x >> 3;
+    const int nbx = (a.W + 29) / 30, nby = (a.H + 7) / 8;
+    int blk = blockIdx.x;
+    const int bx = blk % nbx; blk /= nbx;
+    const int by = blk % nby;
+    const int b = blk / nby;
+    const int x = bx * 30 - 1 + pc, y0 = by * 8;
+    const bool xin = x >= 0 && x < a.W;
+    float S[3][8];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int o = 0; o < 8; ++o) S[dx][o] = 0.f;
+#pragma unroll 1
+    for (int which = 0; which < 2; ++which) {
+        const half_t* in = which ? a.in1 : a.in0;
+        if (!in) continue;
+        const half_t* wsrc = (which ? a.w1 : a.w0) + cgi * 8;
+        const half_t* wlo_src = (which ? a.w1_lo : a.w0_lo);
+        const half_t* in_lo = which ? a.in1_lo : a.in0_lo;
+        half8_t w[9], wl[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            w[t] = *(const half8_t*)(wsrc + t * 64);
+            wl[t] = in_lo ? *(const half8_t*)(wlo_src + cgi * 8 + t * 64) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const int yy = y0 + r - 1;
+            const bool ok = xin && yy >= 0 && yy < a.H;
+            const long long off = ((long long)(b * a.H + yy) * a.W + x) * 64 + cgi * 8;
+            half8_t v = {0, 0, 0, 0, 0, 0, 0, 0}, vl = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (ok) v = *(const half8_t*)(in + off);
+            if (ok && in_lo) vl = *(const half8_t*)(in_lo + off);
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int o = r - dy;
+                if (o < 0 || o >= 8) continue;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    S[dx][o] = dot8(v, w[dy * 3 + dx], S[dx][o]);
+                    if (in_lo) {   // FP16X3: (a_hi + a_lo/2048) * (w_hi + w_lo/2048), cross terms kept
+                        float c = dot8(vl, w[dy * 3 + dx], 0.f);
+                        c = dot8(v, wl[dy * 3 + dx], c);
+                        S[dx][o] += c * 0.00048828125f;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int o = 0; o < 8; ++o) part[dx][o][pc][cgi] = S[dx][o];
+    __syncthreads();
+    const int o = cgi, y = y0 + o;               // second role of the thread: output pixel (column pc, row o)
+    if (pc < 1 || pc > 30 || x >= a.W || y >= a.H) return;
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) v += part[0][o][pc - 1][g] + part[1][o][pc][g] + part[2][o][pc + 1][g];   // input column = output column + dx - 1
+    if (a.skip) {
+        const long long so = (a.skip_off ? a.skip_off[b] : (long long)b * a.skip_sB) + y * a.skip_sH + x * a.skip_sW;
+        v += (a.skip_dtype == MOE_F16) ? ld1<half_t>(a.skip, so) : ld1<float>(a.skip, so);
+    }
+    const long long yo = (a.y_off ? a.y_off[b] : (long long)b * a.H * a.W) + (long long)y * a.W + x;
+    if (a.y_dtype == MOE_F16) ((half_t*)a.y)[yo] = (half_t)v;
+    else ((float*)a.y)[yo] = v;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -573,8 +652,10 @@ void launch_stem(const StemArgs& a, hipStream_t s)
 
 void launch_tail(const TailArgs& a, hipStream_t s)
 {
+    static const bool old9 = [] { const char* e = getenv("MOE_TAIL_V1"); return e && !strcmp(e, "1"); }();
     const int blocks = ((a.W + 31) / 32) * ((a.H + 7) / 8) * a.B;
-    if (a.taps == 9) hipLaunchKernelGGL((tail_kernel<9>), dim3(blocks), dim3(256), 0, s, a);
+    if (a.taps == 9 && !old9) hipLaunchKernelGGL(tail3_kernel, dim3(((a.W + 29) / 30) * ((a.H + 7) / 8) * a.B), dim3(256), 0, s, a);
+    else if (a.taps == 9) hipLaunchKernelGGL((tail_kernel<9>), dim3(blocks), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((tail_kernel<1>), dim3(blocks), dim3(256), 0, s, a);
 }
 
