@@ -32,6 +32,7 @@ struct ConvArgs {
     // FP16X3 (hi/lo split operands): partial products are combined through an fp32 side buffer
     half_t* out_lo;       // low part of the output activation ((v - hi) * 2^11), or nullptr
     const half_t* in_lo;  // acc_mode 4 only: low part of the input activation (same layout as `in`)
+    int plane_w;          // conv3x3_sp only: wpk holds one weight set per PLANE ([B][72 fragments], nchunks = B), 64 output channels
     const half_t* side16; // acc_mode 3 (conv3x3_pp): the two low-order products, already summed, as fp16 in the OUTPUT layout (replaces acc32)
     // conv_mfma_kernel only: fused 1x1 tail (lite's last upsampler stage + its 48->1 conv).  The activated tile is not stored: each
     // lane dots its 16 channels with tail1_w, the two 32-channel halves of the chunk go to two fp32 partial planes [2][B][Ho][Wo]
@@ -136,6 +137,21 @@ struct SednSeArgs {   // _Conv_Block squeeze-excite (models.py:198-213) + per-pl
     int B, nfrag;
 };
 void launch_sedn_se(const SednSeArgs& a, hipStream_t s);
+
+// SEDN fused block tail: trans(g * conv256(x)) == conv(W_t diag(g) W_256, x) -- one 3x3 64->64 conv with per-plane weights.
+struct SednFuseArgs {
+    const half_t* x;          // [B][H][W][64] input of rblock.4
+    float* partial;           // [B][nslab][5][64]: total, first row, last row, first column, last column sums
+    int nslab, B, H, W;
+    const float* w256t;       // [576][256] fp32, k = tap*64 + ci   (rblock.4 weights, transposed)
+    const float* w256;        // [256][576]
+    const float* wt;          // [64][256]  trans weights
+    const float* w_down;      // [16][256]
+    const float* w_up;        // [256][16]
+    float* gate;              // [B][256]
+    half_t* weff;             // [B][72 fragments][64 lanes][8] packed A fragments of the fused conv
+};
+void launch_sedn_fuse(const SednFuseArgs& a, hipStream_t s);
 
 struct FrmArgs {     // FRM gate (models.py:270-287) then out = t*gate + x   (MoeNet_lite2.py:16-20)
     const float* partial; int nslab; long long HW;

@@ -86,11 +86,15 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
     const int w4 = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0..3
     const int j = lane & 31, hh = lane >> 5;
 
+    // EPI 6 (SEDN's fused block tail): the `nchunks` weight sets are PER PLANE, not per output chunk -- workgroups of "chunk" b take
+    // only the patches of plane b and all write the same 64 output channels
+    constexpr bool PLANEW = (EPI == 6);
     const int bid = blockIdx.x;
     const int chunk = (bid >> 3) % a.nchunks;
     const int g = (bid & 7) + 8 * (bid / (8 * a.nchunks));
     if (g >= a.G) return;
-    const int nitems = a.B * a.py * a.px;
+    const int nitems = (PLANEW ? 1 : a.B) * a.py * a.px;
+    const int bofs = PLANEW ? chunk : 0;                          // plane offset of this workgroup's items
     const int K = (nitems - g + a.G - 1) / a.G;                  // this workgroup's items: g, g+G, ...
     if (K <= 0) return;
 
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
     auto patch_src = [&](const Item& it) {
         PatchSrc ps;
         ps.y0 = it.pyi * kTileH - 1; ps.x0 = it.pxi * kTileW - 1;
-        ps.base = a.in + ((long long)(it.b * a.H + ps.y0) * a.W + ps.x0) * a.in_cs;
+        ps.base = a.in + ((long long)((it.b + bofs) * a.H + ps.y0) * a.W + ps.x0) * a.in_cs;
         return ps;
     };
     auto issue_piece = [&](const PatchSrc& ps, int i, char* dstbuf, bool live = true) {
@@ -168,14 +172,14 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
 
     const int r = a.r;
     const int si = (r > 1) ? chunk / r : 0, sj = (r > 1) ? chunk % r : 0;
-    const int cout0 = (r > 1) ? 0 : chunk * kCB;                   // first output channel of this chunk in `out`
+    const int cout0 = (r > 1 || PLANEW) ? 0 : chunk * kCB;         // first output channel of this chunk in `out`
     const int Wo = a.W * r, Ho = a.H * r;
 
     // The bias (an all-zero image when the layer has none) is the C operand of the FIRST MFMA of every accumulator in an
     // iteration, so accumulators are never reset: lane (j, hh) register e of tile [o][nb] is channel nb*32 + 8*(e>>2) + 4*hh + (e&3)
     float16_t biasv[2];
     {
-        const float* bsrc = a.bias_img + chunk * 256 + hh * 4;
+        const float* bsrc = a.bias_img + (PLANEW ? 0 : chunk * 256) + hh * 4;
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -198,7 +202,8 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
     // image (or a disabled slice) store to a trash line and read their residual from the zero page.
     //   4  split-precision FINAL pass: + side16 * 2^-11 (the two low-order products), PReLU in fp32, hi AND lo outputs
     //   5  the same with the residual add (its low part was folded into side16 by the engine)
-    constexpr bool ACT = (EPI == 1) || (EPI == 3), RES = (EPI == 2) || (EPI == 5), TAIL = (EPI == 3), X3 = (EPI == 4) || (EPI == 5);
+    //   6  LeakyReLU/PReLU in fp32, THEN the residual add; per-plane weights (see PLANEW above)
+    constexpr bool ACT = (EPI == 1) || (EPI == 3), RES = (EPI == 2) || (EPI == 5) || (EPI == 6), TAIL = (EPI == 3), X3 = (EPI == 4) || (EPI == 5);
     constexpr int DRAIN0 = 0;      // first of the eight k-steps that carry a slice of the previous tile's epilogue
     unsigned slope2;               // {slope, slope} as packed halves
     {
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
     auto tile_out = [&](const Item& it) {
         TileOut t;
         t.y0 = it.pyi * kTileH + w4 * 2;
-        t.s00 = ((unsigned)(it.b * Ho + t.y0 * r + si) * (unsigned)Wo + (unsigned)(it.pxi * kTileW * r + sj)) * (unsigned)a.out_cs + (unsigned)cout0;
+        t.s00 = ((unsigned)((it.b + bofs) * Ho + t.y0 * r + si) * (unsigned)Wo + (unsigned)(it.pxi * kTileW * r + sj)) * (unsigned)a.out_cs + (unsigned)cout0;
         t.okx = it.pxi * kTileW + j < a.W;
         return t;
     };
@@ -338,6 +343,13 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
                 for (int e = 0; e < 16; ++e) Gacc[o][e] = 0.f;
             }
             return;
+        }
+        if (EPI == 6) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t = v[e] * a.slope;
+                asm("v_max_f32 %0, %1, %2" : "=v"(v[e]) : "v"(v[e]), "v"(t));
+            }
         }
         if (RES) {
             // the residual was fetched as one 16-byte access per lane in the STORE layout (lane (j,0): channels 16*gp..+7,
@@ -598,6 +610,7 @@ hipError_t conv3x3_sp_init()
     if ((e = set_limit<3>()) != hipSuccess) return e;
     if ((e = set_limit<4>()) != hipSuccess) return e;
     if ((e = set_limit<5>()) != hipSuccess) return e;
+    if ((e = set_limit<6>()) != hipSuccess) return e;
     return hipSuccess;
 }
 
@@ -609,10 +622,12 @@ bool launch_conv3x3_sp(const ConvArgs& a, hipStream_t s)
     if (2ll * a.B * a.H * a.r * a.W * a.r * a.out_cs >= (1ll << 32) - 8192) return false;   // 32-bit BYTE offsets for stores / residual loads
     if (a.scale != 1.f || !a.bias_img) return false;           // the engine folds ScaleLayer into the weights and always passes a bias vector
     const bool act = a.slope != 1.f, res = a.res != nullptr, tail = a.tplanes != nullptr;
-    if ((act || tail) && res) return false;
+    if ((act || tail) && res && !a.plane_w) return false;
     if (x3 && (tail || a.res_lo)) return false;                        // (the engine folds res_lo into side16)
     if (tail && 36ll * a.B * a.H * a.r * a.W * a.r >= (1ll << 32) - 8192) return false;
-    const int epi = x3 ? (res ? 5 : 4) : tail ? 3 : (res ? 2 : (act ? 1 : 0));
+    const bool planew = a.plane_w != 0;                                 // per-plane weights: act + residual only (SEDN fused block tail)
+    if (planew && (!res || tail || x3 || a.r != 1)) return false;
+    const int epi = planew ? 6 : x3 ? (res ? 5 : 4) : tail ? 3 : (res ? 2 : (act ? 1 : 0));
     const int blocks = a.nchunks * ((a.G + 7) / 8) * 8;
     const dim3 grid(blocks), blk(256);
     switch (epi) {
@@ -621,6 +636,7 @@ bool launch_conv3x3_sp(const ConvArgs& a, hipStream_t s)
         case 3: conv3x3_sp_kernel<3><<<grid, blk, LDS_BYTES, s>>>(a); break;
         case 4: conv3x3_sp_kernel<4><<<grid, blk, LDS_BYTES, s>>>(a); break;
         case 5: conv3x3_sp_kernel<5><<<grid, blk, LDS_BYTES, s>>>(a); break;
+        case 6: conv3x3_sp_kernel<6><<<grid, blk, LDS_BYTES, s>>>(a); break;
         default: conv3x3_sp_kernel<2><<<grid, blk, LDS_BYTES, s>>>(a); break;
     }
     return true;

@@ -373,6 +373,20 @@ static int build_device_weights(moe_net& n, int precision)
             conv(k + ".trans", p + "trans.0.weight", nullptr, 1, 0.2f, 1.f, true);
             f32table(k + ".down", n.get(p + "conv_down.weight")->data);
             f32table(k + ".up", n.get(p + "conv_up.weight")->data);
+            {   // fused block tail (sedn_fuse): rblock.4 as [256][tap*64 + ci] and transposed, trans as [64][256], all fp32
+                const Param& W4 = *n.get(p + "rblock.4.weight");
+                std::vector<float> w256((size_t)256 * 576), w256t((size_t)576 * 256);
+                for (int m = 0; m < 256; ++m)
+                    for (int ci = 0; ci < 64; ++ci)
+                        for (int tap = 0; tap < 9; ++tap) {
+                            const float v = W4.data[((size_t)m * 64 + ci) * 9 + tap];
+                            w256[(size_t)m * 576 + tap * 64 + ci] = v;
+                            w256t[(size_t)(tap * 64 + ci) * 256 + m] = v;
+                        }
+                f32table(k + ".w256", w256);
+                f32table(k + ".w256t", w256t);
+                f32table(k + ".wt", n.get(p + "trans.0.weight")->data);
+            }
         }
         tail("tail_r", "convt_R1.weight");
     } else {
@@ -712,10 +726,38 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         half_t* wplane_lo = f.x3 ? (half_t*)f.ar.take((size_t)B * wel * 2) : nullptr;
         stem(A);
         f.tap("stem", A, h, w, 64, 64);
+        // fused block tail (see sedn_fuse in misc_kernels.hip): single-pass precision, fast kernel, planes fit the per-XCD split
+        static const bool fuse_env = [] { const char* e = getenv("MOE_SEDN_FUSE"); return !(e && !strcmp(e, "0")); }();
+        const int per_xcd = n.max_groups / 8;
+        const bool sfuse = fuse_env && !f.x3 && !f.direct && !n.debug && conv_impl() == 2 && B <= per_xcd &&
+                           2ll * B * h * w * 64 < (1ll << 32) - 8192;
+        float* xpart = (float*)f.ar.take((size_t)B * nslab * 5 * 64 * 4);
+        float* fgate = (float*)f.ar.take((size_t)B * 256 * 4);
+        half_t* weff = (half_t*)f.ar.take((size_t)B * 72 * 512 * 2);
         for (int b = 0; b < 16; ++b) {
             const std::string k = "b" + std::to_string(b);
             f.conv(k + ".rb0", A, Cc, nullptr, h, w);
             f.conv(k + ".rb2", Cc, Dd, nullptr, h, w);
+            if (sfuse) {
+                if (!f.dry()) {
+                    SednFuseArgs fa{};
+                    fa.x = Dd.hi; fa.partial = xpart; fa.nslab = nslab; fa.B = B; fa.H = h; fa.W = w;
+                    fa.w256t = f.small<float>(k + ".w256t"); fa.w256 = f.small<float>(k + ".w256"); fa.wt = f.small<float>(k + ".wt");
+                    fa.w_down = f.small<float>(k + ".down"); fa.w_up = f.small<float>(k + ".up");
+                    fa.gate = fgate; fa.weff = weff;
+                    launch_sedn_fuse(fa, s);
+                    ConvArgs a{};
+                    a.in = Dd.hi; a.out = A.hi; a.res = A.hi; a.wpk = weff; a.plane_w = 1;
+                    a.bias = f.small<float>("zero_bias"); a.bias_img = f.small<float>("zero_bias_img");
+                    a.zero = f.small<half_t>("zero"); a.trash = f.small<half_t>("trash");
+                    a.B = B; a.H = h; a.W = w; a.in_cs = 64; a.out_cs = 64; a.r = 1; a.nchunks = B;
+                    a.px = (w + kTileW - 1) / kTileW; a.py = (h + kTileH - 1) / kTileH;
+                    a.G = std::max(1, std::min(8 * (per_xcd / B), a.px * a.py));
+                    a.slope = 0.2f; a.scale = 1.f;
+                    if (!launch_conv3x3_sp(a, s)) return fail(MOE_EINVAL, "SEDN fused block tail: kernel rejected the layer");
+                }
+                continue;
+            }
             f.conv(k + ".rb4", Dd, T, nullptr, h, w);
             if (!f.dry()) {
                 launch_pool_partial(T.hi, T.lo, partial, B, (long long)h * w, 256, nslab, s);

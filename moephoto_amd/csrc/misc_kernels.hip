@@ -455,6 +455,155 @@ __global__ __launch_bounds__(256) void sedn_se_kernel(SednSeArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// SEDN fused block tail.  Between rblock.4 (3x3 64->256, no activation) and the gated 1x1 `trans` (256->64) everything is linear:
+//     trans(g * conv256(x)) = conv(W_eff, x),   W_eff[b] = W_t diag(g_b) W_256      (64 x 64 x 9, one set per plane)
+// and the pooled mean the gate needs is W_256 applied to the nine shifted-window sums of x (total minus border rows/columns,
+// zero padding).  The 256-channel tensor, the pooling pass over it and 4.4x of these two convs' FLOPs disappear.
+//   1. sedn_xsum:  per plane and channel the total and the first/last row/column sums of x (two-stage, fixed order)
+//   2. sedn_fgate: shifted sums -> mean[256] -> squeeze-excite gate g[256]
+//   3. sedn_weff:  W_eff = (W_t * g) W_256 in fp32, stored as fp16 MFMA A fragments for conv3x3_sp (EPI 6, per-plane weights)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sedn_xsum_kernel(SednFuseArgs a)
+{
+    __shared__ float red[5][32][64];
+    const int b = blockIdx.y, slab = blockIdx.x;
+    const int cg = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const long long HW = (long long)a.H * a.W;
+    const long long per = (HW + a.nslab - 1) / a.nslab;
+    const long long p0 = slab * per, p1 = (p0 + per < HW) ? p0 + per : HW;
+    float acc[5][8];
+#pragma unroll
+    for (int c = 0; c < 5; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[c][e] = 0.f;
+    for (long long p = p0 + pl; p < p1; p += 32) {
+        const int y = (int)(p / a.W), x = (int)(p - (long long)y * a.W);
+        const half8_t v = *(const half8_t*)(a.x + ((long long)b * HW + p) * 64 + cg * 8);
+        const float f0 = 1.f, fr0 = y == 0 ? 1.f : 0.f, frl = y == a.H - 1 ? 1.f : 0.f, fc0 = x == 0 ? 1.f : 0.f, fcl = x == a.W - 1 ? 1.f : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float t = (float)v[e];
+            acc[0][e] += t * f0; acc[1][e] += t * fr0; acc[2][e] += t * frl; acc[3][e] += t * fc0; acc[4][e] += t * fcl;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 5; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[c][pl][cg * 8 + e] = acc[c][e];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 5 * 64; i += 256) {
+        const int c = i >> 6, ch = i & 63;
+        float t = 0.f;
+        for (int k = 0; k < 32; ++k) t += red[c][k][ch];
+        a.partial[(((long long)b * a.nslab + slab) * 5 + c) * 64 + ch] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void sedn_fgate_kernel(SednFuseArgs a)
+{
+    __shared__ float sums[5][64];
+    __shared__ float corner[4][64];      // x[0][0], x[0][W-1], x[H-1][0], x[H-1][W-1]
+    __shared__ float sh[576];            // shifted-window sums, k = tap*64 + ci
+    __shared__ float mean[256];
+    __shared__ float part[256];
+    __shared__ float hid[16];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const long long HW = (long long)a.H * a.W;
+    for (int i = t; i < 5 * 64; i += 256) {
+        const int c = i >> 6, ch = i & 63;
+        float v = 0.f;
+        for (int k = 0; k < a.nslab; ++k) v += a.partial[(((long long)b * a.nslab + k) * 5 + c) * 64 + ch];
+        sums[c][ch] = v;
+    }
+    {
+        const int q = t >> 6, ch = t & 63;
+        const long long p = (q & 2 ? (long long)(a.H - 1) * a.W : 0) + (q & 1 ? a.W - 1 : 0);
+        corner[q][ch] = (float)a.x[((long long)b * HW + p) * 64 + ch];
+    }
+    __syncthreads();
+    for (int k = t; k < 576; k += 256) {
+        const int tap = k >> 6, ci = k & 63, dy = tap / 3, dx = tap % 3;
+        float v = sums[0][ci];
+        if (dy == 0) v -= sums[2][ci];           // rows y-1: the last row never contributes
+        if (dy == 2) v -= sums[1][ci];           // rows y+1: the first row never contributes
+        if (dx == 0) v -= sums[4][ci];
+        if (dx == 2) v -= sums[3][ci];
+        if (dy == 0 && dx == 0) v += corner[3][ci];
+        if (dy == 0 && dx == 2) v += corner[2][ci];
+        if (dy == 2 && dx == 0) v += corner[1][ci];
+        if (dy == 2 && dx == 2) v += corner[0][ci];
+        sh[k] = v;
+    }
+    __syncthreads();
+    {
+        float m = 0.f;
+        for (int k = 0; k < 576; ++k) m += a.w256t[k * 256 + t] * sh[k];
+        mean[t] = m / (float)HW;
+    }
+    __syncthreads();
+    {
+        const int k = t >> 4, q = t & 15;
+        float h = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) h += a.w_down[k * 256 + q * 16 + c] * mean[q * 16 + c];
+        part[t] = h;
+    }
+    __syncthreads();
+    if (t < 16) {
+        float h = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) h += part[t * 16 + q];
+        hid[t] = prelu(h, 0.2f);
+    }
+    __syncthreads();
+    float u = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) u += a.w_up[t * 16 + k] * hid[k];
+    a.gate[b * 256 + t] = 1.f / (1.f + __expf(-u));
+}
+
+// W_eff[b][co][k] = sum_m (W_t[co][m] g[b][m]) W_256[m][k]: 64 x 576 x 256 per plane.  Block = 64 co x 64 k (one tap), 4 x 4 per thread.
+__global__ __launch_bounds__(256) void sedn_weff_kernel(SednFuseArgs a)
+{
+    __shared__ float As[32][65];         // [m][co]
+    __shared__ float Bs[32][65];         // [m][k]
+    const int tap = blockIdx.x, b = blockIdx.y;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    float acc[4][4] = {};
+    for (int m0 = 0; m0 < 256; m0 += 32) {
+        for (int i = threadIdx.x; i < 32 * 64; i += 256) {
+            const int m = i & 31, co = i >> 5;
+            As[m][co] = a.wt[co * 256 + m0 + m] * a.gate[b * 256 + m0 + m];
+        }
+        for (int i = threadIdx.x; i < 32 * 64; i += 256) {
+            const int k = i & 63, m = i >> 6;
+            Bs[m][k] = a.w256[(long long)(m0 + m) * 576 + tap * 64 + k];
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int m = 0; m < 32; ++m) {
+            float av[4], bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { av[i] = As[m][ty * 4 + i]; bv[i] = Bs[m][tx * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
+        }
+        __syncthreads();
+    }
+    // fragment f = (tap*4 + ks)*2 + nblk, lane l = 32*(ci%16/8) + co%32, element e = ci%8   (pack_conv's order)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int co = ty * 4 + i, ci = tx * 4 + j;
+            const int f = (tap * 4 + (ci >> 4)) * 2 + (co >> 5), l = (((ci >> 3) & 1) << 5) + (co & 31), e = ci & 7;
+            a.weff[(((long long)b * 72 + f) * 64 + l) * 8 + e] = (half_t)acc[i][j];
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // lite FRM gate (models.py:270-287) + LB residual (MoeNet_lite2.py:16-20): out = t * gate + x
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void frm_gate_kernel(FrmArgs a)
@@ -683,6 +832,13 @@ void launch_pool_partial(const half_t* in, const half_t* in_lo, float* partial, 
 void launch_sedn_se(const SednSeArgs& a, hipStream_t s)
 {
     hipLaunchKernelGGL(sedn_se_kernel, dim3(a.B, kSeSplit), dim3(256), 0, s, a);
+}
+
+void launch_sedn_fuse(const SednFuseArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(sedn_xsum_kernel, dim3(a.nslab, a.B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(sedn_fgate_kernel, dim3(a.B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(sedn_weff_kernel, dim3(9, a.B), dim3(256), 0, s, a);
 }
 
 void launch_frm(const FrmArgs& a, hipStream_t s)
