@@ -148,7 +148,7 @@ struct SednFuseArgs {
     const float* wt;          // [64][256]  trans weights
     const float* w_down;      // [16][256]
     const float* w_up;        // [256][16]
-    float* gate;              // [B][256]
+    float* gate;              // [B][256]: the channel means (sedn_fmean -> sedn_weff)
     half_t* weff;             // [B][72 fragments][64 lanes][8] packed A fragments of the fused conv
 };
 void launch_sedn_fuse(const SednFuseArgs& a, hipStream_t s);

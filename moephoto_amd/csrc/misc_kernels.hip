@@ -460,8 +460,8 @@ __global__ __launch_bounds__(256) void sedn_se_kernel(SednSeArgs a)
 // and the pooled mean the gate needs is W_256 applied to the nine shifted-window sums of x (total minus border rows/columns,
 // zero padding).  The 256-channel tensor, the pooling pass over it and 4.4x of these two convs' FLOPs disappear.
 //   1. sedn_xsum:  per plane and channel the total and the first/last row/column sums of x (two-stage, fixed order)
-//   2. sedn_fgate: shifted sums -> mean[256] -> squeeze-excite gate g[256]
-//   3. sedn_weff:  W_eff = (W_t * g) W_256 in fp32, stored as fp16 MFMA A fragments for conv3x3_sp (EPI 6, per-plane weights)
+//   2. sedn_fmean: shifted sums -> channel means of the (never formed) 256-channel tensor
+//   3. sedn_weff:  squeeze-excite gate g from the means, then W_eff = (W_t * g) W_256 in fp32, stored as fp16 MFMA A fragments for conv3x3_sp (EPI 6, per-plane weights)
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sedn_xsum_kernel(SednFuseArgs a)
 {
@@ -499,19 +499,19 @@ __global__ __launch_bounds__(256) void sedn_xsum_kernel(SednFuseArgs a)
     }
 }
 
-__global__ __launch_bounds__(256) void sedn_fgate_kernel(SednFuseArgs a)
+constexpr int kMeanSplit = 4;          // blocks per plane in sedn_fmean: 64 of the 256 channel means each
+__global__ __launch_bounds__(256) void sedn_fmean_kernel(SednFuseArgs a)
 {
     __shared__ float sums[5][64];
     __shared__ float corner[4][64];      // x[0][0], x[0][W-1], x[H-1][0], x[H-1][W-1]
     __shared__ float sh[576];            // shifted-window sums, k = tap*64 + ci
-    __shared__ float mean[256];
-    __shared__ float part[256];
-    __shared__ float hid[16];
+    __shared__ float red[4][64];
     const int b = blockIdx.x, t = threadIdx.x;
     const long long HW = (long long)a.H * a.W;
     for (int i = t; i < 5 * 64; i += 256) {
         const int c = i >> 6, ch = i & 63;
         float v = 0.f;
+#pragma unroll 8
         for (int k = 0; k < a.nslab; ++k) v += a.partial[(((long long)b * a.nslab + k) * 5 + c) * 64 + ch];
         sums[c][ch] = v;
     }
@@ -535,69 +535,81 @@ __global__ __launch_bounds__(256) void sedn_fgate_kernel(SednFuseArgs a)
         sh[k] = v;
     }
     __syncthreads();
-    {
-        float m = 0.f;
-        for (int k = 0; k < 576; ++k) m += a.w256t[k * 256 + t] * sh[k];
-        mean[t] = m / (float)HW;
+    {   // thread (part q of 4, channel m): 144 of the 576 terms, then a fixed-order sum of the four parts
+        const int q = t >> 6, m = blockIdx.y * 64 + (t & 63);
+        float m0 = 0.f, m1 = 0.f;
+#pragma unroll 8
+        for (int k = q * 144; k < q * 144 + 144; k += 2) {
+            m0 += a.w256t[(k + 0) * 256 + m] * sh[k + 0];
+            m1 += a.w256t[(k + 1) * 256 + m] * sh[k + 1];
+        }
+        red[q][t & 63] = m0 + m1;
     }
     __syncthreads();
-    {
-        const int k = t >> 4, q = t & 15;
-        float h = 0.f;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) h += a.w_down[k * 256 + q * 16 + c] * mean[q * 16 + c];
-        part[t] = h;
-    }
-    __syncthreads();
-    if (t < 16) {
-        float h = 0.f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) h += part[t * 16 + q];
-        hid[t] = prelu(h, 0.2f);
-    }
-    __syncthreads();
-    float u = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) u += a.w_up[t * 16 + k] * hid[k];
-    a.gate[b * 256 + t] = 1.f / (1.f + __expf(-u));
+    if (t < 64) a.gate[b * 256 + blockIdx.y * 64 + t] = ((red[0][t] + red[1][t]) + (red[2][t] + red[3][t])) / (float)HW;   // (the MEAN; the gate is formed in sedn_weff)
 }
 
-// W_eff[b][co][k] = sum_m (W_t[co][m] g[b][m]) W_256[m][k]: 64 x 576 x 256 per plane.  Block = 64 co x 64 k (one tap), 4 x 4 per thread.
+// W_eff[b][co][k] = sum_m (W_t[co][m] g[b][m]) W_256[m][k]: 64 x 576 x 256 per plane.  Block = 32 co x 64 k (one tap, half of
+// the output channels), 2 x 4 per thread; grid 9 x B x 2.
 __global__ __launch_bounds__(256) void sedn_weff_kernel(SednFuseArgs a)
 {
-    __shared__ float As[32][65];         // [m][co]
-    __shared__ float Bs[32][65];         // [m][k]
-    const int tap = blockIdx.x, b = blockIdx.y;
+    constexpr int MC = 64;               // m per stage
+    __shared__ float As[MC][33];         // [m][co]
+    __shared__ __attribute__((aligned(16))) float Bs[MC][64];         // [m][k]
+    __shared__ float mean[256], part[256], hid[16], gate[256];
+    const int tap = blockIdx.x, b = blockIdx.y, co0 = blockIdx.z * 32;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    float acc[4][4] = {};
-    for (int m0 = 0; m0 < 256; m0 += 32) {
-        for (int i = threadIdx.x; i < 32 * 64; i += 256) {
-            const int m = i & 31, co = i >> 5;
-            As[m][co] = a.wt[co * 256 + m0 + m] * a.gate[b * 256 + m0 + m];
-        }
-        for (int i = threadIdx.x; i < 32 * 64; i += 256) {
-            const int k = i & 63, m = i >> 6;
-            Bs[m][k] = a.w256[(long long)(m0 + m) * 576 + tap * 64 + k];
+    {   // squeeze-excite gate of this plane from its channel means (16 KFLOP: every block redoes it rather than wait for a launch)
+        const int t = threadIdx.x;
+        mean[t] = a.gate[b * 256 + t];
+        __syncthreads();
+        {
+            const int k = t >> 4, q = t & 15;
+            float h = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) h += a.w_down[k * 256 + q * 16 + c] * mean[q * 16 + c];
+            part[t] = h;
         }
         __syncthreads();
-#pragma unroll 8
-        for (int m = 0; m < 32; ++m) {
-            float av[4], bv[4];
+        if (t < 16) {
+            float h = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { av[i] = As[m][ty * 4 + i]; bv[i] = Bs[m][tx * 4 + i]; }
+            for (int q = 0; q < 16; ++q) h += part[t * 16 + q];
+            hid[t] = prelu(h, 0.2f);
+        }
+        __syncthreads();
+        float u = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
+        for (int k = 0; k < 16; ++k) u += a.w_up[t * 16 + k] * hid[k];
+        gate[t] = 1.f / (1.f + __expf(-u));
+        __syncthreads();
+    }
+    float acc[2][4] = {};
+    for (int m0 = 0; m0 < 256; m0 += MC) {
+        for (int i = threadIdx.x; i < MC * 32; i += 256) {
+            const int m = i % MC, co = i / MC;
+            As[m][co] = a.wt[(co0 + co) * 256 + m0 + m] * gate[m0 + m];
+        }
+        for (int i = threadIdx.x; i < MC * 16; i += 256) {      // 16-byte loads: 16 per row of 64 k
+            const int kq = i & 15, m = i >> 4;
+            *(float4*)&Bs[m][kq * 4] = *(const float4*)(a.w256 + (long long)(m0 + m) * 576 + tap * 64 + kq * 4);
+        }
+        __syncthreads();
+#pragma unroll 16
+        for (int m = 0; m < MC; ++m) {
+            const float4 bv = *(const float4*)&Bs[m][tx * 4];
+            const float a0 = As[m][ty * 2], a1 = As[m][ty * 2 + 1];
+            acc[0][0] += a0 * bv.x; acc[0][1] += a0 * bv.y; acc[0][2] += a0 * bv.z; acc[0][3] += a0 * bv.w;
+            acc[1][0] += a1 * bv.x; acc[1][1] += a1 * bv.y; acc[1][2] += a1 * bv.z; acc[1][3] += a1 * bv.w;
         }
         __syncthreads();
     }
     // fragment f = (tap*4 + ks)*2 + nblk, lane l = 32*(ci%16/8) + co%32, element e = ci%8   (pack_conv's order)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int co = ty * 4 + i, ci = tx * 4 + j;
+            const int co = co0 + ty * 2 + i, ci = tx * 4 + j;
             const int f = (tap * 4 + (ci >> 4)) * 2 + (co >> 5), l = (((ci >> 3) & 1) << 5) + (co & 31), e = ci & 7;
             a.weff[(((long long)b * 72 + f) * 64 + l) * 8 + e] = (half_t)acc[i][j];
         }
@@ -837,8 +849,8 @@ void launch_sedn_se(const SednSeArgs& a, hipStream_t s)
 void launch_sedn_fuse(const SednFuseArgs& a, hipStream_t s)
 {
     hipLaunchKernelGGL(sedn_xsum_kernel, dim3(a.nslab, a.B), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(sedn_fgate_kernel, dim3(a.B), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(sedn_weff_kernel, dim3(9, a.B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(sedn_fmean_kernel, dim3(a.B, kMeanSplit), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(sedn_weff_kernel, dim3(9, a.B, 2), dim3(256), 0, s, a);
 }
 
 void launch_frm(const FrmArgs& a, hipStream_t s)
