@@ -152,6 +152,22 @@ def test_ragged_and_tiny_tiles(dev):
     assert np.abs(y.float().cpu().numpy() - want).max() <= 2.5e-3                 # + fp16 rounding of the output
 
 
+def test_sedn_fused_block_tail_shapes(dev):
+    """SEDN's fused block tail (per-plane effective weights, gate from shifted-window sums of the block input) on ragged and
+    tiny tiles and on more planes than one tile has; the unfused form (MOE_SEDN_FUSE=0 is an environment switch, so the split
+    precision mode is used here) must agree with the oracle as well."""
+    sd = gd.state_dict_for('l25', load_state_dict_file)
+    mf = module_for('l25', 'fp16')
+    for (bn, h, w) in ((3, 8, 16), (3, 24, 56), (5, 88, 40), (12, 16, 64)):
+        x = gd.natural_image(13, (bn, h, w))[:, None]
+        want = onets.forward('sedn', sd, x).numpy()
+        got = mf(torch.from_numpy(x).to(dev))[-1].cpu().numpy()
+        assert np.abs(got - want).max() <= TOL_NATURAL, (bn, h, w, float(np.abs(got - want).max()))
+    mx = module_for('l25', 'fp16x3')
+    x = gd.natural_image(13, (3, 24, 56))[:, None]
+    assert np.abs(mx(torch.from_numpy(x).to(dev))[-1].cpu().numpy() - onets.forward('sedn', sd, x).numpy()).max() <= 2e-5
+
+
 def test_config5_tile_size_vs_independent_device_kernel(dev):
     """BASELINE config 5 uses 512-px tiles (2048x2048 output per plane).  A CPU oracle run at that size takes minutes, so the
     MFMA path (software-pipelined convs, fused tail) is checked against the engine's independent scalar device convolution
