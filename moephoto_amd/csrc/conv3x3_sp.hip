@@ -90,12 +90,16 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
     // only the patches of plane b and all write the same 64 output channels
     constexpr bool PLANEW = (EPI == 6);
     const int bid = blockIdx.x;
-    const int chunk = (bid >> 3) % a.nchunks;
-    const int g = (bid & 7) + 8 * (bid / (8 * a.nchunks));
-    if (g >= a.G) return;
+    // default: the nchunks workgroups that share an input patch sit on one XCD (blocks go round-robin to the 8 XCDs).  Per-plane
+    // weights: nothing is shared between workgroups, so block b simply takes plane b % B and is the (b / B)-th of that plane's
+    // G = ceil((blocks - plane) / B) groups -- every CU is used whatever the plane count (12 planes: 21 or 22 groups each)
+    const int chunk = PLANEW ? bid % a.nchunks : (bid >> 3) % a.nchunks;
+    const int g = PLANEW ? bid / a.nchunks : (bid & 7) + 8 * (bid / (8 * a.nchunks));
+    const int G = PLANEW ? ((int)gridDim.x - chunk + a.nchunks - 1) / a.nchunks : a.G;
+    if (g >= G) return;
     const int nitems = (PLANEW ? 1 : a.B) * a.py * a.px;
     const int bofs = PLANEW ? chunk : 0;                          // plane offset of this workgroup's items
-    const int K = (nitems - g + a.G - 1) / a.G;                  // this workgroup's items: g, g+G, ...
+    const int K = (nitems - g + G - 1) / G;                       // this workgroup's items: g, g+G, ...
     if (K <= 0) return;
 
     const half_t* const zsrc = a.zero + (lane & 7) * 8;
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         poff[i] = (r * a.W + c) * a.in_cs + sl * 8;
     }
     // work items g, g+G, g+2G, ... are walked with carries instead of divisions
-    const int Gx = a.G % a.px, Gy = (a.G / a.px) % a.py, Gb = a.G / (a.px * a.py);
+    const int Gx = G % a.px, Gy = (G / a.px) % a.py, Gb = G / (a.px * a.py);
     auto advance = [&](const Item& it) {
         Item n;
         int x = it.pxi + Gx;
@@ -628,7 +632,7 @@ bool launch_conv3x3_sp(const ConvArgs& a, hipStream_t s)
     const bool planew = a.plane_w != 0;                                 // per-plane weights: act + residual only (SEDN fused block tail)
     if (planew && (!res || tail || x3 || a.r != 1)) return false;
     const int epi = planew ? 6 : x3 ? (res ? 5 : 4) : tail ? 3 : (res ? 2 : (act ? 1 : 0));
-    const int blocks = a.nchunks * ((a.G + 7) / 8) * 8;
+    const int blocks = planew ? a.G : a.nchunks * ((a.G + 7) / 8) * 8;          // per-plane weights: a.G is the TOTAL number of workgroups
     const dim3 grid(blocks), blk(256);
     switch (epi) {
         case 0: conv3x3_sp_kernel<0><<<grid, blk, LDS_BYTES, s>>>(a); break;

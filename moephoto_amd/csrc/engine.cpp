@@ -728,8 +728,7 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         f.tap("stem", A, h, w, 64, 64);
         // fused block tail (see sedn_fuse in misc_kernels.hip): single-pass precision, fast kernel, planes fit the per-XCD split
         static const bool fuse_env = [] { const char* e = getenv("MOE_SEDN_FUSE"); return !(e && !strcmp(e, "0")); }();
-        const int per_xcd = n.max_groups / 8;
-        const bool sfuse = fuse_env && !f.x3 && !f.direct && !n.debug && conv_impl() == 2 && B <= per_xcd &&
+        const bool sfuse = fuse_env && !f.x3 && !f.direct && !n.debug && conv_impl() == 2 && B <= n.max_groups &&
                            2ll * B * h * w * 64 < (1ll << 32) - 8192;
         float* xpart = (float*)f.ar.take((size_t)B * nslab * 5 * 64 * 4);
         float* fgate = (float*)f.ar.take((size_t)B * 256 * 4);
@@ -752,7 +751,7 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
                     a.zero = f.small<half_t>("zero"); a.trash = f.small<half_t>("trash");
                     a.B = B; a.H = h; a.W = w; a.in_cs = 64; a.out_cs = 64; a.r = 1; a.nchunks = B;
                     a.px = (w + kTileW - 1) / kTileW; a.py = (h + kTileH - 1) / kTileH;
-                    a.G = std::max(1, std::min(8 * (per_xcd / B), a.px * a.py));
+                    a.G = (int)std::max<long long>(B, std::min<long long>(n.max_groups, (long long)B * a.px * a.py));   // total workgroups (plane b gets every B-th)
                     a.slope = 0.2f; a.scale = 1.f;
                     if (!launch_conv3x3_sp(a, s)) return fail(MOE_EINVAL, "SEDN fused block tail: kernel rejected the layer");
                 }
