@@ -134,6 +134,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
 
     const int j = lane & 31, hh = lane >> 5;
     float16_t acc[4];
+    // the chunk's bias for this lane's 16 channels, once per kernel (loaded inside the epilogue, every tile waited four times for L2)
+    float4_t bias4[4];
+#pragma unroll
+    for (int grp = 0; grp < 4; ++grp) {
+        bias4[grp] = float4_t{0.f, 0.f, 0.f, 0.f};
+        if (a.bias) bias4[grp] = *(const float4_t*)(a.bias + chunk * kCB + wn * 32 + hh * 4 + grp * 8);
+    }
     float tw[4][4];                                      // fused 1x1 tail: this lane's 16 tail weights (channel wn*32 + hh*4 + 8*grp + e)
 #pragma unroll
     for (int grp = 0; grp < 4; ++grp)
@@ -258,7 +265,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
                             *p = *p + v; continue;
                         }
                         if (a.acc_mode == 3) v = v + *(const float4_t*)(a.acc32 + apix + pcb + grp * 8) * 0.00048828125f;
-                        if (a.bias) v = v + *(const float4_t*)(a.bias + pcb + grp * 8);
+                        v = v + bias4[grp];
                         v = v * a.scale;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * a.slope;
