@@ -46,4 +46,31 @@ for key in os.environ.get('FUZZ_KEYS', 'a2,a3,a4,dn_lite5,l25,lite2,lite4').spli
         flag = '' if worst <= tol else '   <-- EXCEEDS {:g}'.format(tol)
         bad += worst > tol
         print('{:9s} {:5s} ({:6s}) worst {:.3e} at B,h,w={}{}'.format(key, prec, 'x3' if x3 else 'fp16', worst, wcase, flag), flush=True)
+
+# ---- whole doCrop (planner + tile loop + stitch) on random image sizes / tile sizes, a2 (x2) and dn_lite5 ------------------------
+from moephoto_amd import imageProcess as ip, runDN, runSR  # noqa: E402
+from moephoto_amd.config import config  # noqa: E402
+from oracle import planner as oplanner, stitch as ostitch  # noqa: E402
+config.modelRoot, config.fp16, config.deviceId = gd.ZOO, False, 0
+for i in range(int(os.environ.get('FUZZ_CROPS', '5'))):
+    H, W = int(rng.integers(60, 200)), int(rng.integers(60, 260))
+    crop = 8 * int(rng.integers(6, 14))
+    C = int(rng.integers(1, 5))
+    x = gd.natural_image(300 + i, (C, H, W))
+    for kind in ('SR a2', 'DN lite5'):
+        ip.modelCache.clear()
+        if kind == 'SR a2':
+            config.crop_sr = crop
+            opt = runSR.getOpt({'model': 'a', 'scale': 2, 'ensemble': 0})
+            arch, sd, pad, sc, tol = 'net2x', gd.state_dict_for('a2', load_state_dict_file), 5, 2, 3e-3
+        else:
+            config.crop_dn = crop
+            opt = runDN.getOpt({'model': 'lite5'})
+            arch, sd, pad, sc, tol = 'netdn', gd.state_dict_for('dn_lite5', load_state_dict_file), 7, 1, 2e-5
+        got = ip.doCrop(opt, torch.from_numpy(x).cuda()).cpu().numpy()
+        pl = oplanner.prepare((C, H, W), 1 << 40, 1e-3, pad, sc, 8, crop)
+        want = ostitch.do_crop(x, pl, sc, onets.model_fn(arch, sd))
+        err = float(np.abs(got - want).max())
+        bad += err > tol
+        print('doCrop {:8s} C={} {}x{} crop {:3d} tiles {:3d}: {:.3e}{}'.format(kind, C, H, W, crop, len(pl.tiles), err, '' if err <= tol else '   <-- EXCEEDS'), flush=True)
 sys.exit(1 if bad else 0)
