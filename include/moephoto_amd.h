@@ -63,6 +63,11 @@ extern "C" {
 #define MOE_PREC_FP16 0        /* fp16 operands, one MFMA pass: the reference's GPU fp16 mode (config.fp16) */
 #define MOE_PREC_FP16X3 1      /* hi/lo split operands, three MFMA passes: ~fp32 products */
 #define MOE_PREC_DEBUG_DIRECT 2 /* slow scalar device convolution, fp32 accumulate; kernel debugging only */
+#define MOE_PREC_MIXED 3       /* Net2x/3x/4x, NetDN: fp16 operands; the trunk stream x + s*conv2(..) of the six ARSBs
+                                * (python/models.py:76-80) and the stem output are carried as hi + lo pairs (~fp32),
+                                * conv_input2 and the first moe_net_set_exact_blocks() ARSBs use split operands, the 64->1
+                                * tail convs see their weights to ~22 bits: <= 1e-3 vs the fp32 reference on every input
+                                * class at ~1.1-1.2x the FP16 time */
 
 typedef struct moe_net moe_net;
 typedef struct moe_plan moe_plan;
@@ -88,6 +93,10 @@ int moe_net_set_param(moe_net* net, const char* name, const float* data, const i
 int moe_net_finalize(moe_net* net, int device, int precision);
 /* device bytes of scratch a forward of B planes of h x w needs (allocated lazily, grow-only, owned by the net) */
 int64_t moe_net_workspace_bytes(const moe_net* net, int B, int h, int w);
+/* largest tile (pixels of one input plane) a forward accepts: the convolution kernels address their tensors with 32-bit byte
+ * offsets.  Batches of planes beyond that range are split into several launch sets internally; a single larger plane is
+ * refused with MOE_ENOMEM (the planner's "tile does not fit" convention, python/imageProcess.py:58-59). */
+int64_t moe_net_max_tile_pixels(const moe_net* net);
 /* y[b] = Net(x[b]),  x: B planes of h x w (h, w >= 1), element (b,i,j) at x + x_off[b] + i*sH + j*sW
  * (strides in elements; x_off == NULL means b*sB), dtype MOE_F32/MOE_F16.  y: B contiguous planes of
  * (scale*h) x (scale*w), plane b at y + (y_off ? y_off[b] : b*scale*h*scale*w), dtype MOE_F32/MOE_F16.
@@ -95,12 +104,17 @@ int64_t moe_net_workspace_bytes(const moe_net* net, int B, int h, int w);
 int moe_net_forward(moe_net* net, const void* x, int x_dtype, int B, int h, int w,
                     int64_t sB, int64_t sH, int64_t sW, const int64_t* x_off,
                     void* y, int y_dtype, const int64_t* y_off, void* stream);
-/* Live kernel timing for the roofline report: bracket every MFMA-conv launch whose layer key contains
- * `layer_substring` (e.g. "up1": the 64->256 upsampler convs at 2x resolution) with hipEvents on the launch
- * stream.  NULL / "" disables.  moe_net_get_profile waits for the recorded events, returns the summed kernel time,
- * the number of launches and their algorithmic FLOPs (2*pixels*Cout*Cin*taps, real channel counts), and resets. */
-int moe_net_set_profile(moe_net* net, const char* layer_substring);
+/* Live kernel timing for the roofline report: bracket the MFMA-conv launches of every layer whose key contains one of the
+ * comma-separated `layer_substrings` (e.g. "up1,c2_": the 64->256 upsampler convs at 2x resolution, and conv_2 of the ARSBs)
+ * with hipEvents on the launch stream.  NULL / "" disables.  moe_net_get_profile_at waits for the recorded events of the
+ * index-th substring and returns their summed kernel time, the number of launches and their algorithmic FLOPs
+ * (2*pixels*Cout*Cin*taps, real channel counts); moe_net_get_profile = index 0, and resets the recording. */
+int moe_net_set_profile(moe_net* net, const char* layer_substrings);
+int moe_net_get_profile_at(moe_net* net, int index, double* total_ms, int64_t* launches, double* flops);
 int moe_net_get_profile(moe_net* net, double* total_ms, int64_t* launches, double* flops);
+/* MOE_PREC_MIXED only: how many leading ARSBs run with split operands (0..6; -1 = the architecture's default:
+ * Net2x 6, Net3x 2, Net4x 1, NetDN 1).  Takes effect at the next forward. */
+int moe_net_set_exact_blocks(moe_net* net, int blocks);
 /* keep fp32 copies of named intermediates during forwards (slow; debugging / layer-by-layer parity only) */
 int moe_net_set_debug(moe_net* net, int enable);
 /* copy a named intermediate of the LAST forward to host as fp32 NCHW (debug / layer-by-layer parity);
@@ -149,6 +163,13 @@ int moe_run_plan_ex(moe_net* net, const moe_plan* plan, const void* img, int img
 int moe_run_plan_frames(moe_net* net, const moe_plan* plan, const void* imgs, int img_dtype, int64_t frame_stride,
                         int64_t sC, int64_t sH, int64_t sW, int n_frames, float* pools, int64_t pool_stride,
                         int owner_index, int owner_count, int max_tiles_per_batch, void* stream);
+/* The same tile loop with an explicit destination per (frame, tile): tile k of frame f is computed iff
+ * tile_dst[f * n_tiles + k] >= 0 and its C result planes go to dst + tile_dst[f * n_tiles + k] (fp32 elements; HOST table).
+ * dist.py points the entries straight into its all-to-all send buffer (tiles another rank stitches) and into the stitch
+ * buffer (tiles this rank stitches itself), so nothing is copied between the net, the collective and moe_stitch. */
+int moe_run_plan_tiles(moe_net* net, const moe_plan* plan, const void* imgs, int img_dtype, int64_t frame_stride,
+                       int64_t sC, int64_t sH, int64_t sW, int n_frames, float* dst, const int64_t* tile_dst,
+                       int max_tiles_per_batch, void* stream);
 /* elements of the fp32 tile pool for C planes, and the element offset of every tile inside it (default layout:
  * tile k = C contiguous planes of its HR extent, tiles in raster order) */
 int64_t moe_plan_pool_elems(const moe_plan* plan, int C);

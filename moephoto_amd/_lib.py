@@ -13,8 +13,8 @@ LIB_PATH = os.path.join(HERE, 'libmoephoto_amd.so')
 OK, EINVAL, ENOMEM, EHIP, ESTATE = 0, -1, -2, -3, -4
 ARCH_NET2X, ARCH_NET3X, ARCH_NET4X, ARCH_NETDN, ARCH_SEDN, ARCH_LITE = range(6)
 F32, F16, U8, U16 = range(4)
-PREC_FP16, PREC_FP16X3, PREC_DEBUG_DIRECT = range(3)
-PRECISIONS = {'fp16': PREC_FP16, 'fp16x3': PREC_FP16X3, 'debug_direct': PREC_DEBUG_DIRECT}
+PREC_FP16, PREC_FP16X3, PREC_DEBUG_DIRECT, PREC_MIXED = range(4)
+PRECISIONS = {'fp16': PREC_FP16, 'fp16x3': PREC_FP16X3, 'debug_direct': PREC_DEBUG_DIRECT, 'mixed': PREC_MIXED}
 
 _lib = None
 
@@ -46,9 +46,12 @@ def lib():
         'moe_net_set_param': (c_int, [c_vp, ctypes.c_char_p, c_vp, P(c_i64), c_int]),
         'moe_net_finalize': (c_int, [c_vp, c_int, c_int]),
         'moe_net_workspace_bytes': (c_i64, [c_vp, c_int, c_int, c_int]),
+        'moe_net_max_tile_pixels': (c_i64, [c_vp]),
         'moe_net_forward': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_int, c_vp, c_vp]),
         'moe_net_set_profile': (c_int, [c_vp, ctypes.c_char_p]),
         'moe_net_get_profile': (c_int, [c_vp, P(c_dbl), P(c_i64), P(c_dbl)]),
+        'moe_net_get_profile_at': (c_int, [c_vp, c_int, P(c_dbl), P(c_i64), P(c_dbl)]),
+        'moe_net_set_exact_blocks': (c_int, [c_vp, c_int]),
         'moe_net_set_debug': (c_int, [c_vp, c_int]),
         'moe_net_debug_tap': (c_i64, [c_vp, ctypes.c_char_p, c_vp, c_i64, P(c_i64), c_vp]),
         'moe_plan_create': (c_int, [P(c_i64), c_dbl, c_dbl, c_int, c_int, c_int, c_int, P(c_vp)]),
@@ -62,6 +65,7 @@ def lib():
         'moe_run_plan': (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_vp, c_int, c_int, c_vp]),
         'moe_run_plan_ex': (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp]),
         'moe_run_plan_frames': (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_i64, c_int, c_vp, c_i64, c_int, c_int, c_int, c_vp]),
+        'moe_run_plan_tiles': (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_i64, c_int, c_vp, P(c_i64), c_int, c_vp]),
         'moe_to_float': (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp]),
         'moe_to_output': (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp]),
     }
@@ -76,9 +80,9 @@ def lib():
 
 EXPORTS = ['moe_last_error', 'moe_abi_version', 'moe_device_count', 'moe_net_create', 'moe_net_destroy', 'moe_net_scale',
            'moe_net_num_params', 'moe_net_param_info', 'moe_net_set_param', 'moe_net_finalize', 'moe_net_workspace_bytes',
-           'moe_net_forward', 'moe_net_set_profile', 'moe_net_get_profile', 'moe_net_set_debug', 'moe_net_debug_tap', 'moe_plan_create', 'moe_plan_destroy', 'moe_plan_info',
+           'moe_net_max_tile_pixels', 'moe_net_forward', 'moe_net_set_profile', 'moe_net_get_profile', 'moe_net_get_profile_at', 'moe_net_set_exact_blocks', 'moe_net_set_debug', 'moe_net_debug_tap', 'moe_plan_create', 'moe_plan_destroy', 'moe_plan_info',
            'moe_plan_tiles', 'moe_plan_ramp', 'moe_plan_pool_elems', 'moe_plan_tile_offsets', 'moe_stitch', 'moe_run_plan',
-           'moe_run_plan_ex', 'moe_run_plan_frames', 'moe_to_float', 'moe_to_output']
+           'moe_run_plan_ex', 'moe_run_plan_frames', 'moe_run_plan_tiles', 'moe_to_float', 'moe_to_output']
 
 
 def check(rc):

@@ -9,7 +9,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['conv_mfma.hip', 'conv3x3_pp.hip', 'conv3x3_sp.hip', 'misc_kernels.hip', 'engine.cpp', 'planner.cpp']
+SOURCES = ['conv_mfma.hip', 'conv3x3_sp.hip', 'misc_kernels.hip', 'engine.cpp', 'planner.cpp']
 HEADERS = ['common.h', 'engine.h', os.path.join('..', '..', 'include', 'moephoto_amd.h')]
 LIB = os.path.join(HERE, 'libmoephoto_amd.so')
 ARCH = 'gfx950'

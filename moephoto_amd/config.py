@@ -42,7 +42,10 @@ class Config(object):
         return free - 2 ** 28
 
     def calcFreeMem(self, ratio=.9):
-        free = (self.getFreeMem() + torch.cuda.memory_reserved(self.deviceId)) * ratio
+        # The engine allocates its workspace and tile pools with hipMalloc, outside torch's caching allocator: memory torch has
+        # reserved but not handed out is NOT available to it (the reference adds it back because its nets allocate through torch,
+        # python/config.py:61-71), so the cache is released before asking the driver.
+        free = self.getFreeMem(emptyCache=torch.cuda.memory_reserved(self.deviceId) > torch.cuda.memory_allocated(self.deviceId)) * ratio
         if self.maxGraphicMemoryUsage > 0:
             free = min(free, self.maxGraphicMemoryUsage * 2 ** 20 - torch.cuda.memory_allocated(self.deviceId))
         return int(free)

@@ -33,7 +33,7 @@ struct ConvArgs {
     half_t* out_lo;       // low part of the output activation ((v - hi) * 2^11), or nullptr
     const half_t* in_lo;  // acc_mode 4 only: low part of the input activation (same layout as `in`)
     int plane_w;          // conv3x3_sp only: wpk holds one weight set per PLANE ([B][72 fragments], nchunks = B), 64 output channels
-    const half_t* side16; // acc_mode 3 (conv3x3_pp): the two low-order products, already summed, as fp16 in the OUTPUT layout (replaces acc32)
+    const half_t* side16; // acc_mode 3 (conv3x3_sp): the two low-order products, already summed, as fp16 in the OUTPUT layout (replaces acc32)
     // conv_mfma_kernel only: fused 1x1 tail (lite's last upsampler stage + its 48->1 conv).  The activated tile is not stored: each
     // lane dots its 16 channels with tail1_w, the two 32-channel halves of the chunk go to two fp32 partial planes [2][B][Ho][Wo]
     const float* tail1_w;  // [64] fp32 in output-channel order of the chunk, or nullptr
@@ -61,12 +61,9 @@ struct ConvArgs {
 void launch_conv_mfma(const ConvArgs& a, int taps, int nseg, hipStream_t s);
 int conv_mfma_max_groups();  // persistent workgroups the device holds (1 per CU)
 hipError_t conv_mfma_init(); // raise dynamic-LDS limits once per process
-// 3x3 / 64-channel specialisation with the two-group ping-pong schedule (conv3x3_pp.hip)
-void launch_conv3x3_pp(const ConvArgs& a, hipStream_t s);
-// same work, one wave per SIMD with the epilogue software-pipelined into the MFMA stream (conv3x3_sp.hip)
+// 3x3 / 64-channel specialisation: one wave per SIMD with the epilogue software-pipelined into the MFMA stream (conv3x3_sp.hip)
 bool launch_conv3x3_sp(const ConvArgs& a, hipStream_t s);   // false: epilogue variant not compiled, use another kernel
 hipError_t conv3x3_sp_init();
-hipError_t conv3x3_pp_init();
 
 struct DirectConvArgs {
     const half_t* in; half_t* out; const half_t* res;

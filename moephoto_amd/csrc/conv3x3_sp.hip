@@ -3,8 +3,8 @@
 //
 // Measured background (profiles/r01): the matrix loop alone runs at ~69 % of the fp16 MFMA peak, but the epilogue
 // (64 outputs per lane per 144 MFMAs: K is only 576) costs as many issue cycles as the MFMAs.  Running it in a second
-// wave on the same SIMD (conv3x3_pp.hip) does not hide it: s_memtime traces show the two waves of a SIMD slowing each
-// other down to the SUM of their solo times.  What the hardware does hide is a wave's OWN independent VALU / LDS / VMEM
+// wave on the same SIMD (the round-1 "ping-pong" variant, since removed) does not hide it: s_memtime traces show the two
+// waves of a SIMD slowing each other down to the SUM of their solo times.  What the hardware does hide is a wave's OWN independent VALU / LDS / VMEM
 // instructions issued in the shadow of its MFMAs (about 5 issue slots per 32-cycle v_mfma_f32_32x32x16_f16).  So:
 //
 //   * 4 waves per workgroup (one per SIMD, all 512 registers each), two accumulator sets per wave;
@@ -17,7 +17,7 @@
 //     74 % MFMA occupancy in cycles (97 % for the bare MFMA/LDS stream); DESIGN.md section 4 has the cycle budget.
 //
 // GEMM view, LDS image (column-keyed XOR swizzle), weight fragment order and the fused epilogue are those of
-// conv_mfma.hip / conv3x3_pp.hip; wave tile = 2 output rows x 32 pixels x 64 output channels.
+// conv_mfma.hip; wave tile = 2 output rows x 32 pixels x 64 output channels.
 #include "common.h"
 
 #ifndef MOE_ABL
@@ -301,6 +301,10 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
             const half8_t bf = __builtin_bit_cast(half8_t, make_uint4(hv[0], hv[1], hv[2], hv[3]));   // k = 8*hh + e  <->  channel nb*32 + 16*gp + perm(hh, e)
             Gacc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tailw[nb * 2 + gp], bf, Gacc[o], 0, 0, 0);
             if ((s8 & 3) == 3) {     // row o complete: lane (j, hh) holds taps 4*hh .. 4*hh+3 in regs 0..3 and tap 8 + 4*hh in reg 4
+                // rows 16..24 of the A fragments hold the rounding remainders of the tail weights (units of 2^-11, engine.cpp): the
+                // same MFMAs formed the low-order sums in regs 8..12 -- fold them in (5 FMAs per row for ~22-bit tail weights)
+#pragma unroll
+                for (int k = 0; k < 5; ++k) Gacc[o][k] = __builtin_fmaf(Gacc[o][8 + k], 0.00048828125f, Gacc[o][k]);
                 // 4-byte-per-lane stores are what this epilogue paid for (~110 cycles each beside the MFMAs; 16-byte ones are nearly
                 // free) while VALU work hides: so a 4x4 transpose inside each lane quad (two DPP exchange stages) turns the four
                 // one-float-per-lane tap registers into ONE 16-byte store: lane (4m+i, hh) ends up with tap 4hh+i of pixels 4m..4m+3.
@@ -623,7 +627,8 @@ bool launch_conv3x3_sp(const ConvArgs& a, hipStream_t s)
 {
     const bool x3 = a.acc_mode == 3 && a.side16 && a.out_lo;          // split-precision final pass (the low-order products are in side16)
     if ((a.acc_mode != 0 && !x3 && !(a.dbg & 64)) || a.slope > 1.f) return false;
-    if (2ll * a.B * a.H * a.r * a.W * a.r * a.out_cs >= (1ll << 32) - 8192) return false;   // 32-bit BYTE offsets for stores / residual loads
+    // 32-bit BYTE offsets for stores / residual loads (the fused-tail epilogue stores no tensor: its tap planes are checked below)
+    if (!a.tplanes && 2ll * a.B * a.H * a.r * a.W * a.r * a.out_cs >= (1ll << 32) - 8192) return false;
     if (a.scale != 1.f || !a.bias_img) return false;           // the engine folds ScaleLayer into the weights and always passes a bias vector
     const bool act = a.slope != 1.f, res = a.res != nullptr, tail = a.tplanes != nullptr;
     if ((act || tail) && res && !a.plane_w) return false;

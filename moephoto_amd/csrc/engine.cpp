@@ -5,6 +5,7 @@
 // python/MoeNet_lite2.py:22-54 (Net), python/imageProcess.py:157-172 (doCrop).  See include/moephoto_amd.h.
 #include "engine.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -83,6 +84,7 @@ struct moe_net {
     std::map<std::string, int> index;
     bool finalized = false;
     int device = -1, precision = MOE_PREC_FP16;
+    int exact_blocks = -1;       // MOE_PREC_MIXED: leading ARSBs computed with split operands (-1: per-architecture default)
     // device weights
     char* blob = nullptr;
     size_t blob_bytes = 0;
@@ -95,10 +97,10 @@ struct moe_net {
     size_t ws_bytes = 0;
     int max_groups = 256;
     // live kernel timing of selected conv layers (bench.py's roofline leg): hipEvent pairs on the launch stream
-    std::string prof_key;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
+    std::vector<std::string> prof_keys;          // comma-separated substrings of moe_net_set_profile
+    struct ProfRec { hipEvent_t e0 = nullptr, e1 = nullptr; int key = 0; double flops = 0; };
+    std::vector<ProfRec> prof_ev;                // event pairs, reused across steps
     size_t prof_used = 0;
-    double prof_flops = 0;
     // debug taps
     bool debug = false;
     struct Tap { float* dev = nullptr; int64_t shape[4] = {0, 0, 0, 0}; };
@@ -284,11 +286,13 @@ static int build_device_weights(moe_net& n, int precision)
 {
     BlobBuilder bb;
     n.convs.clear(); n.conv_index.clear(); n.small.clear(); n.scalars.clear();
-    const bool lo = precision == MOE_PREC_FP16X3, plain = precision == MOE_PREC_DEBUG_DIRECT;
+    const bool mixed = precision == MOE_PREC_MIXED, plain = precision == MOE_PREC_DEBUG_DIRECT;
     auto conv = [&](const std::string& key, const std::string& wname, const char* bname, int r, float slope, float scale,
                     bool per_plane = false) {
         ConvLayer L;
         const Param* b = bname ? n.get(bname) : nullptr;
+        // low-order weight parts: every conv under FP16X3; under MIXED the trunk convs that may run with split operands
+        const bool lo = precision == MOE_PREC_FP16X3 || (mixed && (key == "input2" || key.compare(0, 3, "c1_") == 0 || key.compare(0, 3, "c2_") == 0));
         // the debug path keeps the plain weights and applies the scale in its epilogue; the MFMA kernels get it pre-multiplied
         pack_conv(*n.get(wname), b, r, L, bb, lo, plain, per_plane, plain ? 1.f : scale);
         L.slope = slope; L.scale = plain ? scale : 1.f; L.per_plane = per_plane;
@@ -322,13 +326,22 @@ static int build_device_weights(moe_net& n, int precision)
         n.small[key] = o; n.small[key + ".lo"] = ol;
         n.scalars["tail_taps"] = (float)taps;
         if (taps == 9) {   // A fragments for the fused tail (conv3x3_sp EPI 3): slice i = 16 channels, lane row = tap, k = (hh, e)
+            // Rows 0..8 carry the fp16 weights of the nine taps, rows 16..24 their rounding remainders (w - fp16(w)) * 2^11: the same
+            // MFMA that forms the tap sums also forms the low-order sums (23 of the 32 rows were idle), and the epilogue adds
+            // row 16+t * 2^-11 to row t -- the tail conv sees its weights to ~22 bits at no extra matrix work.
             const size_t of = bb.take(4 * 512 * 2);
             for (int i = 0; i < 4; ++i)
                 for (int l = 0; l < 64; ++l)
                     for (int e8 = 0; e8 < 8; ++e8) {
-                        const int tap = l & 31, hh = l >> 5;
+                        const int row = l & 31, hh = l >> 5;
+                        const int tap = row < 9 ? row : (row >= 16 && row < 25 ? row - 16 : -1);
                         const int ch = i * 16 + (e8 < 4 ? 4 * hh + e8 : 8 + 4 * hh + (e8 - 4));
-                        const float v = (tap < 9 && ch < C) ? W.data[(size_t)ch * taps + tap] : 0.f;
+                        float v = 0.f;
+                        if (tap >= 0 && ch < C) {
+                            const float wv = W.data[(size_t)ch * taps + tap];
+                            const half_t hv = (half_t)wv;
+                            v = row < 9 ? (float)hv : (wv - (float)hv) * 2048.f;
+                        }
                         bb.at<half_t>(of)[(i * 64 + l) * 8 + e8] = (half_t)v;
                     }
             n.small[key + ".frag"] = of;
@@ -435,9 +448,9 @@ static int build_device_weights(moe_net& n, int precision)
 // =====================================================================================================
 namespace {
 
-static int conv_impl()   // MOE_CONV_IMPL = sp (default) | pp | v1
+static int conv_impl()   // MOE_CONV_IMPL = sp (default: conv3x3_sp.hip for the 3x3 / 64-channel layers) | v1 (the generic kernel everywhere; debugging)
 {
-    static const int impl = [] { const char* e = getenv("MOE_CONV_IMPL"); return !e ? 2 : (!strcmp(e, "v1") ? 0 : (!strcmp(e, "pp") ? 1 : 2)); }();
+    static const int impl = [] { const char* e = getenv("MOE_CONV_IMPL"); return (e && !strcmp(e, "v1")) ? 0 : 2; }();
     return impl;
 }
 
@@ -447,18 +460,19 @@ struct Fwd {
     int B, h, w;
     Arena ar;
     bool x3, direct;
+    bool mixed = false;          // MOE_PREC_MIXED: fp16 operands, fp32-equivalent (hi + lo) trunk stream, split operands on selected layers
     bool y_vec = false;
     float* acc32 = nullptr;
     size_t acc32_elems = 0;
     half_t* side16 = nullptr;    // fp16 sum of the two low-order products of a 3x3 conv (split precision), output layout
     bool dry() const { return ar.base == nullptr; }
 
-    Act act(long long pixels, int ch = 64)
+    Act act(long long pixels, int ch = 64, bool want_lo = false)
     {
         Act a;
         // + 2 KiB slack: the branch-free conv epilogue parks its predicated-off lanes just behind the last element
         a.hi = (half_t*)ar.take((size_t)pixels * ch * 2 + 2048);
-        if (x3) a.lo = (half_t*)ar.take((size_t)pixels * ch * 2 + 2048);
+        if (x3 || want_lo) a.lo = (half_t*)ar.take((size_t)pixels * ch * 2 + 2048);
         return a;
     }
     template <typename T> T* blob(size_t off) const { return (T*)(n.blob + off); }
@@ -475,13 +489,34 @@ struct Fwd {
         launch_nhwc_to_nchw_f32(a.hi, a.lo, t.dev, B, H, W, cs, C, s);
     }
 
+    // live timing (bench.py's roofline legs): a hipEvent pair on the launch stream around the launches of a layer whose key matches
+    // one of the profile substrings.  Returns the record index or -1.
+    int prof_begin(const std::string& key, double flops)
+    {
+        for (size_t i = 0; i < n.prof_keys.size(); ++i) {
+            if (key.find(n.prof_keys[i]) == std::string::npos) continue;
+            if (n.prof_used == n.prof_ev.size()) {
+                moe_net::ProfRec r;
+                if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return -1;
+                n.prof_ev.push_back(r);
+            }
+            moe_net::ProfRec& r = n.prof_ev[n.prof_used];
+            r.key = (int)i; r.flops = flops;
+            (void)hipEventRecord(r.e0, s);
+            return (int)n.prof_used++;
+        }
+        return -1;
+    }
+    void prof_end(int rec) { if (rec >= 0) (void)hipEventRecord(n.prof_ev[rec].e1, s); }
+
     // one convolution layer: in [B][H][W][64*nseg] -> out [B][H*r][W*r][r>1 ? 64 : 64*nchunks]
     // returns false only when asked for the fused tail (tplanes != nullptr) and the fused kernel cannot take the layer
     bool conv(const std::string& key, const Act& in, const Act& out, const Act* res, int H, int W, const half_t* plane_w = nullptr,
               const half_t* plane_w_lo = nullptr, const half_t* tail_w = nullptr, float* tplanes = nullptr,
-              const float* tail1_w = nullptr, float* tail1_out = nullptr)
+              const float* tail1_w = nullptr, float* tail1_out = nullptr, bool exact = false)
     {
         if (dry()) return true;
+        const bool x3 = this->x3 || exact;      // split operands for this layer (every layer under FP16X3, selected ones under MIXED)
         const ConvLayer& L = n.convs[n.conv_index.at(key)];
         const int out_cs = L.r > 1 ? 64 : 64 * L.nchunks;
         if (direct) {
@@ -521,19 +556,18 @@ struct Fwd {
         a.dbg = dbg;
         a.tail_w = tail_w; a.tplanes = tplanes;
         a.tail1_w = tail1_w; a.tail1_out = tail1_out;
-        // MOE_CONV_IMPL = sp (default: software-pipelined epilogue) | pp (two-group ping-pong) | v1 (generic kernel)
-        const int impl = conv_impl();
-        const bool pp = L.taps == 9 && L.nseg == 1 && !L.per_plane && impl != 0;
-        if (tplanes && !(pp && impl == 2 && !x3)) return false;
+        // 3x3 / 64-input-channel layers with shared weights run on the software-pipelined kernel (conv3x3_sp.hip); everything else
+        // (1x1 convs, SEDN's per-plane `trans`, epilogues that kernel does not compile, MOE_CONV_IMPL=v1) on the generic one
+        const bool fast = L.taps == 9 && L.nseg == 1 && !L.per_plane && conv_impl() == 2;
+        if (tplanes && !(fast && !x3)) return false;
         bool fused_ok = true;
         auto launch = [&](const ConvArgs& ca) {
-            if (pp && impl == 2 && launch_conv3x3_sp(ca, s)) return;
+            if (fast && launch_conv3x3_sp(ca, s)) return;
             if (ca.tplanes) { fused_ok = false; return; }
-            if (pp) launch_conv3x3_pp(ca, s);
-            else launch_conv_mfma(ca, L.taps, L.nseg, s);
+            launch_conv_mfma(ca, L.taps, L.nseg, s);
         };
         static const std::string trace_key = [] { const char* e = getenv("MOE_TRACE_KEY"); return std::string(e ? e : "convt_R1.up1"); }();
-        if (!x3 && (dbg & 64) && pp && key == trace_key) {   // timing trace of one launch -> /tmp/moe_trace.bin
+        if (!x3 && (dbg & 64) && fast && key == trace_key) {   // timing trace of one launch -> /tmp/moe_trace.bin
             unsigned long long* tr = nullptr;
             const size_t nb = 8 * 32 * 4 * 16 * 8;
             if (hipMalloc((void**)&tr, nb) == hipSuccess) {
@@ -548,32 +582,30 @@ struct Fwd {
                 return true;
             }
         }
+        if (!x3 && res && res->lo && out.lo) {
+            // MIXED, single-pass layer on the trunk stream: fp16 operands, but the residual is read as hi + lo * 2^-11, added in fp32
+            // and the sum stored as hi and lo again (the split-precision final epilogue with the residual's low part as its addend):
+            // the stream x + s*conv2(...) is carried to ~22 bits through the six ARSBs, only the MFMA operand is its fp16 part
+            ConvArgs q = a; q.acc_mode = 3; q.side16 = res->lo; q.out_lo = out.lo; q.res_lo = nullptr;
+            const int rec = prof_begin(key, 2.0 * (double)B * H * W * L.cout * L.cin * L.taps);
+            const bool ok = fast && launch_conv3x3_sp(q, s);
+            prof_end(rec);
+            return ok;
+        }
         if (!x3) {
-            const bool prof = !n.prof_key.empty() && key.find(n.prof_key) != std::string::npos;
-            if (prof) {
-                if (n.prof_used == n.prof_ev.size()) {
-                    hipEvent_t e0, e1;
-                    if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) n.prof_ev.push_back({e0, e1});
-                }
-                if (n.prof_used < n.prof_ev.size()) (void)hipEventRecord(n.prof_ev[n.prof_used].first, s);
-            }
+            const int rec = prof_begin(key, 2.0 * (double)B * H * W * L.cout * L.cin * L.taps);   // algorithmic (real channel counts)
             launch(a);
-            if (prof && n.prof_used < n.prof_ev.size()) {
-                (void)hipEventRecord(n.prof_ev[n.prof_used].second, s);
-                n.prof_used += 1;
-                n.prof_flops += 2.0 * (double)B * H * W * L.cout * L.cin * L.taps;   // algorithmic (real channel counts)
-            }
+            prof_end(rec);
             return fused_ok;
         }
-        if (L.has_x3 && !pp) {
+        if (L.has_x3 && !fast) {
             // 1x1 conv: all three products in one launch (K segments (w_lo, a_hi), (w_hi, a_lo), (w_hi, a_hi)); the activations are
             // read once per product from L2/HBM and nothing goes through the fp32 side buffer (2.6x less traffic than three passes)
             ConvArgs f4 = a; f4.wpk = blob<half_t>(L.w_x3); f4.acc_mode = 4; f4.in_lo = in.lo; f4.out_lo = out.lo; f4.res_lo = res ? res->lo : nullptr;
             launch_conv_mfma(f4, 1, 3, s);
             return true;
         }
-        static const bool sp_low = [] { const char* e = getenv("MOE_X3_SP"); return !(e && !strcmp(e, "0")); }();
-        if (pp && impl == 2 && sp_low && L.nchunks <= 16) {
+        if (fast && L.nchunks <= 16) {
             // 3x3 conv: the two low-order products run on the fast kernel as ordinary fp16-output convolutions --
             //   side = conv(w_lo, a_hi)            (plain epilogue)
             //   side = conv(w_hi, a_lo) + side     (residual epilogue, in place)
@@ -585,11 +617,12 @@ struct Fwd {
             ConvArgs q2 = q1; q2.in = in.lo; q2.wpk = blob<half_t>(L.w_hi); q2.res = side16;
             if (launch_conv3x3_sp(q1, s) && launch_conv3x3_sp(q2, s)) {
                 ConvArgs q3 = a; q3.acc_mode = 3; q3.side16 = side16; q3.out_lo = out.lo; q3.res_lo = nullptr;   // res_lo is inside side16
-                if (!launch_conv3x3_sp(q3, s)) launch_conv3x3_pp(q3, s);
-                return true;
+                if (launch_conv3x3_sp(q3, s)) return true;
+                // (a final epilogue the fast kernel does not compile, e.g. a PReLU slope above 1: redo the layer through the fp32 side buffer)
             }
         }
         // hi/lo split: (w_lo * a_hi) -> acc32,  += (w_hi * a_lo),  then (w_hi * a_hi) + acc32/2048 and the epilogue
+        if (!acc32) return false;                               // (MIXED carries no fp32 side buffer)
         a.acc32 = acc32;
         ConvArgs p1 = a; p1.wpk = L.per_plane ? plane_w_lo : blob<half_t>(L.w_lo); p1.acc_mode = 1; p1.res = nullptr; p1.bias = nullptr;
         launch(p1);
@@ -616,6 +649,43 @@ size_t acc32_need(const moe_net& n, int B, int h, int w)
     return best;
 }
 
+int exact_blocks_of(const moe_net& n)
+{
+    // leading ARSBs with split operands under MOE_PREC_MIXED.  Emulated error budget (tools/emu_precision.py), worst
+    // of uniform-noise tiles: Net4x 7.6e-4 / 6.2e-4 / 5.1e-4 with 0 / 1 / 3 blocks; Net2x (whose trunk is 61 % of the net and whose
+    // output swing is three times larger) 1.3e-3 / 9.1e-4 / 6.2e-4 / 3.7e-4 with 0 / 1 / 3 / 6; NetDN 7.8e-4 / 6.5e-4 / 5.0e-4 with 0 / 1 / 3
+    if (n.exact_blocks >= 0) return n.exact_blocks > 6 ? 6 : n.exact_blocks;
+    static const int env = [] { const char* e = getenv("MOE_EXACT_BLOCKS"); return e ? atoi(e) : -1; }();
+    if (env >= 0) return env > 6 ? 6 : env;
+    switch (n.arch) {
+        case MOE_ARCH_NET2X: return 6;
+        case MOE_ARCH_NET3X: return 2;
+        case MOE_ARCH_NET4X: return 1;
+        case MOE_ARCH_NETDN: return 1;
+        default: return 0;
+    }
+}
+
+// The fast 3x3 kernel addresses its stores, residual loads and tap planes with 32-bit BYTE offsets.  Bytes one plane of h x w
+// pixels occupies in the largest tensor such a launch touches (so that planes-per-launch = 2^32 / this):
+//   trunk / LR layers            128 B per pixel (64 fp16 channels; SEDN's 256-channel rblock.4 output 512 B when unfused)
+//   upsampler stage k output     128 B * r^(2(k+1)) per input pixel; the LAST stage stores no tensor when the tail is fused,
+//                                its nine fp32 tap planes take 36 B per output pixel instead
+long long sp_bytes_per_pixel(const moe_net& n)
+{
+    long long per = 128;
+    if (n.arch == MOE_ARCH_SEDN) per = 512;
+    if (n.arch == MOE_ARCH_NET2X || n.arch == MOE_ARCH_NET3X || n.arch == MOE_ARCH_NET4X) {
+        long long rr = 1;
+        for (int st = 0; st < n.stages; ++st) {
+            rr *= (long long)n.r * n.r;
+            per = std::max(per, st == n.stages - 1 ? 36 * rr : 128 * rr);     // (the unfused fallback of the last stage runs on the 64-bit kernels)
+        }
+    }
+    return per;
+}
+constexpr long long kSpRange = (1ll << 32) - (1ll << 16);
+
 bool can_fuse_tail(const moe_net& n, const Fwd& f, int B, int h, int w)
 {
     static const bool off = [] { const char* e = getenv("MOE_FUSE_TAIL"); return e && !strcmp(e, "0"); }();
@@ -624,7 +694,7 @@ bool can_fuse_tail(const moe_net& n, const Fwd& f, int B, int h, int w)
     long long sc = 1;
     for (int s = 0; s < n.stages; ++s) sc *= n.r;
     if ((w * (sc / n.r)) % 4 != 0) return false;            // the fused kernel stores tap planes four input columns at a time
-    if (9ll * B * h * sc * w * sc >= (1ll << 32) - 4096) return false;
+    if (sp_bytes_per_pixel(n) * B * h * w > kSpRange) return false;    // (forward_dev keeps every launch set inside this range)
     for (const char* br : {"u", "convt_R1"}) {
         const auto it = n.conv_index.find(std::string(br) + ".up" + std::to_string(n.stages - 1));
         if (it == n.conv_index.end() || n.convs[it->second].slope > 1.f) return false;
@@ -642,6 +712,11 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         f.acc32_elems = acc32_need(n, B, h, w);
         f.acc32 = (float*)f.ar.take(f.acc32_elems * 4);
         f.side16 = (half_t*)f.ar.take(f.acc32_elems * 2 + 4096);
+    } else if (f.mixed) {
+        f.side16 = (half_t*)f.ar.take((size_t)P * 64 * 2 + 4096);     // split-operand layers exist at the input resolution only
+        bool steep = false;                                            // a PReLU slope above 1 takes the layer off the fast kernel's final pass
+        for (int i = 1; i <= exact_blocks_of(n); ++i) steep = steep || n.convs[n.conv_index.at("c1_" + std::to_string(i))].slope > 1.f;
+        if (steep) { f.acc32_elems = (size_t)P * 64; f.acc32 = (float*)f.ar.take(f.acc32_elems * 4); }
     }
 
     auto stem = [&](const Act& out) {
@@ -657,7 +732,7 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         TailArgs a{};
         a.in0 = r->hi; a.w0 = f.small<half_t>("tail_r");
         if (u) { a.in1 = u->hi; a.w1 = f.small<half_t>("tail_u"); }
-        if (f.x3) {
+        if (r->lo && (!u || u->lo)) {     // split operands (FP16X3; MIXED on NetDN, whose tail convs read the hi + lo stream directly)
             a.in0_lo = r->lo; a.w0_lo = f.small<half_t>("tail_r.lo");
             if (u) { a.in1_lo = u->lo; a.w1_lo = f.small<half_t>("tail_u.lo"); }
         }
@@ -667,17 +742,33 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
     };
 
     if (n.arch == MOE_ARCH_NET2X || n.arch == MOE_ARCH_NET3X || n.arch == MOE_ARCH_NET4X || n.arch == MOE_ARCH_NETDN) {
-        Act A = f.act(P), Bb = f.act(P), Cc = f.act(P);
+        // MIXED (the default of these nets): the stem output and the trunk stream are kept as hi + lo pairs; conv_input2 and the first
+        // `nx` ARSBs run with split operands (three products, ~fp32), the others with fp16 operands and the fp32-equivalent residual
+        // add (see Fwd::conv).  DESIGN.md section 5 has the error budget behind this choice.
+        const bool mixed = f.mixed;
+        const int nx = mixed ? exact_blocks_of(n) : 0;
+        Act A = f.act(P, 64, mixed), Bb = f.act(P, 64, mixed), Cc = f.act(P, 64, mixed && nx > 0);
         stem(A);
         f.tap("stem", A, h, w, 64, n.C);
-        f.conv("input2", A, Bb, nullptr, h, w);
+        auto trunk_conv = [&](const std::string& key, const Act& in, const Act& out, const Act* res, bool exact) {
+            if (!f.conv(key, in, out, res, h, w, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, exact))
+                return fail(MOE_EINVAL, "layer %s: %d planes of %dx%d exceed the conv kernel's addressing range (use smaller tiles)", key.c_str(), B, h, w);
+            return (int)MOE_OK;
+        };
+        if (int rc = trunk_conv("input2", A, Bb, nullptr, mixed)) return rc;
         f.tap("input2", Bb, h, w, 64, n.C);
         for (int i = 1; i <= 6; ++i) {
-            f.conv("c1_" + std::to_string(i), Bb, Cc, nullptr, h, w);
-            f.conv("c2_" + std::to_string(i), Cc, Bb, &Bb, h, w);
+            const bool ex = mixed && i <= nx;
+            Act m = Cc;
+            if (mixed && !ex) m.lo = nullptr;                    // single-pass ARSB: conv_1's output is an fp16 operand only
+            Act bin = Bb;
+            if (mixed && !ex) bin.lo = nullptr;
+            if (int rc = trunk_conv("c1_" + std::to_string(i), bin, m, nullptr, ex)) return rc;
+            if (int rc = trunk_conv("c2_" + std::to_string(i), m, Bb, &Bb, ex)) return rc;
             f.tap("arsb" + std::to_string(i), Bb, h, w, 64, n.C);
         }
         if (n.arch == MOE_ARCH_NETDN) { tail(&Bb, &A, h, w, false); return MOE_OK; }
+        if (mixed) { A.lo = nullptr; Bb.lo = nullptr; }          // the upsampler convs take the fp16 parts
         // two upsampler branches: R on the trunk output, U on the stem output (models.py:117-123)
         Act fin[2];
         float* tp[2] = {nullptr, nullptr};
@@ -851,9 +942,13 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
 size_t workspace_need(moe_net& n, int B, int h, int w)
 {
     Fwd f{n, nullptr, B, h, w, Arena{}, n.precision == MOE_PREC_FP16X3, n.precision == MOE_PREC_DEBUG_DIRECT};
+    f.mixed = n.precision == MOE_PREC_MIXED;
     run_forward(n, f, nullptr, MOE_F32, 0, 0, 0, nullptr, nullptr, MOE_F32, nullptr);
     return f.ar.off + 4096;
 }
+
+int forward_dev_chunk(moe_net& n, const void* x, int x_dtype, int B, int h, int w, long long sB, long long sH, long long sW,
+                      const long long* x_off_dev, void* y, int y_dtype, const long long* y_off_dev, hipStream_t s, bool y_off_mult8);
 
 int forward_dev(moe_net& n, const void* x, int x_dtype, int B, int h, int w, long long sB, long long sH, long long sW,
                 const long long* x_off_dev, void* y, int y_dtype, const long long* y_off_dev, hipStream_t s, bool y_off_mult8 = true)
@@ -862,6 +957,30 @@ int forward_dev(moe_net& n, const void* x, int x_dtype, int B, int h, int w, lon
     if (B < 1 || h < 1 || w < 1) return fail(MOE_EINVAL, "moe_net_forward: bad shape B=%d h=%d w=%d", B, h, w);
     if ((x_dtype != MOE_F32 && x_dtype != MOE_F16) || (y_dtype != MOE_F32 && y_dtype != MOE_F16))
         return fail(MOE_EINVAL, "moe_net_forward: x/y dtype must be MOE_F32 or MOE_F16");
+    // planes per launch set: whatever the caller batched (whole-image tiles under cropsize 'auto', MOE_TILES_PER_BATCH ...), a launch
+    // never leaves the fast kernel's addressing range -- larger batches are run as several launch sets
+    const long long bmax = kSpRange / (sp_bytes_per_pixel(n) * (long long)h * w);
+    if (bmax < 1)
+        return fail(MOE_ENOMEM, "a %dx%d tile exceeds the convolution kernels' addressing range (%lld pixels per plane at most for this net): use a smaller cropsize",
+                    h, w, kSpRange / sp_bytes_per_pixel(n));
+    if (B <= bmax) return forward_dev_chunk(n, x, x_dtype, B, h, w, sB, sH, sW, x_off_dev, y, y_dtype, y_off_dev, s, y_off_mult8);
+    const size_t xe = x_dtype == MOE_F32 ? 4 : 2, ye = y_dtype == MOE_F32 ? 4 : 2;
+    const long long yplane = (long long)h * n.scale * w * n.scale;
+    for (int b0 = 0; b0 < B; b0 += (int)bmax) {
+        const int cnt = (int)std::min<long long>(bmax, B - b0);
+        const void* xc = x_off_dev ? x : (const void*)((const char*)x + (size_t)b0 * sB * xe);
+        void* yc = y_off_dev ? y : (void*)((char*)y + (size_t)b0 * yplane * ye);
+        const bool al = y_off_mult8 && (y_off_dev || ((size_t)b0 * yplane * ye) % 16 == 0);
+        int rc = forward_dev_chunk(n, xc, x_dtype, cnt, h, w, sB, sH, sW, x_off_dev ? x_off_dev + b0 : nullptr, yc, y_dtype,
+                                   y_off_dev ? y_off_dev + b0 : nullptr, s, al);
+        if (rc) return rc;
+    }
+    return MOE_OK;
+}
+
+int forward_dev_chunk(moe_net& n, const void* x, int x_dtype, int B, int h, int w, long long sB, long long sH, long long sW,
+                      const long long* x_off_dev, void* y, int y_dtype, const long long* y_off_dev, hipStream_t s, bool y_off_mult8)
+{
     int cur = -1;
     HIP_TRY(hipGetDevice(&cur));
     if (cur != n.device) HIP_TRY(hipSetDevice(n.device));
@@ -873,6 +992,7 @@ int forward_dev(moe_net& n, const void* x, int x_dtype, int B, int h, int w, lon
         n.ws_bytes = need;
     }
     Fwd f{n, s, B, h, w, Arena{n.ws, 0}, n.precision == MOE_PREC_FP16X3, n.precision == MOE_PREC_DEBUG_DIRECT};
+    f.mixed = n.precision == MOE_PREC_MIXED;
     f.y_vec = y_off_mult8 && ((uintptr_t)y % 16 == 0);   // every output plane starts 16-byte aligned: wide stores allowed
     int rc = run_forward(n, f, x, x_dtype, sB, sH, sW, x_off_dev, y, y_dtype, y_off_dev);
     if (rc) return rc;
@@ -1001,7 +1121,7 @@ void moe_net_destroy(moe_net* n)
     if (n->blob) (void)hipFree(n->blob);
     if (n->ws) (void)hipFree(n->ws);
     for (auto& t : n->taps) if (t.second.dev) (void)hipFree(t.second.dev);
-    for (auto& ev : n->prof_ev) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (auto& ev : n->prof_ev) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); }
     delete n;
 }
 
@@ -1041,8 +1161,10 @@ int moe_net_set_param(moe_net* n, const char* name, const float* data, const int
 int moe_net_finalize(moe_net* n, int device, int precision)
 {
     if (!n) return fail(MOE_EINVAL, "moe_net_finalize: NULL net");
-    if (precision != MOE_PREC_FP16 && precision != MOE_PREC_FP16X3 && precision != MOE_PREC_DEBUG_DIRECT)
+    if (precision != MOE_PREC_FP16 && precision != MOE_PREC_FP16X3 && precision != MOE_PREC_DEBUG_DIRECT && precision != MOE_PREC_MIXED)
         return fail(MOE_EINVAL, "moe_net_finalize: unknown precision %d", precision);
+    if (precision == MOE_PREC_MIXED && (n->arch == MOE_ARCH_SEDN || n->arch == MOE_ARCH_LITE))
+        return fail(MOE_EINVAL, "moe_net_finalize: MOE_PREC_MIXED is defined for Net2x/3x/4x and NetDN (use FP16 for SEDN, FP16X3 for lite)");
     std::string missing;
     for (const auto& p : n->params) if (!p.set) missing += (missing.empty() ? "\"" : ", \"") + p.name + "\"";
     if (!missing.empty()) return fail(MOE_ESTATE, "Missing key(s) in state_dict: %s", missing.c_str());
@@ -1089,28 +1211,58 @@ int moe_net_forward(moe_net* n, const void* x, int x_dtype, int B, int h, int w,
     return rc;
 }
 
-int moe_net_set_profile(moe_net* n, const char* layer_substring)
+int moe_net_set_profile(moe_net* n, const char* layer_substrings)
 {
     if (!n) return fail(MOE_EINVAL, "moe_net_set_profile: NULL net");
-    n->prof_key = layer_substring ? layer_substring : "";
+    n->prof_keys.clear();
+    std::string all = layer_substrings ? layer_substrings : "";
+    size_t pos = 0;
+    while (pos <= all.size() && !all.empty()) {
+        const size_t c = all.find(',', pos);
+        const std::string k = all.substr(pos, c == std::string::npos ? std::string::npos : c - pos);
+        if (!k.empty()) n->prof_keys.push_back(k);
+        if (c == std::string::npos) break;
+        pos = c + 1;
+    }
     n->prof_used = 0;
-    n->prof_flops = 0;
+    return MOE_OK;
+}
+
+int moe_net_get_profile_at(moe_net* n, int index, double* total_ms, int64_t* launches, double* flops)
+{
+    if (!n || !total_ms || !launches || !flops) return fail(MOE_EINVAL, "moe_net_get_profile: NULL argument");
+    double ms = 0, fl = 0;
+    int64_t cnt = 0;
+    for (size_t i = 0; i < n->prof_used; ++i) {
+        const moe_net::ProfRec& r = n->prof_ev[i];
+        if (r.key != index) continue;
+        HIP_TRY(hipEventSynchronize(r.e1));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, r.e0, r.e1));
+        ms += t; fl += r.flops; ++cnt;
+    }
+    *total_ms = ms; *launches = cnt; *flops = fl;
     return MOE_OK;
 }
 
 int moe_net_get_profile(moe_net* n, double* total_ms, int64_t* launches, double* flops)
 {
-    if (!n || !total_ms || !launches || !flops) return fail(MOE_EINVAL, "moe_net_get_profile: NULL argument");
-    double ms = 0;
-    for (size_t i = 0; i < n->prof_used; ++i) {
-        HIP_TRY(hipEventSynchronize(n->prof_ev[i].second));
-        float t = 0.f;
-        HIP_TRY(hipEventElapsedTime(&t, n->prof_ev[i].first, n->prof_ev[i].second));
-        ms += t;
-    }
-    *total_ms = ms; *launches = (int64_t)n->prof_used; *flops = n->prof_flops;
-    n->prof_used = 0;
-    n->prof_flops = 0;
+    int rc = moe_net_get_profile_at(n, 0, total_ms, launches, flops);
+    if (rc == MOE_OK) n->prof_used = 0;
+    return rc;
+}
+
+int64_t moe_net_max_tile_pixels(const moe_net* n)
+{
+    if (!n) return fail(MOE_EINVAL, "moe_net_max_tile_pixels: NULL net");
+    return (int64_t)(kSpRange / sp_bytes_per_pixel(*n));
+}
+
+int moe_net_set_exact_blocks(moe_net* n, int blocks)
+{
+    if (!n) return fail(MOE_EINVAL, "moe_net_set_exact_blocks: NULL net");
+    if (blocks < -1 || blocks > 6) return fail(MOE_EINVAL, "moe_net_set_exact_blocks: %d not in -1..6", blocks);
+    n->exact_blocks = blocks;
     return MOE_OK;
 }
 
@@ -1153,6 +1305,7 @@ void moe_plan_destroy(moe_plan* p)
     if (!p) return;
     for (auto& d : p->p.dev) if (d->blob) (void)hipFree(d->blob);
     for (auto& d : p->p.fdev) if (d->blob) (void)hipFree(d->blob);
+    for (auto& c : p->p.custom_off) if (c.dev) (void)hipFree(c.dev);
     if (p->p.pool) (void)hipFree(p->p.pool);
     delete p;
 }
@@ -1207,15 +1360,25 @@ int moe_stitch(const moe_plan* p, int device, const float* tiles_dev, const int6
     int rc = plan_device_tables(p->p, device, C, 0, 0, 0, 0, 1, &d);
     if (rc) return rc;
     long long* toff = nullptr;
-    if (tile_off) {   // caller-defined pool layout: blocking upload
-        HIP_TRY(hipMalloc((void**)&toff, p->p.tiles.size() * 8));
-        HIP_TRY(hipMemcpy(toff, tile_off, p->p.tiles.size() * 8, hipMemcpyHostToDevice));
+    if (tile_off) {   // caller-defined pool layout (e.g. the receive buffer of dist.py): uploaded once per distinct table, then cached on the plan
+        const size_t nt = p->p.tiles.size();
+        for (auto& c : p->p.custom_off)
+            if (c.device == device && c.host.size() == nt && std::equal(c.host.begin(), c.host.end(), tile_off)) { toff = c.dev; break; }
+        if (!toff) {
+            if (p->p.custom_off.size() >= 16) {
+                HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+                (void)hipFree(p->p.custom_off.front().dev);
+                p->p.custom_off.erase(p->p.custom_off.begin());
+            }
+            HIP_TRY(hipMalloc((void**)&toff, nt * 8));
+            HIP_TRY(hipMemcpy(toff, tile_off, nt * 8, hipMemcpyHostToDevice));
+            p->p.custom_off.push_back(CustomOffsets{device, std::vector<long long>(tile_off, tile_off + nt), toff});
+        }
     }
     StitchArgs a{};
     fill_stitch(p->p, *d, a, tiles_dev, toff ? toff : d->tile_off, C, out, out_dtype);
     launch_stitch(a, (hipStream_t)stream);
     hipError_t e = hipGetLastError();
-    if (toff) { HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); HIP_TRY(hipFree(toff)); }
     if (e != hipSuccess) return fail(MOE_EHIP, "stitch launch failed: %s", hipGetErrorString(e));
     return MOE_OK;
 }
@@ -1272,25 +1435,24 @@ int moe_run_plan_ex(moe_net* n, const moe_plan* pl, const void* img, int img_dty
     return MOE_OK;
 }
 
-int moe_run_plan_frames(moe_net* n, const moe_plan* pl, const void* imgs, int img_dtype, int64_t frame_stride,
-                        int64_t sC, int64_t sH, int64_t sW, int n_frames, float* pools, int64_t pool_stride,
-                        int owner_index, int owner_count, int max_tiles, void* stream)
+int moe_run_plan_tiles(moe_net* n, const moe_plan* pl, const void* imgs, int img_dtype, int64_t frame_stride,
+                       int64_t sC, int64_t sH, int64_t sW, int n_frames, float* dst, const int64_t* tile_dst,
+                       int max_tiles, void* stream)
 {
-    if (!n || !pl || !imgs || !pools || n_frames < 1) return fail(MOE_EINVAL, "moe_run_plan_frames: bad argument");
-    if (!n->finalized) return fail(MOE_ESTATE, "moe_run_plan_frames: net is not finalized");
+    if (!n || !pl || !imgs || !dst || !tile_dst || n_frames < 1) return fail(MOE_EINVAL, "moe_run_plan_tiles: bad argument");
+    if (!n->finalized) return fail(MOE_ESTATE, "moe_run_plan_tiles: net is not finalized");
     const Plan& p = pl->p;
-    if (p.sc != n->scale) return fail(MOE_EINVAL, "moe_run_plan_frames: plan scale %d != net scale %d", p.sc, n->scale);
-    if (owner_count < 1) { owner_count = 1; owner_index = 0; }
-    if (owner_index < 0 || owner_index >= owner_count) return fail(MOE_EINVAL, "moe_run_plan_frames: owner %d of %d", owner_index, owner_count);
-    if (pool_stride < (int64_t)p.pool_elems_per_plane_set) return fail(MOE_EINVAL, "moe_run_plan_frames: pool stride smaller than one frame's pool");
+    if (p.sc != n->scale) return fail(MOE_EINVAL, "moe_run_plan_tiles: plan scale %d != net scale %d", p.sc, n->scale);
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(n->device));
     const int C = p.C;
+    const long long nt = (long long)p.tiles.size();
     FramesDeviceCache* d = nullptr;
     for (auto& up : p.fdev) {
         FramesDeviceCache& c = *up;
         if (c.blob && c.device == n->device && c.C == C && c.sC == sC && c.sH == sH && c.sW == sW && c.frame_stride == frame_stride &&
-            c.pool_stride == pool_stride && c.n_frames == n_frames && c.owner_index == owner_index && c.owner_count == owner_count) { d = &c; break; }
+            c.n_frames == n_frames && c.tile_dst.size() == (size_t)(nt * n_frames) &&
+            std::equal(c.tile_dst.begin(), c.tile_dst.end(), tile_dst)) { d = &c; break; }
     }
     if (!d) {
         if (p.fdev.size() >= 8) {
@@ -1300,7 +1462,6 @@ int moe_run_plan_frames(moe_net* n, const moe_plan* pl, const void* imgs, int im
         }
         p.fdev.push_back(std::make_unique<FramesDeviceCache>());
         d = p.fdev.back().get();
-        const long long nt = (long long)p.tiles.size();
         std::vector<long long> xo, yo;
         int slot = 0;
         for (const auto& g : p.groups) {      // same-shaped tiles of ALL frames share launches
@@ -1309,11 +1470,12 @@ int moe_run_plan_frames(moe_net* n, const moe_plan* pl, const void* imgs, int im
             const long long plane = (long long)(g.th * p.sc) * (g.tw * p.sc);
             for (int f = 0; f < n_frames; ++f)
                 for (int k : g.tiles) {
-                    if ((f * nt + k) % owner_count != owner_index) continue;
+                    const long long at = tile_dst[(long long)f * nt + k];
+                    if (at < 0) continue;                                  // not computed by this call
                     const TileRect& t = p.tiles[k];
                     for (int c = 0; c < C; ++c) {
                         xo.push_back((long long)f * frame_stride + (long long)c * sC + (long long)t.top * sH + (long long)t.left * sW);
-                        yo.push_back((long long)f * pool_stride + p.tile_off[k] + (long long)c * plane);
+                        yo.push_back(at + (long long)c * plane);
                     }
                     ++slot; ++cnt;
                 }
@@ -1326,8 +1488,8 @@ int moe_run_plan_frames(moe_net* n, const moe_plan* pl, const void* imgs, int im
         d->x_off = (long long*)d->blob; d->y_off = d->x_off + xo.size();
         HIP_TRY(hipMemcpy(d->x_off, xo.data(), xo.size() * 8, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d->y_off, yo.data(), yo.size() * 8, hipMemcpyHostToDevice));
-        d->device = n->device; d->C = C; d->sC = sC; d->sH = sH; d->sW = sW; d->frame_stride = frame_stride; d->pool_stride = pool_stride;
-        d->n_frames = n_frames; d->owner_index = owner_index; d->owner_count = owner_count;
+        d->device = n->device; d->C = C; d->sC = sC; d->sH = sH; d->sW = sW; d->frame_stride = frame_stride;
+        d->n_frames = n_frames; d->tile_dst.assign(tile_dst, tile_dst + nt * n_frames);
     }
     if (max_tiles <= 0) {
         max_tiles = 4;
@@ -1335,18 +1497,35 @@ int moe_run_plan_frames(moe_net* n, const moe_plan* pl, const void* imgs, int im
     }
     for (size_t gi = 0; gi < p.groups.size(); ++gi) {
         const auto& g = p.groups[gi];
-        const int nt = d->group_count[gi];
-        if (nt < 1) continue;
+        const int ntl = d->group_count[gi];
+        if (ntl < 1) continue;
         const long long px = (long long)g.th * g.tw;
-        const int per = (int)std::max<long long>(1, std::min<long long>(nt, (long long)max_tiles * 65536 / std::max<long long>(px, 1)));
-        for (int t0 = 0; t0 < nt; t0 += per) {
-            const int cnt = std::min(per, nt - t0);
+        const int per = (int)std::max<long long>(1, std::min<long long>(ntl, (long long)max_tiles * 65536 / std::max<long long>(px, 1)));
+        for (int t0 = 0; t0 < ntl; t0 += per) {
+            const int cnt = std::min(per, ntl - t0);
             const long long slot = (long long)(d->group_first[gi] + t0) * C;
-            int rc = forward_dev(*n, imgs, img_dtype, cnt * C, g.th, g.tw, 0, sH, sW, d->x_off + slot, pools, MOE_F32, d->y_off + slot, s, d->y_mult8);
+            int rc = forward_dev(*n, imgs, img_dtype, cnt * C, g.th, g.tw, 0, sH, sW, d->x_off + slot, dst, MOE_F32, d->y_off + slot, s, d->y_mult8);
             if (rc) return rc;
         }
     }
     return MOE_OK;
+}
+
+int moe_run_plan_frames(moe_net* n, const moe_plan* pl, const void* imgs, int img_dtype, int64_t frame_stride,
+                        int64_t sC, int64_t sH, int64_t sW, int n_frames, float* pools, int64_t pool_stride,
+                        int owner_index, int owner_count, int max_tiles, void* stream)
+{
+    if (!n || !pl || !imgs || !pools || n_frames < 1) return fail(MOE_EINVAL, "moe_run_plan_frames: bad argument");
+    const Plan& p = pl->p;
+    if (owner_count < 1) { owner_count = 1; owner_index = 0; }
+    if (owner_index < 0 || owner_index >= owner_count) return fail(MOE_EINVAL, "moe_run_plan_frames: owner %d of %d", owner_index, owner_count);
+    if (pool_stride < (int64_t)p.pool_elems_per_plane_set) return fail(MOE_EINVAL, "moe_run_plan_frames: pool stride smaller than one frame's pool");
+    const long long nt = (long long)p.tiles.size();
+    std::vector<int64_t> at((size_t)(nt * n_frames));
+    for (int f = 0; f < n_frames; ++f)
+        for (long long k = 0; k < nt; ++k)
+            at[(size_t)(f * nt + k)] = ((f * nt + k) % owner_count == owner_index) ? (int64_t)f * pool_stride + p.tile_off[(size_t)k] : -1;
+    return moe_run_plan_tiles(n, pl, imgs, img_dtype, frame_stride, sC, sH, sW, n_frames, pools, at.data(), max_tiles, stream);
 }
 
 int moe_run_plan(moe_net* n, const moe_plan* pl, const void* img, int img_dtype, int64_t sC, int64_t sH, int64_t sW,

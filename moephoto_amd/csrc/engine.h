@@ -36,15 +36,18 @@ struct PlanDeviceCache {       // device-side tables of a plan for one (layout, 
     float* ramp = nullptr;
 };
 
-struct FramesDeviceCache {     // offset tables of one multi-frame sharded run (moe_run_plan_frames), cached per layout
-    int device = -1, C = 0, n_frames = 0, owner_index = 0, owner_count = 1;
-    int64_t sC = 0, sH = 0, sW = 0, frame_stride = 0, pool_stride = 0;
+struct FramesDeviceCache {     // offset tables of one multi-frame sharded run (moe_run_plan_tiles), cached per layout
+    int device = -1, C = 0, n_frames = 0;
+    int64_t sC = 0, sH = 0, sW = 0, frame_stride = 0;
+    std::vector<long long> tile_dst;             // host copy of the (frame, tile) -> destination table the device tables were built from
     bool y_mult8 = false;
     std::vector<int> group_first, group_count;   // per plan group: first slot / number of owned (frame, tile) pairs
     void* blob = nullptr;
     long long* x_off = nullptr;
     long long* y_off = nullptr;
 };
+
+struct CustomOffsets { int device; std::vector<long long> host; long long* dev; };   // a caller-defined tile layout for moe_stitch
 
 struct TileGroup { int th, tw; std::vector<int> tiles; int first_slot; };   // same-shaped tiles, slots in x_off order
 
@@ -60,6 +63,7 @@ struct Plan {
     size_t pool_elems_per_plane_set = 0;
     mutable std::vector<std::unique_ptr<PlanDeviceCache>> dev;   // a few entries at most (one per shard/layout seen)
     mutable std::vector<std::unique_ptr<FramesDeviceCache>> fdev;
+    mutable std::vector<CustomOffsets> custom_off;
     mutable float* pool = nullptr;     // internal per-tile fp32 results (when the caller passes none)
     mutable size_t pool_elems = 0;
 };

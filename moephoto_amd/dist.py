@@ -8,17 +8,26 @@ embarrassingly parallel decomposition with ONE exchange step:
   ownership   (frame f, tile k) flattened round-robin:  owner = (f * n_tiles + k) % world
   stitcher    frame f is folded by rank f % world  -> with `world` frames in flight every rank computes
               n_tiles tiles and stitches exactly one frame (weak scaling, balanced)
-  exchange    one all_to_all_single of packed fp32 tile results: every rank sends the tiles it computed
-              to the frame's stitcher (point-to-point traffic, all 7 xGMI links of a GPU busy at once;
-              a ring collective would be bound by one link)
+  exchange    one all_to_all_single of fp32 tile results: every rank sends the tiles it computed to the
+              frame's stitcher (point-to-point traffic, all 7 xGMI links of a GPU busy at once; a ring
+              collective would be bound by one link)
   weights     broadcast once from rank 0 (flattened state dict)
 
-Everything in `TileExchange` is index arithmetic + collectives on plain tensors, so it runs unchanged
-under gloo on CPU (tests/test_dist_cpu.py); `run_frames` adds the engine calls.
+Nothing is copied around the collective.  `TileExchange` lays ONE device buffer out once per plan,
+
+    [ own | recv from rank 0 | recv from rank 1 | ... | send to rank 0 | send to rank 1 | ... ]
+
+and hands the engine a (frame, tile) -> offset table (moe_run_plan_tiles): the net writes every tile it owns
+straight into its slot of the send region (or of `own` when this rank is also the frame's stitcher), the
+all-to-all moves send -> recv inside that buffer, and moe_stitch reads each frame's tiles through a second
+offset table -- wherever in `own`/`recv` they landed.  Segment lists, split sizes and both tables are plain
+index arithmetic, computed in __init__ and reused every step; they run unchanged under gloo on CPU
+(tests/test_dist_cpu.py).
 """
 import ctypes
 from collections import OrderedDict
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -26,64 +35,89 @@ from . import _lib
 
 
 class TileExchange(object):
-    def __init__(self, n_tiles, tile_off, pool_elems, rank, world, group=None):
-        self.n_tiles, self.rank, self.world, self.group = int(n_tiles), int(rank), int(world), group
-        self.off = [int(v) for v in tile_off] + [int(pool_elems)]
-        self.pool_elems = int(pool_elems)
+    """Layout of the exchange buffer for `n_frames` frames of one tile plan on `world` ranks.
 
+    tile_elems[k] = fp32 elements of tile k's result (all C planes)."""
+
+    def __init__(self, tile_elems, n_frames, rank, world, group=None):
+        self.sizes = [int(v) for v in tile_elems]
+        self.n_tiles, self.n_frames = len(self.sizes), int(n_frames)
+        self.rank, self.world, self.group = int(rank), int(world), group
+        r, W, nt = self.rank, self.world, self.n_tiles
+        self.mine = [f for f in range(self.n_frames) if self.stitcher(f) == r]
+        # where this rank WRITES its tiles (engine table) and where it READS the tiles of the frames it stitches
+        self.tile_dst = np.full((self.n_frames, nt), -1, np.int64)
+        self.stitch_off = {f: np.full(nt, -1, np.int64) for f in self.mine}
+        pos = 0
+        for f in self.mine:                                   # own: computed here, stitched here
+            for k in self.tiles_of(f, r):
+                self.tile_dst[f, k] = self.stitch_off[f][k] = pos
+                pos += self.sizes[k]
+        self.own_elems = pos
+        self.recv_split = []
+        for src in range(W):                                  # recv: computed by src, stitched here (wire order = _segments)
+            n0 = pos
+            if src != r:
+                for f, k in self._segments(src, r):
+                    self.stitch_off[f][k] = pos
+                    pos += self.sizes[k]
+            self.recv_split.append(pos - n0)
+        self.recv_elems = pos - self.own_elems
+        self.send_split = []
+        for dst in range(W):                                  # send: computed here, stitched by dst
+            n0 = pos
+            if dst != r:
+                for f, k in self._segments(r, dst):
+                    self.tile_dst[f, k] = pos
+                    pos += self.sizes[k]
+            self.send_split.append(pos - n0)
+        self.send_elems = pos - self.own_elems - self.recv_elems
+        self.total_elems = pos
+        for f in self.mine:
+            assert (self.stitch_off[f] >= 0).all()
+        self._tile_dst_c = (ctypes.c_int64 * self.tile_dst.size)(*self.tile_dst.reshape(-1).tolist())
+        self._stitch_c = {f: (ctypes.c_int64 * nt)(*v.tolist()) for f, v in self.stitch_off.items()}
+
+    # ---- index arithmetic ----------------------------------------------------------------------------
     def owner(self, frame, tile):
         return (frame * self.n_tiles + tile) % self.world
 
     def stitcher(self, frame):
         return frame % self.world
 
-    def shard_of(self, frame, rank=None):
-        """(shard_index, shard_count) such that tile k belongs to `rank` iff k % count == index."""
-        r = self.rank if rank is None else rank
-        return (r - frame * self.n_tiles) % self.world, self.world
-
     def tiles_of(self, frame, rank):
-        idx, cnt = self.shard_of(frame, rank)
-        return [k for k in range(self.n_tiles) if k % cnt == idx]
+        return [k for k in range(self.n_tiles) if self.owner(frame, k) == rank]
 
-    def _segments(self, src, dst, frames):
+    def _segments(self, src, dst):
         """(frame, tile) pairs computed by `src` whose stitcher is `dst`, in wire order."""
-        return [(f, k) for f in frames if self.stitcher(f) == dst for k in self.tiles_of(f, src)]
+        return [(f, k) for f in range(self.n_frames) if self.stitcher(f) == dst for k in self.tiles_of(f, src)]
 
-    def exchange(self, pools):
-        """pools: {frame: 1-D fp32 tensor of pool_elems} holding this rank's tiles.  After the call the
-        pools of the frames this rank stitches are complete.  Returns those frames."""
-        frames = sorted(pools.keys())
-        mine = [f for f in frames if self.stitcher(f) == self.rank]
-        if self.world == 1:
-            return mine
-        any_pool = pools[frames[0]]
-        send_parts, send_split, recv_split = [], [], []
-        for dst in range(self.world):
-            seg = [] if dst == self.rank else self._segments(self.rank, dst, frames)
-            send_split.append(sum(self.off[k + 1] - self.off[k] for _, k in seg))
-            send_parts += [pools[f][self.off[k]:self.off[k + 1]] for f, k in seg]
-        for src in range(self.world):
-            seg = [] if src == self.rank else self._segments(src, self.rank, frames)
-            recv_split.append(sum(self.off[k + 1] - self.off[k] for _, k in seg))
-        send = torch.cat(send_parts) if send_parts else any_pool.new_empty(0)
+    def signature(self):
+        """Order-sensitive digest of everything the ranks must agree on (checked once per layout in run_frames)."""
+        h = 1469598103934665603
+        for v in [self.n_tiles, self.n_frames, self.world] + self.sizes:
+            h = ((h ^ int(v)) * 1099511628211) % (1 << 61)
+        return h
+
+    # ---- the collective --------------------------------------------------------------------------------
+    def exchange(self, buf):
+        """buf: 1-D fp32 tensor of total_elems holding this rank's tiles at tile_dst.  After the call the `own` + `recv`
+        regions hold every tile of the frames this rank stitches (read them through stitch_off)."""
+        if self.world == 1 and not FORCE_COLLECTIVE:
+            return self.mine
+        a, b = self.own_elems, self.own_elems + self.recv_elems
+        recv, send = buf[a:b], buf[b:b + self.send_elems]
         if send.is_cuda and dist.get_backend(self.group) == 'gloo':
             # test mode (several ranks sharing one GPU, MOE_DIST_BACKEND=gloo): stage through the host
-            recv_h = torch.empty(sum(recv_split), dtype=send.dtype)
-            dist.all_to_all_single(recv_h, send.cpu(), recv_split, send_split, group=self.group)
-            recv = recv_h.to(send.device)
+            recv_h = torch.empty(self.recv_elems, dtype=send.dtype)
+            dist.all_to_all_single(recv_h, send.cpu(), self.recv_split, self.send_split, group=self.group)
+            recv.copy_(recv_h)
         else:
-            recv = any_pool.new_empty(sum(recv_split))
-            dist.all_to_all_single(recv, send, recv_split, send_split, group=self.group)
-        pos = 0
-        for src in range(self.world):
-            if src == self.rank:
-                continue
-            for f, k in self._segments(src, self.rank, frames):
-                n = self.off[k + 1] - self.off[k]
-                pools[f][self.off[k]:self.off[k + 1]] = recv[pos:pos + n]
-                pos += n
-        return mine
+            dist.all_to_all_single(recv, send, self.recv_split, self.send_split, group=self.group)
+        return self.mine
+
+
+FORCE_COLLECTIVE = False      # tests: issue the all-to-all even on a world of one rank (exercises the RCCL path on a 1-GPU box)
 
 
 def broadcast_state_dict(sd, src=0, device=None, group=None):
@@ -107,19 +141,59 @@ def broadcast_state_dict(sd, src=0, device=None, group=None):
     return out
 
 
+def _agreed_plan(opt, shape, group, device):
+    """One tile plan for all ranks.  With an explicit cropsize the plan is a pure function of the shape; with cropsize
+    'auto' it depends on free memory, which differs between ranks -- the MINIMUM over the ranks is used so that every rank
+    derives the same grid (different grids would desynchronise the all-to-all split sizes)."""
+    from .config import config
+    from .imageProcess import EngineModule, prepare
+    key = ('dist',) + tuple(int(v) for v in shape[-3:])
+    plan = opt._plans.get(key)
+    if plan is not None:
+        return plan[0]
+    free = config.calcFreeMem()
+    if dist.get_world_size(group) > 1:
+        t = torch.tensor([float(free)], dtype=torch.float64, device=device if dist.get_backend(group) != 'gloo' else None)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        free = float(t.item())
+    model = opt.modelCached
+    if isinstance(model, EngineModule):
+        free = min(free, model.max_tile_pixels() * key[1] * key[1] / opt.ramCoef)
+    it = prepare(key[1:], free, opt, opt.padding, opt.scale, opt.align, opt.cropsize)[0]
+    opt._plans[key] = [it.plan, 0]
+    return it.plan
+
+
 def run_frames(opt, frames, group=None, out_dtype=None, max_tiles_per_batch=0):
     """Tile-parallel doCrop over a list of equally-shaped (C,H,W) frames that every rank holds
     (broadcast them first).  Returns {frame index: stitched (C, sc*H, sc*W) tensor} for the frames
     this rank stitches."""
-    from .imageProcess import _plan_for, _DT
+    from .imageProcess import _DT
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     model = opt.modelCached
     x0 = frames[0]
-    plan = _plan_for(opt, x0.shape)
-    C = x0.shape[0]
-    ex = TileExchange(plan.n_tiles, plan.tile_offsets(C), plan.pool_elems(C), rank, world, group)
-    L = _lib.lib()
     dev = x0.device
+    plan = _agreed_plan(opt, x0.shape, group, dev)
+    C = x0.shape[0]
+    cache = opt.__dict__.setdefault('_exchanges', {})
+    ck = (id(plan), len(frames), rank, world, C)
+    ent = cache.get(ck)
+    if ent is None:
+        off = plan.tile_offsets(C) + [plan.pool_elems(C)]
+        ex = TileExchange([off[k + 1] - off[k] for k in range(plan.n_tiles)], len(frames), rank, world, group)
+        if world > 1:       # every rank must have derived the same layout
+            sig = torch.tensor([ex.signature()], dtype=torch.int64, device=dev if dist.get_backend(group) != 'gloo' else None)
+            lo, hi = sig.clone(), sig.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+            if int(lo.item()) != int(hi.item()):
+                raise RuntimeError('run_frames: the ranks derived different tile plans (pass an explicit cropsize)')
+        buf = torch.empty(ex.total_elems, dtype=torch.float32, device=dev)
+        ent = cache[ck] = (ex, buf)
+        while len(cache) > 4:
+            cache.pop(next(iter(cache)))
+    ex, buf = ent
+    L = _lib.lib()
     stream = torch.cuda.current_stream(dev).cuda_stream
     padded = [plan.padImage(x) for x in frames]
     # one launch set for ALL frames: same-shaped tiles of different frames share batches (a rank owns only n_tiles/world tiles
@@ -132,17 +206,16 @@ def run_frames(opt, frames, group=None, out_dtype=None, max_tiles_per_batch=0):
         stacked = torch.stack(padded)            # frames are not slices of one tensor: gather them once
         padded = list(stacked.unbind(0))
         fstride = stacked.stride(0)
-    all_pools = torch.empty((len(frames), ex.pool_elems), dtype=torch.float32, device=dev)
-    pools = {f: all_pools[f] for f in range(len(frames))}
     sC, sH, sW = padded[0].stride()
-    _lib.check(L.moe_run_plan_frames(model._h, plan._h, padded[0].data_ptr(), _DT[padded[0].dtype], int(fstride), sC, sH, sW,
-                                     len(frames), ctypes.c_void_p(all_pools.data_ptr()), int(ex.pool_elems), rank, world,
-                                     int(max_tiles_per_batch), stream))
-    mine = ex.exchange(pools)
+    _lib.check(L.moe_run_plan_tiles(model._h, plan._h, padded[0].data_ptr(), _DT[padded[0].dtype], int(fstride), sC, sH, sW,
+                                    len(frames), ctypes.c_void_p(buf.data_ptr()), ex._tile_dst_c, int(max_tiles_per_batch), stream))
+    for p in padded:
+        p.record_stream(torch.cuda.current_stream(dev))
+    mine = ex.exchange(buf)
     out = {}
     odt = out_dtype if out_dtype is not None else x0.dtype
     for f in mine:
         y = torch.empty((C, plan.outH, plan.outW), dtype=odt, device=dev)
-        _lib.check(L.moe_stitch(plan._h, dev.index or 0, pools[f].data_ptr(), None, C, y.data_ptr(), _DT[odt], stream))
+        _lib.check(L.moe_stitch(plan._h, dev.index or 0, buf.data_ptr(), ex._stitch_c[f], C, y.data_ptr(), _DT[odt], stream))
         out[f] = y
     return out

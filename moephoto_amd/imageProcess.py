@@ -31,6 +31,7 @@ log = logging.getLogger('Moe')
 modelCache = {}
 weightCache = {}
 minSize = 28
+PLAN_CACHE = 4           # tile plans (with their device pools) kept per Option: an image shape and its transposed twin for the ensemble, x2
 identity = lambda x, *_, **__: x
 apply = lambda v, f: f(v)
 _DT = {torch.float32: _lib.F32, torch.float16: _lib.F16}
@@ -200,19 +201,27 @@ def _plan_for(opt, shape):
     re-plans every 29 calls to follow free memory -- here the plan only depends on free memory when
     cropsize is 'auto', and is then re-derived with the same cadence."""
     key = tuple(int(v) for v in shape[-3:])
-    ent = opt._plans.get(key)
+    ent = opt._plans.pop(key, None)
     if ent is None or (opt.cropsize <= 0 and ent[1] > 28):
         try:
             freeMem = config.calcFreeMem()
         except Exception:
             raise MemoryError('Can not calculate free memory.')
+        model = opt.modelCached
+        if isinstance(model, EngineModule):
+            # the planner's pixel budget is ram * ramCoef / C^2 (solveRam with fixChannel = 0): keep it within the largest
+            # tile the convolution kernels address, however much memory is free (288 GB would otherwise plan whole 8K images)
+            freeMem = min(freeMem, model.max_tile_pixels() * key[0] * key[0] / opt.ramCoef)
         it, padImage, unpad, outShape, bl = prepare(key, freeMem, opt, opt.padding, opt.scale, opt.align, opt.cropsize)
         ent = [it.plan, 0]
+        while len(opt._plans) >= PLAN_CACHE:       # each plan owns a device tile pool of ~1.1x its output image: keep a few, drop the
+            opt._plans.pop(next(iter(opt._plans)))   # least recently used (the reference keeps exactly one, re-planning on a shape change)
         opt._plans[key] = ent
         opt.iterClip, opt.padImage, opt.unpad, opt.blend = it, padImage, unpad, bl
         opt.outShape = list(outShape)
     else:
         ent[1] += 1
+        opt._plans[key] = ent                      # re-inserted last = most recently used
     return ent[0]
 
 

@@ -47,9 +47,11 @@ class EngineModule(object):
         self._dtype = torch.float32
         self._finalized_key = None
         self.training = False
-        # 'auto': fp16 operands for the deep 64-channel nets (Net2x/3x/4x, SEDN: <= 1e-3 vs the fp32 reference on
-        # natural images), hi/lo-split operands for the cheap 48-channel nets (NetDN, lite*) whose fp16 activation
-        # rounding alone costs 1-3e-3.  MOE_PRECISION=fp16 forces the single-pass mode everywhere.
+        # 'auto' = the cheapest arithmetic that stays within 1e-3 of the fp32 reference on every input class:
+        #   'mixed'  Net2x/3x/4x, NetDN: fp16 MFMA operands, hi+lo trunk stream, split operands on the few layers that set the error
+        #   'fp16'   SEDN (4-6e-4 as it is)
+        #   'fp16x3' lite* (every layer of these shallow 48-channel nets is error-critical)
+        # MOE_PRECISION=fp16 forces the single-pass mode everywhere (the arithmetic of the reference's own GPU fp16 mode).
         self.precision = os.environ.get('MOE_PRECISION', 'auto')
 
     def __del__(self):
@@ -158,8 +160,19 @@ class EngineModule(object):
 
     def resolved_precision(self):
         if self.precision == 'auto':
-            return 'fp16x3' if self.ARCH in (_lib.ARCH_NETDN, _lib.ARCH_LITE) else 'fp16'
+            return {_lib.ARCH_LITE: 'fp16x3', _lib.ARCH_SEDN: 'fp16'}.get(self.ARCH, 'mixed')
+        if self.precision == 'mixed' and self.ARCH in (_lib.ARCH_LITE, _lib.ARCH_SEDN):
+            return 'fp16x3' if self.ARCH == _lib.ARCH_LITE else 'fp16'       # 'mixed' is defined for the ARSB nets only
         return self.precision
+
+    def max_tile_pixels(self):
+        """Largest tile (pixels per plane) one forward accepts; the planner's budget is clamped to it."""
+        return int(_lib.check(_lib.lib().moe_net_max_tile_pixels(self._h)))
+
+    def set_exact_blocks(self, blocks):
+        """'mixed' precision: number of leading ARSBs computed with split operands (0..6, -1 = architecture default)."""
+        _lib.check(_lib.lib().moe_net_set_exact_blocks(self._h, int(blocks)))
+        return self
 
     def _finalize(self):
         key = (self._device.index, self.resolved_precision())
@@ -190,14 +203,24 @@ class EngineModule(object):
     __call__ = forward
 
     # ---- live kernel timing (bench.py roofline leg) -----------------------------------------------------
-    def set_profile(self, layer_substring):
-        _lib.check(_lib.lib().moe_net_set_profile(self._h, layer_substring.encode() if layer_substring else None))
+    def set_profile(self, layer_substrings):
+        """Comma-separated layer-key substrings to time (None: off), e.g. 'up1,c2_'."""
+        self._prof_n = len([k for k in (layer_substrings or '').split(',') if k])
+        _lib.check(_lib.lib().moe_net_set_profile(self._h, layer_substrings.encode() if layer_substrings else None))
         return self
 
-    def get_profile(self):
+    def get_profile(self, all_keys=False):
+        """Summed kernel time / launches / algorithmic FLOPs of the first profiled substring (a dict), or of each one (a list,
+        all_keys=True), since set_profile; resets the recording."""
+        L = _lib.lib()
+        out = []
+        for i in range(max(1, getattr(self, '_prof_n', 1)) if all_keys else 1):
+            ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+            _lib.check(L.moe_net_get_profile_at(self._h, i, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)))
+            out.append(dict(total_ms=ms.value, launches=n.value, flops=fl.value))
         ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
-        _lib.check(_lib.lib().moe_net_get_profile(self._h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)))
-        return dict(total_ms=ms.value, launches=n.value, flops=fl.value)
+        _lib.check(L.moe_net_get_profile(self._h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)))     # (resets)
+        return out if all_keys else out[0]
 
     # ---- debugging -----------------------------------------------------------------------------------
     def set_debug(self, flag=True):

@@ -1,0 +1,159 @@
+"""CPU emulation of the engine's arithmetic modes -- the error budget behind MOE_PREC_MIXED.
+
+Test infrastructure (like oracle/): a functional fp32 forward of Net2x/3x/4x and NetDN (python/models.py:108-164 of the
+reference) in which each convolution's weights and/or input activations can be rounded to fp16, and the trunk stream
+(x + s*conv2(PReLU(conv1(x))), models.py:76-80) can be stored as fp16 or kept in fp32.  fp32 accumulation is what the MFMA
+kernels do, so `F.conv2d` on rounded operands models them up to summation order.
+
+  python tests/emu_precision.py layers a2      per-layer contribution of weight / activation rounding
+  python tests/emu_precision.py budget         max-abs error of fp16 / mixed(n) on noise and natural tiles, all ARSB nets
+
+Used by tests/test_precision_budget.py (CPU suite) to pin the defaults of `exact_blocks_of` in engine.cpp.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+for _p in (HERE, os.path.dirname(HERE)):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+import golden_defs as gd  # noqa: E402
+
+
+def r16(x):
+    return x.half().float()
+
+
+def prelu(x, a):
+    return torch.where(x >= 0, x, x * a)
+
+
+def shuffle(x, r):
+    B, C, H, W = x.shape
+    c = C // (r * r)
+    return x.view(B, c, r, r, H, W).permute(0, 1, 4, 2, 5, 3).reshape(B, c, H * r, W * r)
+
+
+def layer_names(arch):
+    trunk = ['input2'] + [n for i in range(1, 7) for n in ('c1_%d' % i, 'c2_%d' % i)]
+    if arch == 'netdn':
+        return trunk + ['r.tail', 'u.tail']
+    st = 2 if arch == 'net4x' else 1
+    out = list(trunk)
+    for tag in ('r', 'u'):
+        out += ['%s.up%d' % (tag, k) for k in range(st)] + [tag + '.tail']
+    return out
+
+
+def forward(arch, sd, x, w16=(), a16=(), stream16=False):
+    """w16 / a16: names of the convs whose weights / input activations are rounded to fp16 ('all' = every conv);
+    stream16: the trunk stream is stored as fp16 after conv_input2 and after every ARSB."""
+    T = lambda k: torch.from_numpy(np.asarray(sd[k], dtype=np.float32))
+    r = 3 if arch == 'net3x' else 2
+
+    def conv(name, v, w, b=None):
+        if name in w16 or 'all' in w16:
+            w = r16(w)
+        if name in a16 or 'all' in a16:
+            v = r16(v)
+        return F.conv2d(v, w, b, padding=1)
+    x = torch.from_numpy(np.asarray(x, dtype=np.float32))
+    out = prelu(F.conv2d(x, T('conv_input.weight'), padding=1), float(T('relu.weight')[0]))       # the stem is fp32 in every mode
+    t = conv('input2', out, T('conv_input2.weight'))
+    if stream16:
+        t = r16(t)
+    for i in range(1, 7):
+        p = 'convt_F{}.0.'.format(i)
+        m = prelu(conv('c1_%d' % i, t, T(p + 'conv_1.weight')), float(T(p + 'relu.weight')[0]))
+        t = t + conv('c2_%d' % i, m, T(p + 'conv_2.weight') * float(T(p + 'scale.scale')[0]))    # ScaleLayer folded into the weights (fp32 product)
+        if stream16:
+            t = r16(t)
+    if arch == 'netdn':
+        return conv('r.tail', t, T('convt_R1.weight')) + conv('u.tail', out, T('u.weight'))
+
+    def ups(pre, tag, v):
+        k = 0
+        while '{}{}.0.weight'.format(pre, k) in sd:
+            p = '{}{}.'.format(pre, k)
+            v = conv('%s.up%d' % (tag, k), v, T(p + '0.weight'), T(p + '0.bias'))
+            v = prelu(shuffle(v, r), float(T(p + '2.weight')[0]))
+            k += 1
+        return conv('%s.tail' % tag, v, T('{}{}.weight'.format(pre, k)))
+    return ups('convt_R1.', 'r', t) + ups('u.', 'u', out)
+
+
+def mode_sets(arch, mode, n_exact=0):
+    """(w16, a16, stream16) of an engine precision mode."""
+    L = set(layer_names(arch))
+    if mode == 'fp32':
+        return set(), set(), False
+    if mode == 'fp16':
+        return L, L, True
+    if mode == 'mixed':
+        # exact: conv_input2 and the first n ARSBs (split operands); the tails' WEIGHTS (low-order rows of the fused tail GEMM, or the
+        # split-operand tail kernel of NetDN, which also takes the hi+lo activations); hi+lo stream
+        ex = {'input2'} | {'c%d_%d' % (j, i) for i in range(1, n_exact + 1) for j in (1, 2)}
+        tails = {'r.tail', 'u.tail'}
+        w16 = L - ex - tails
+        a16 = L - ex - (tails if arch == 'netdn' else set())
+        return w16, a16, False
+    raise ValueError(mode)
+
+
+def max_err(arch, sd, x, mode, n_exact=0, want=None):
+    with torch.no_grad():
+        if want is None:
+            want = forward(arch, sd, x)
+        w16, a16, s16 = mode_sets(arch, mode, n_exact)
+        return float((forward(arch, sd, x, w16, a16, s16) - want).abs().max())
+
+
+DEFAULT_EXACT = {'net2x': 6, 'net3x': 2, 'net4x': 1, 'netdn': 1}      # == exact_blocks_of() in engine.cpp
+
+
+def _load(key):
+    from moephoto_amd.weights import load_state_dict_file
+    return gd.state_dict_for(key, load_state_dict_file)
+
+
+def main(argv):
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    cmd = argv[1] if len(argv) > 1 else 'budget'
+    if cmd == 'layers':
+        key = argv[2] if len(argv) > 2 else 'a2'
+        arch, sd = gd.MODELS[key][0], _load(key)
+        for kind, shape in (('natural', (3, 40, 264)), ('noise', (3, 96, 96))):
+            x = (gd.natural_image(5, shape) if kind == 'natural' else gd.noise_image(5, shape))[:, None]
+            with torch.no_grad():
+                want = forward(arch, sd, x)
+                print(key, kind, 'fp16 everywhere %.2e' % max_err(arch, sd, x, 'fp16', want=want),
+                      ' stream rounding alone %.2e' % float((forward(arch, sd, x, stream16=True) - want).abs().max()))
+                for L in layer_names(arch):
+                    ew = float((forward(arch, sd, x, w16={L}) - want).abs().max())
+                    ea = float((forward(arch, sd, x, a16={L}) - want).abs().max())
+                    print('  %-8s weights fp16: %.2e   input activations fp16: %.2e' % (L, ew, ea), flush=True)
+        return
+    for key in ('a2', 'a3', 'a4', 'dn_lite5', 'dn_lite10', 'dn_lite15'):
+        arch, sd = gd.MODELS[key][0], _load(key)
+        for kind, shape, seed in (('noise', (3, 96, 96), 5), ('noise-u8', (3, 256, 256), 0), ('natural', (3, 40, 264), 5)):
+            if kind == 'natural':
+                x = gd.natural_image(seed, shape)
+            elif kind == 'noise':
+                x = gd.noise_image(seed, shape)
+            else:
+                x = (gd.noise_u8(seed, shape).astype(np.float32) / 255.0)
+            x = x[:, None]
+            with torch.no_grad():
+                want = forward(arch, sd, x)
+            line = '%-9s %-8s %s: fp16 %.2e' % (key, kind, shape[1:], max_err(arch, sd, x, 'fp16', want=want))
+            for n in (0, 1, 2, 3, 6):
+                line += ' | mixed n=%d %.2e' % (n, max_err(arch, sd, x, 'mixed', n, want))
+            print(line + '   (default n=%d)' % DEFAULT_EXACT[arch], flush=True)
+
+
+if __name__ == '__main__':
+    main(sys.argv)

@@ -22,29 +22,35 @@ shape, sc, pad, crop, frames = (2, 70, 90), 2, 5, 40, 5
 pl = oplanner.prepare(shape, 1 << 40, 1e-3, pad, sc, 8, crop)
 C = shape[0]
 sizes = [C * (t[1] - t[0]) * (t[3] - t[2]) * sc * sc for t in pl.tiles]
-off = [0] + list(np.cumsum(sizes))[:-1]
-ex = TileExchange(len(pl.tiles), off, sum(sizes), rank, world)
-# every (frame, tile) has exactly one owner and the shard formula agrees with it
+nt = len(pl.tiles)
+ex = TileExchange(sizes, frames, rank, world)
+# every (frame, tile) has exactly one owner; the engine table marks exactly the owned tiles; regions do not overlap
 for f in range(frames):
-    owners = [[r for r in range(world) if k in ex.tiles_of(f, r)] for k in range(len(pl.tiles))]
+    owners = [[r for r in range(world) if k in ex.tiles_of(f, r)] for k in range(nt)]
     assert all(len(o) == 1 and o[0] == ex.owner(f, k) for k, o in enumerate(owners))
+    assert [k for k in range(nt) if ex.tile_dst[f, k] >= 0] == ex.tiles_of(f, rank)
+spans = sorted((int(ex.tile_dst[f, k]), int(ex.tile_dst[f, k]) + sizes[k]) for f in range(frames) for k in range(nt) if ex.tile_dst[f, k] >= 0)
+assert all(a1 >= b0 for (_, b0), (a1, _) in zip(spans, spans[1:])) and spans[-1][1] <= ex.total_elems
+assert ex.own_elems + ex.recv_elems + ex.send_elems == ex.total_elems
+sigs = [None] * world
+dist.all_gather_object(sigs, ex.signature())
+assert len(set(sigs)) == 1
 def tile_value(f, k):
     t = pl.tiles[k]
     return np.random.default_rng(1000 * f + k).random((C, (t[1] - t[0]) * sc, (t[3] - t[2]) * sc), dtype=np.float32)
-pools = {}
-for f in range(frames):
-    p = torch.full((sum(sizes),), float('nan'))
+buf = torch.full((ex.total_elems,), float('nan'))
+for f in range(frames):                      # what moe_run_plan_tiles does with ex.tile_dst
     for k in ex.tiles_of(f, rank):
-        p[off[k]:off[k] + sizes[k]] = torch.from_numpy(tile_value(f, k).reshape(-1))
-    pools[f] = p
-mine = ex.exchange(pools)
-assert mine == [f for f in range(frames) if f % world == rank]
-for f in mine:
-    assert not torch.isnan(pools[f]).any()
-    tiles = [pools[f][off[k]:off[k] + sizes[k]].numpy().reshape(tile_value(f, k).shape) for k in range(len(pl.tiles))]
-    want = ostitch.fold_stitch([tile_value(f, k) for k in range(len(pl.tiles))], pl, sc)
-    got = ostitch.fold_stitch(tiles, pl, sc)
-    assert np.array_equal(got, want)
+        at = int(ex.tile_dst[f, k])
+        buf[at:at + sizes[k]] = torch.from_numpy(tile_value(f, k).reshape(-1))
+for rep in range(2):                         # the layout is reused every step
+    mine = ex.exchange(buf)
+    assert mine == [f for f in range(frames) if f % world == rank]
+    for f in mine:                           # what moe_stitch does with ex.stitch_off[f]
+        tiles = [buf[int(ex.stitch_off[f][k]):int(ex.stitch_off[f][k]) + sizes[k]].numpy().reshape(tile_value(f, k).shape) for k in range(nt)]
+        assert not any(np.isnan(t).any() for t in tiles)
+        want = ostitch.fold_stitch([tile_value(f, k) for k in range(nt)], pl, sc)
+        assert np.array_equal(ostitch.fold_stitch(tiles, pl, sc), want)
 sd = OrderedDict([('a.weight', torch.arange(12.).reshape(3, 4)), ('b', torch.tensor([2.5]))]) if rank == 0 else None
 out = broadcast_state_dict(sd, src=0)
 assert list(out.keys()) == ['a.weight', 'b'] and out['a.weight'].shape == (3, 4) and float(out['b']) == 2.5

@@ -1,21 +1,18 @@
 """Parity of the HIP path (through the C ABI) against the oracle and the reference's golden vectors.
 Needs a HIP device: `pytest -m gpu`.
 
-Tolerances (max-abs, compared in fp32; north star: 1e-3 vs the reference's PyTorch-CPU fp32 path):
-  precision 'auto' (the product default):  fp16 MFMA operands + fp32 accumulate for Net2x/3x/4x and SEDN,
-      hi/lo-split operands (3 MFMA passes) for the 48-channel NetDN / lite nets
-                                  natural-image-like input:   1e-3   NetDN / lite / SEDN
-                                                              1.5e-3 Net2x/3x/4x: single-pass fp16 operands sit at
-                                                                     0.6-1.4e-3 depending on the tile (the rounding floor of
-                                                                     fp16 operands); with precision 'fp16x3'
-                                                                     the same cases are asserted at 2e-5
-                                  white-noise input:          1e-3   NetDN / lite (split operands, observed ~1e-6)
-                                                              5e-3   Net*x / SEDN (adversarial for fp16 operands: the
-                                                                     outputs span [-0.6, 1.8]; measured 0.7-2.5e-3)
-  precision 'fp16x3' forced:      any input, any family:      1e-3   (observed ~1e-6)
-  precision 'fp16' forced (= the arithmetic of the reference's own GPU fp16 mode, fp32 accumulate on top):
-                                  natural: 1e-3 Net*x/SEDN, 2.5e-3 NetDN, 6e-3 lite;  noise: 1e-2
+ONE tolerance for the product's default arithmetic (precision 'auto'), on every input class and every golden:
+
+    TOL = 1e-3 max-abs, compared in fp32        (north star: 1e-3 vs the reference's PyTorch-CPU fp32 path)
+
+'auto' resolves to 'mixed' for Net2x/3x/4x and NetDN (fp16 MFMA operands, hi+lo trunk stream, split operands on the few
+error-setting layers: DESIGN.md section 5, tests/emu_precision.py), 'fp16' for SEDN, 'fp16x3' for lite*.  Other bounds
+in this file belong to explicitly forced, non-default modes and are written where they are used:
+  'fp16x3' forced (hi/lo split operands everywhere)   2e-5   (observed ~1e-6)
+  'fp16' forced (= the arithmetic of the reference's own GPU fp16 mode)   documented per family in
+      test_net_forward_fast_mode_documented_error
   stitch kernel alone (fp32 in/out): 1e-6 (the ramp's sigmoid differs from torch's by <= 1 ulp)
+  fp16 OUTPUT dtype requested by the caller (config.fp16): + 5e-4, the rounding of a value in [1, 2) to half
 """
 import glob
 import os
@@ -31,8 +28,8 @@ from tests_util import oracle_ensemble
 
 pytestmark = pytest.mark.gpu
 G = gd.GOLDEN
-TOL_NATURAL, TOL_NOISE_FP16, TOL_X3 = 1e-3, 5e-3, 1e-3
-TOL_FP16_SR = 1.5e-3      # single-pass fp16 operands on the deep 64-channel nets: 0.6-1.4e-3 depending on the tile
+TOL = 1e-3
+HALF_OUT = 5e-4           # extra allowance when the caller asks for an fp16 result tensor (values up to 2: half an ulp = 4.9e-4)
 
 
 @pytest.fixture(scope='module')
@@ -69,12 +66,11 @@ def test_net_forward_vs_reference_golden(key, dev):
     h, w = [int(v) for v in z['hw']]
     seed = int(z['seed'])
     m = module_for(key)
-    split = m.resolved_precision() == 'fp16x3'
-    for kind, tol in (('natural', TOL_NATURAL if split else TOL_FP16_SR), ('noise', TOL_X3 if split else TOL_NOISE_FP16)):
+    for kind in ('natural', 'noise'):
         x = gd.natural_image(seed, (3, h, w))[:, None] if kind == 'natural' else gd.noise_image(seed, (3, 1, h, w))
         y = m(torch.from_numpy(x).to(dev))[-1].float().cpu().numpy()
         err = np.abs(y - z['y_' + kind]).max()
-        assert err <= tol, '{} {}: {:.3e}'.format(key, kind, err)
+        assert err <= TOL, '{} {} ({}): {:.3e}'.format(key, kind, m.resolved_precision(), err)
 
 
 @pytest.mark.parametrize('key', NET_KEYS)
@@ -84,7 +80,7 @@ def test_net_forward_fast_mode_documented_error(key, dev):
     h, w = [int(v) for v in z['hw']]
     seed = int(z['seed'])
     arch = gd.MODELS[key][0]
-    tol_nat = TOL_FP16_SR if arch in ('net2x', 'net3x', 'net4x', 'sedn') else (2.5e-3 if arch == 'netdn' else 6e-3)
+    tol_nat = 1.5e-3 if arch in ('net2x', 'net3x', 'net4x', 'sedn') else (2.5e-3 if arch == 'netdn' else 6e-3)
     m = module_for(key, 'fp16')
     for kind, tol in (('natural', tol_nat), ('noise', 1e-2)):
         x = gd.natural_image(seed, (3, h, w))[:, None] if kind == 'natural' else gd.noise_image(seed, (3, 1, h, w))
@@ -117,9 +113,10 @@ def test_layer_by_layer(key, dev):
     for name, want in taps.items():
         got = m.debug_tap(name)
         want = want.numpy()
-        scale = max(1.0, float(np.abs(want).max()))
+        scale = max(1.0, float(np.abs(want).max()))      # intermediates are not normalised to [0, 1]: the bound is relative to their swing
         assert got.shape == want.shape, name
-        assert np.abs(got - want).max() <= 4e-3 * scale, '{} {}: {:.3e}'.format(key, name, np.abs(got - want).max())
+        tol = (2e-3 if arch == 'sedn' else 1e-3) * scale      # SEDN: fp16 operands through 16 blocks (its OUTPUT is held to TOL elsewhere)
+        assert np.abs(got - want).max() <= tol, '{} {}: {:.3e} (swing {:.2f})'.format(key, name, np.abs(got - want).max(), scale)
     m.set_debug(False)
 
 
@@ -135,21 +132,22 @@ def test_ragged_and_tiny_tiles(dev):
         y = mx(xs)[-1]
         assert y.shape == (3, 1, 2 * h, 2 * w) and y.dtype == torch.float32
         assert np.abs(y.cpu().numpy() - want).max() <= 2e-5, (h, w)
-    mf = module_for('a2', 'fp16')
-    x = gd.natural_image(9, (3, 40, 264))[:, None]
+    mf = module_for('a2')                             # the default arithmetic (fused tail kernel, hi+lo stream)
+    x = gd.natural_image(9, (3, 40, 264))[:, None]    # the busiest tile of the sweep: 1.3-1.4e-3 with plain fp16 operands
     y = mf(torch.from_numpy(x).to(dev))[-1].cpu().numpy()
-    assert np.abs(y - onets.forward('net2x', sd, x).numpy()).max() <= 2e-3        # single-pass fp16 operands on a busy tile: 1.4e-3
-    for (h, w) in ((9, 35), (24, 52), (16, 42)):      # fused-tail kernel: widths that are odd / 4-aligned only / 2-aligned (fallback paths)
-        x = gd.natural_image(11, (3, h, w))[:, None]
-        y = mf(torch.from_numpy(x).to(dev))[-1].cpu().numpy()
-        assert np.abs(y - onets.forward('net2x', sd, x).numpy()).max() <= 2e-3, (h, w)
+    assert np.abs(y - onets.forward('net2x', sd, x).numpy()).max() <= TOL
+    for (h, w) in ((9, 35), (24, 52), (16, 42), (8, 16), (88, 192)):      # fused-tail kernel: widths that are odd / 4-aligned only / 2-aligned (fallback paths)
+        for kind in ('natural', 'noise'):
+            x = (gd.natural_image(11, (3, h, w)) if kind == 'natural' else gd.noise_image(11, (3, h, w)))[:, None]
+            y = mf(torch.from_numpy(x).to(dev))[-1].cpu().numpy()
+            assert np.abs(y - onets.forward('net2x', sd, x).numpy()).max() <= TOL, (h, w, kind)
     m16 = module_for('a2', dtype=torch.float16)
     x = gd.natural_image(9, (4, 40, 48))[:, None]                                 # 4 planes: RGBA through SR
     x16 = torch.from_numpy(x).half()
     y = m16(x16.to(dev))[-1]
     assert y.dtype == torch.float16
     want = onets.forward('net2x', sd, x16.float().numpy()).numpy()                # same fp16-quantised input
-    assert np.abs(y.float().cpu().numpy() - want).max() <= 2.5e-3                 # + fp16 rounding of the output
+    assert np.abs(y.float().cpu().numpy() - want).max() <= TOL + HALF_OUT
 
 
 def test_sedn_fused_block_tail_shapes(dev):
@@ -162,27 +160,42 @@ def test_sedn_fused_block_tail_shapes(dev):
         x = gd.natural_image(13, (bn, h, w))[:, None]
         want = onets.forward('sedn', sd, x).numpy()
         got = mf(torch.from_numpy(x).to(dev))[-1].cpu().numpy()
-        assert np.abs(got - want).max() <= TOL_NATURAL, (bn, h, w, float(np.abs(got - want).max()))
+        assert np.abs(got - want).max() <= TOL, (bn, h, w, float(np.abs(got - want).max()))
     mx = module_for('l25', 'fp16x3')
     x = gd.natural_image(13, (3, 24, 56))[:, None]
     assert np.abs(mx(torch.from_numpy(x).to(dev))[-1].cpu().numpy() - onets.forward('sedn', sd, x).numpy()).max() <= 2e-5
 
 
-def test_config5_tile_size_vs_independent_device_kernel(dev):
-    """BASELINE config 5 uses 512-px tiles (2048x2048 output per plane).  A CPU oracle run at that size takes minutes, so the
-    MFMA path (software-pipelined convs, fused tail) is checked against the engine's independent scalar device convolution
-    (MOE_PREC_DEBUG_DIRECT: plain OIHW fp32 weights, pixel shuffle by formula, separate tail kernel) on one full 512x512 tile,
-    and the top-left 96x96 corner of the same tile against the CPU oracle of that corner's receptive field."""
-    sd = gd.state_dict_for('a4', load_state_dict_file)
-    x = gd.natural_image(21, (3, 512, 512))[:, None]
+def test_config5_512px_tiles(dev):
+    """BASELINE config 5 in miniature (8K -> 32K with 512-px overlapped tiles): a 1100x1100 RGB image, a4, crop_sr = 512
+    -> 3x3 = 9 tiles (four full 512x512 ones = 2048x2048 outputs per plane, ragged last row / column).  The whole
+    device doCrop runs; one full tile and the ragged corner tile are compared with the oracle, and the stitched 4400x4400 canvas
+    with the oracle's closed-form fold of the engine's own tile results."""
+    import ctypes
+    from moephoto_amd import _lib, imageProcess as ip
+    opt = _opt_sr('a', 4, 512)
+    x = gd.natural_image(55, (3, 1100, 1100))
     xd = torch.from_numpy(x).to(dev)
-    y_fast = module_for('a4', 'fp16')(xd)[-1]
-    y_ref = module_for('a4', 'debug_direct')(xd)[-1]
-    assert y_fast.shape == (3, 1, 2048, 2048)
-    assert float((y_fast - y_ref).abs().max()) <= 2e-3            # both carry fp16 activation rounding; weights fp16 vs fp32
-    # corner: outputs within 96 px of the top-left only depend on inputs within 96 + 40 px (17 conv layers + margin)
-    want = onets.forward('net4x', sd, np.ascontiguousarray(x[:, :, :136, :136])).numpy()[:, :, :384, :384]
-    assert np.abs(y_fast[:, :, :384, :384].cpu().numpy() - want).max() <= TOL_FP16_SR
+    plan = ip._plan_for(opt, xd.shape)
+    assert plan.n_tiles == 9 and plan.tiles[0][:4] == (0, 512, 0, 512)
+    pool = torch.zeros(plan.pool_elems(3), dtype=torch.float32, device=dev)
+    out = torch.empty((3, plan.outH, plan.outW), dtype=torch.float32, device=dev)
+    sC, sH, sW = xd.stride()
+    _lib.check(_lib.lib().moe_run_plan_ex(opt.modelCached._h, plan._h, xd.data_ptr(), _lib.F32, sC, sH, sW, out.data_ptr(), _lib.F32, 0,
+                                          ctypes.c_void_p(pool.data_ptr()), 0, 1, 1, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert torch.equal(out, ip.doCrop(opt, xd))
+    off = plan.tile_offsets(3)
+    sd = gd.state_dict_for('a4', load_state_dict_file)
+    for k in (4, 8):           # the interior 512x512 tile and the ragged bottom-right corner
+        top, bottom, left, right = plan.tiles[k][:4]
+        want = onets.forward('net4x', sd, np.ascontiguousarray(x[:, None, top:bottom, left:right])).numpy()[:, 0]
+        got = pool[off[k]:off[k] + want.size].reshape(want.shape).cpu().numpy()
+        assert np.abs(got - want).max() <= TOL, (k, float(np.abs(got - want).max()))
+    pl = oplanner.prepare((3, 1100, 1100), 1 << 40, 1e-3, 5, 4, 8, 512)
+    hp = pool.cpu().numpy()
+    tiles = [hp[off[k]:off[k] + 3 * (t[1] - t[0]) * (t[3] - t[2]) * 16].reshape(3, (t[1] - t[0]) * 4, (t[3] - t[2]) * 4) for k, t in enumerate(pl.tiles)]
+    assert np.abs(out.cpu().numpy() - ostitch.fold_stitch(tiles, pl, 4)).max() <= 1e-6
 
 
 STITCH_ONLY = [os.path.basename(p)[:-4] for p in sorted(glob.glob(os.path.join(G, 'stitch_only', '*.npz')))]
@@ -227,8 +240,8 @@ def _opt_sr(model, scale, crop, ensemble=0, precision='auto', fp16_io=False):
     return opt
 
 
-STITCHED = [('a2_natural', 'a', 2, TOL_FP16_SR), ('a2_noise', 'a', 2, TOL_NOISE_FP16), ('a4_natural', 'a', 4, TOL_FP16_SR),
-            ('lite2_natural', 'lite', 2, TOL_NATURAL), ('a2_onetile_pad', 'a', 2, TOL_FP16_SR)]
+STITCHED = [('a2_natural', 'a', 2, TOL), ('a2_noise', 'a', 2, TOL), ('a4_natural', 'a', 4, TOL),
+            ('lite2_natural', 'lite', 2, TOL), ('a2_onetile_pad', 'a', 2, TOL)]
 
 
 @pytest.mark.parametrize('name,model,scale,tol', STITCHED)
@@ -255,12 +268,12 @@ def test_ensemble_golden(dev):
     x = gd.natural_image(101, (3, 60, 72))
     opt = _opt_sr('a', 2, 48, ensemble=3)
     y = runSR.sr(opt)(torch.from_numpy(x).to(dev))
-    assert np.abs(y.float().cpu().numpy() - z['y']).max() <= TOL_FP16_SR
+    assert np.abs(y.float().cpu().numpy() - z['y']).max() <= TOL
     z = np.load(os.path.join(G, 'stitched', 'a2_ens7.npz'))
     x = gd.noise_image(101, (3, 52, 60))
-    opt = _opt_sr('a', 2, 48, ensemble=7, precision='fp16x3')
+    opt = _opt_sr('a', 2, 48, ensemble=7)          # eight passes over white noise, default arithmetic
     y = runSR.sr(opt)(torch.from_numpy(x).to(dev))
-    assert np.abs(y.float().cpu().numpy() - z['y']).max() <= TOL_X3
+    assert np.abs(y.float().cpu().numpy() - z['y']).max() <= TOL
 
 
 def test_dn_rgbfilter_golden(dev):
@@ -273,11 +286,11 @@ def test_dn_rgbfilter_golden(dev):
     opt = runDN.getOpt({'op': 'DN', 'model': 'lite5', 'strength': 0.6})
     y = ip.RGBFilter(opt)(torch.from_numpy(x).to(dev))
     assert tuple(y.shape) == (4, 64, 80)
-    assert np.abs(y.float().cpu().numpy() - z['y']).max() <= TOL_NATURAL
+    assert np.abs(y.float().cpu().numpy() - z['y']).max() <= TOL
     z = np.load(os.path.join(G, 'stitched', 'dn10_noise.npz'))
     opt = runDN.getOpt({'op': 'DN', 'model': 'lite10'})
     y = ip.RGBFilter(opt)(torch.from_numpy(gd.noise_image(101, (3, 100, 140))).to(dev))
-    assert np.abs(y.float().cpu().numpy() - z['y']).max() <= TOL_X3     # NetDN runs with split operands by default
+    assert np.abs(y.float().cpu().numpy() - z['y']).max() <= TOL     # white noise through NetDN in the default ('mixed') arithmetic
     # SEDN (l25, synthetic weights written in the zoo format)
     from moephoto_amd.weights import save_state_dict_file
     path = '/tmp/moe_synth_l25.pth'
@@ -286,7 +299,7 @@ def test_dn_rgbfilter_golden(dev):
     z = np.load(os.path.join(G, 'stitched', 'l25_natural.npz'))
     opt = runDN.getOpt({'op': 'DN', 'model': '25'})
     y = ip.RGBFilter(opt)(torch.from_numpy(gd.natural_image(101, (3, 60, 72))).to(dev))
-    assert np.abs(y.float().cpu().numpy() - z['y']).max() <= TOL_NATURAL
+    assert np.abs(y.float().cpu().numpy() - z['y']).max() <= TOL
 
 
 def test_e2e_uint8_config1(dev):
@@ -332,7 +345,7 @@ def test_step_chain_dn_then_sr_config3(dev, tmp_path):
     y = ostitch.do_crop(d, pl, 2, onets.model_fn('net2x', sd_sr))
     want = oio.to_output(oio.to_hwc(y))
     diff = np.abs(out.astype(np.int32) - want.astype(np.int32))
-    assert diff.max() <= 1 and (diff > 0).mean() < 0.1          # 1.5e-3 * 256 < 1 grey level
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.1          # 1e-3 * 256 < 1 grey level
     with pytest.raises(NotImplementedError):
         procedure.genProcess([{'op': 'slomo', 'sf': 2}])
 
@@ -357,7 +370,7 @@ def test_video_frame_buffer_chain_16bit(dev):
     y = ostitch.do_crop(x, pl, 2, onets.model_fn('net2x', gd.state_dict_for('a2', load_state_dict_file)))
     want = oio.to_output(oio.to_hwc(y), 16).astype(np.int64)
     diff = np.abs(got.astype(np.int64) - want)
-    assert diff.max() <= TOL_FP16_SR * 65536 + 1, diff.max()       # 1.5e-3 in 16-bit levels
+    assert diff.max() <= TOL * 65536 + 1, diff.max()
     assert process((b'', h, w)) == []
 
 
@@ -396,7 +409,7 @@ def test_dropin_protocol_reference_loop(dev):
         q, _ = blend(q, t2, lt, pl.pad_sc, -1, ramp.view(1, -1))
         hh, ww = q.shape[-2:]
         out[..., bsc - hh:bsc, rsc - ww:rsc] = q
-    assert np.abs(out.cpu().numpy() - z['y']).max() <= TOL_FP16_SR
+    assert np.abs(out.cpu().numpy() - z['y']).max() <= TOL
 
 
 def test_run_plan_frames_owner_sharding(dev):
@@ -474,9 +487,168 @@ def test_full_size_properties_config2(dev):
         top, bottom, left, right = plan.tiles[k][:4]
         want = onets.forward('net4x', sd, np.ascontiguousarray(x[:, None, top:bottom, left:right])).numpy()[:, 0]
         got = pool4[off[k]:off[k] + want.size].reshape(want.shape).cpu().numpy()
-        assert np.abs(got - want).max() <= TOL_FP16_SR, k
+        assert np.abs(got - want).max() <= TOL, k
     pl = oplanner.prepare((3, 1080, 1920), 1 << 40, 1e-3, 5, 4, 8, 256)
     hp = pool4.cpu().numpy()
     tiles = [hp[off[k]:off[k] + 3 * (t[1] - t[0]) * (t[3] - t[2]) * 16].reshape(3, (t[1] - t[0]) * 4, (t[3] - t[2]) * 4) for k, t in enumerate(pl.tiles)]
     want = ostitch.fold_stitch(tiles, pl, 4)
     assert np.abs(out4.cpu().numpy() - want).max() <= 1e-6
+
+
+def test_step_chain_config3_l25_then_a2(dev, tmp_path):
+    """BASELINE config 3 as written, at test size: [{'op':'DN','model':'25'}, {'op':'SR','model':'a','scale':2}] through
+    procedure.genProcess on an image that needs a 2x2 tile grid in BOTH steps (SEDN l25 with pad 7, then Net2x a2 with pad 5),
+    uint8 file in -> uint8 out, against the oracle chain (sequential doCrop of each step)."""
+    from PIL import Image
+    from moephoto_amd import imageProcess as ip, procedure, runDN
+    from moephoto_amd.config import config
+    from moephoto_amd.weights import save_state_dict_file
+    config.modelRoot, config.crop_sr, config.crop_dn, config.crop_dns, config.fp16, config.deviceId = gd.ZOO, 64, 64, 64, False, 0
+    ip.modelCache.clear()
+    path = '/tmp/moe_synth_l25.pth'
+    save_state_dict_file(gd.synth_state_dict('l25', load_state_dict_file), path)
+    runDN.mode_switch['25'] = (path,) + tuple(runDN.mode_switch['25'][1:])
+    img = gd.to_u8(gd.natural_image(34, (3, 96, 104)))
+    src = tmp_path / 'in.png'
+    Image.fromarray(img).save(src)
+    process, nodes = procedure.genProcess([{'op': 'file'}, {'op': 'DN', 'model': '25'}, {'op': 'SR', 'model': 'a', 'scale': 2, 'ensemble': 0}])
+    assert [(n['op'], n['model']) for n in nodes] == [('DN', '25'), ('SR', 'a')]
+    out = process(str(src))
+    assert out.dtype == np.uint8 and out.shape == (192, 208, 3)
+    x = oio.to_float_image(img)
+    sd_dn, sd_sr = gd.state_dict_for('l25', load_state_dict_file), gd.state_dict_for('a2', load_state_dict_file)
+    pl = oplanner.prepare((3, 96, 104), 1 << 40, 1e-3, 7, 1, 8, 64)
+    assert len(pl.tiles) == 4
+    d = ostitch.do_crop(x, pl, 1, onets.model_fn('sedn', sd_dn))
+    pl = oplanner.prepare((3, 96, 104), 1 << 40, 1e-3, 5, 2, 8, 64)
+    assert len(pl.tiles) == 4
+    y = ostitch.do_crop(d, pl, 2, onets.model_fn('net2x', sd_sr))
+    want = oio.to_output(oio.to_hwc(y))
+    diff = np.abs(out.astype(np.int32) - want.astype(np.int32))
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.1          # 1e-3 * 256 < 1 grey level
+    # and the float result of the chain itself, before quantisation
+    dev_x = ip.toTorch(8, torch.float32, dev)(img)
+    from moephoto_amd import runSR
+    yd = runSR.sr(runSR.getOpt({'op': 'SR', 'model': 'a', 'scale': 2, 'ensemble': 0}))(ip.RGBFilter(runDN.getOpt({'op': 'DN', 'model': '25'}))(dev_x))
+    assert np.abs(yd.cpu().numpy() - y).max() <= TOL
+
+
+def test_config4_frames_over_8_owners(dev):
+    """BASELINE config 4 at test size: two 1080p frames, a4, 256-px tiles (2 x 40 tiles), the (frame, tile) pairs dealt
+    round-robin to 8 owners exactly as on 8 GPUs (each owner computes its tenth-ish with cross-frame batching through
+    moe_run_plan_frames); pools and stitched frames must equal the frame-by-frame doCrop bit for bit."""
+    import ctypes
+    from moephoto_amd import _lib, imageProcess as ip
+    opt = _opt_sr('a', 4, 256, fp16_io=True)
+    frames = torch.stack([torch.from_numpy(gd.natural_image(80 + f, (3, 1080, 1920))) for f in range(2)]).to(dev).half()
+    plan = ip._plan_for(opt, frames[0].shape)
+    assert plan.n_tiles == 40
+    L, model = _lib.lib(), opt.modelCached
+    stream = torch.cuda.current_stream().cuda_stream
+    pe = plan.pool_elems(3)
+    sC, sH, sW = frames[0].stride()
+    pools = torch.zeros((2, pe), dtype=torch.float32, device=dev)
+    for i in range(8):
+        _lib.check(L.moe_run_plan_frames(model._h, plan._h, frames.data_ptr(), _lib.F16, frames.stride(0), sC, sH, sW, 2,
+                                         ctypes.c_void_p(pools.data_ptr()), pe, i, 8, 0, stream))
+    for f in range(2):
+        y = torch.empty((3, plan.outH, plan.outW), dtype=torch.float16, device=dev)
+        _lib.check(L.moe_stitch(plan._h, 0, pools[f].data_ptr(), None, 3, y.data_ptr(), _lib.F16, stream))
+        torch.cuda.synchronize()
+        assert torch.equal(y, ip.doCrop(opt, frames[f])), f
+
+
+@pytest.mark.parametrize('model,scale', [('a', 2), ('a', 3), ('a', 4)])
+def test_auto_cropsize_whole_frame_tiles(model, scale, dev):
+    """cropsize 'auto' on a 288-GB part plans a 1080p frame as ONE tile: three planes of 1080x1920 through every kernel
+    (the fused tail's tap planes alone are 36 B per output pixel).  The frame must run -- batches are split so that no launch
+    leaves the kernels' 32-bit addressing range -- and its top-left corner must match the oracle of that corner's receptive
+    field (a whole-frame oracle run would take minutes)."""
+    from moephoto_amd import imageProcess as ip
+    opt = _opt_sr(model, scale, 0)
+    x = gd.natural_image(60 + scale, (3, 1080, 1920))
+    xd = torch.from_numpy(x).to(dev)
+    plan = ip._plan_for(opt, xd.shape)
+    assert plan.n_tiles == 1, plan.n_tiles
+    y = ip.doCrop(opt, xd)
+    assert tuple(y.shape) == (3, 1080 * scale, 1920 * scale)
+    key = model + str(scale)
+    sd = gd.state_dict_for(key, load_state_dict_file)
+    # outputs within 96 px of the corner depend on inputs within 96 + ~25 px (19 conv layers, the last ones at higher resolution)
+    want = onets.forward(gd.MODELS[key][0], sd, np.ascontiguousarray(x[:, None, :160, :160])).numpy()[:, 0, :96 * scale, :96 * scale]
+    assert np.abs(y[:, :96 * scale, :96 * scale].cpu().numpy() - want).max() <= TOL
+    want = onets.forward(gd.MODELS[key][0], sd, np.ascontiguousarray(x[:, None, -160:, -160:])).numpy()[:, 0, -96 * scale:, -96 * scale:]
+    assert np.abs(y[:, -96 * scale:, -96 * scale:].cpu().numpy() - want).max() <= TOL
+
+
+def test_large_batches_are_split(dev):
+    """40 tiles (120 planes of 256x256) in ONE requested batch exceed the fast kernel's 32-bit addressing range for Net4x
+    (576 B per pixel-plane): the engine runs them as several launch sets with results identical to 4-tile batches."""
+    import ctypes
+    from moephoto_amd import _lib, imageProcess as ip
+    opt = _opt_sr('a', 4, 256)
+    xd = torch.from_numpy(gd.natural_image(0, (3, 1080, 1920))).to(dev)
+    plan = ip._plan_for(opt, xd.shape)
+    sC, sH, sW = xd.stride()
+    outs = []
+    for per in (4, 40):
+        out = torch.empty((3, plan.outH, plan.outW), dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().moe_run_plan(opt.modelCached._h, plan._h, xd.data_ptr(), _lib.F32, sC, sH, sW, out.data_ptr(), _lib.F32, per,
+                                           torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_exact_blocks_knob(dev):
+    """'mixed' precision: more split-operand ARSBs can only tighten the result; every setting stays within TOL on white noise
+    for Net4x, and 6 blocks on Net2x is what the default resolves to."""
+    z = np.load(os.path.join(G, 'nets', 'a4.npz'))
+    h, w = [int(v) for v in z['hw']]
+    x = torch.from_numpy(gd.noise_image(int(z['seed']), (3, 1, h, w))).to(dev)
+    m = module_for('a4', 'mixed')
+    errs = []
+    for nb in (0, 1, 3, 6):
+        m.set_exact_blocks(nb)
+        errs.append(float(np.abs(m(x)[-1].cpu().numpy() - z['y_noise']).max()))
+    m.set_exact_blocks(-1)
+    assert max(errs) <= TOL and errs[-1] <= errs[0] + 1e-4, errs
+    with pytest.raises(RuntimeError):
+        m.set_exact_blocks(9)
+    from moephoto_amd import models
+    with pytest.raises(RuntimeError):                    # 'mixed' is defined for the ARSB nets only
+        from moephoto_amd import _lib
+        net = models.SEDN()
+        net.load_state_dict({n: torch.from_numpy(v) for n, v in gd.state_dict_for('l25', load_state_dict_file).items()})
+        _lib.check(_lib.lib().moe_net_finalize(net._h, 0, _lib.PREC_MIXED))
+
+
+def test_rccl_path_world1(dev):
+    """The collective path of dist.run_frames on the real RCCL backend (`nccl` on ROCm) with one rank: process group on the
+    device, weight broadcast on device tensors, the all-to-all issued even though nothing crosses ranks
+    (dist.FORCE_COLLECTIVE), stitch from the exchange buffer.  Result == single-process doCrop, bit for bit."""
+    import socket
+    import torch.distributed as dist
+    from moephoto_amd import dist as mdist, imageProcess as ip
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    try:
+        sd = {k: torch.from_numpy(v) for k, v in gd.state_dict_for('a2', load_state_dict_file).items()}
+        got = mdist.broadcast_state_dict(sd, src=0, device=dev)
+        assert list(got.keys()) == list(sd.keys()) and all(torch.equal(got[k], sd[k]) for k in sd)
+        opt = _opt_sr('a', 2, 64, fp16_io=True)
+        frames = [torch.from_numpy(gd.natural_image(90 + f, (3, 150, 200))).to(dev).half() for f in range(3)]
+        mdist.FORCE_COLLECTIVE = True
+        for rep in range(2):          # second call: cached layout, same buffer
+            out = mdist.run_frames(opt, frames, out_dtype=torch.float16)
+            torch.cuda.synchronize()
+            assert sorted(out) == [0, 1, 2]
+            for f, y in out.items():
+                assert torch.equal(y, ip.doCrop(opt, frames[f])), (rep, f)
+    finally:
+        mdist.FORCE_COLLECTIVE = False
+        dist.destroy_process_group()
