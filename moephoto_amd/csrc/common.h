@@ -65,6 +65,20 @@ hipError_t conv_mfma_init(); // raise dynamic-LDS limits once per process
 bool launch_conv3x3_sp(const ConvArgs& a, hipStream_t s);   // false: epilogue variant not compiled, use another kernel
 hipError_t conv3x3_sp_init();
 
+// One fused ARSB  y = x + conv_2(PReLU(conv_1(x)))  (arsb_fused.hip; conv_2's weights carry the ScaleLayer factor)
+struct ArsbArgs {
+    const half_t* x_hi; const half_t* x_lo;   // stream in  [B][H][W][64] (x_lo: low part in units of 2^-11, or nullptr)
+    half_t* y_hi; half_t* y_lo;               // stream out, NOT aliasing x (neighbouring patches read x's halo)
+    const half_t* w1; const half_t* w2;       // packed A fragments of conv_1 / conv_2 (one 64-channel chunk each, 72 fragments)
+    const half_t* zero;                       // >= 256 B of zeros
+    float slope;                              // PReLU slope of conv_1 (<= 1)
+    int B, H, W;
+    int px, py;                               // set by the launcher
+    unsigned long long* trace;                // -DARSB_TRACE builds only: s_memtime stamps [workgroup < 8][patch < 16][wave 4][slot 40]
+};
+bool launch_arsb_fused(ArsbArgs a, int max_groups, hipStream_t s);   // false: not applicable (caller runs the two convs)
+hipError_t arsb_fused_init();
+
 struct DirectConvArgs {
     const half_t* in; half_t* out; const half_t* res;
     const float* w;       // plain fp32 OIHW weights [cout][cin][k][k] (original channel counts)

@@ -55,6 +55,7 @@ struct ConvLayer {               // one MFMA convolution
     float slope = 1.f, scale = 1.f;
     bool per_plane = false;      // SEDN trans: weights rebuilt per plane by the SE kernel
     size_t w_hi = 0, w_lo = 0, bias = 0, bias_img = 0, w_plain = 0, bias_plain = 0, w_pk32 = 0;   // offsets into the device blob
+    size_t w_arsb = 0;           // 3x3 64->64 trunk convs: A fragments of v_mfma_f32_16x16x32_f16 in the fused ARSB kernel's order (arsb_fused.hip)
     size_t w_x3 = 0;             // 1x1, one segment, split precision: [chunk][w_lo | w_hi | w_hi] for the single-launch path (acc_mode 4)
     bool has_x3 = false;
     bool has_bias = false;
@@ -280,6 +281,28 @@ void pack_conv(const Param& W, const Param* bias, int r, ConvLayer& L, BlobBuild
 
 }  // namespace
 
+// Fused-ARSB weight order (arsb_fused.hip): [wave w][fragment f = tap * 2 + kh][lane l][e], lane l = (m = l & 15, kq = l >> 4) holds
+// W[cout = 16w + m][cin = 8 * SL(kh, kq) + e][tap] with SL(kh, kq) = (2kh + (kq >> 1)) ^ 4(kq & 1) -- the k order in which that kernel's
+// bank-conflict-free LDS image delivers the activations
+static void pack_arsb(const Param& W, ConvLayer& L, BlobBuilder& bb, float fold)
+{
+    const int cout = (int)W.shape[0], cin = (int)W.shape[1];
+    L.w_arsb = bb.take((size_t)4 * 18 * 512 * 2);
+    for (int w = 0; w < 4; ++w)
+        for (int f = 0; f < 18; ++f) {
+            const int tap = f >> 1, kh = f & 1;
+            for (int l = 0; l < 64; ++l) {
+                const int m = l & 15, kq = l >> 4;
+                const int slot = (2 * kh + (kq >> 1)) ^ (4 * (kq & 1));
+                for (int e = 0; e < 8; ++e) {
+                    const int oc = 16 * w + m, ci = 8 * slot + e;
+                    const float v = (oc < cout && ci < cin) ? W.data[((size_t)oc * cin + ci) * 9 + tap] * fold : 0.f;
+                    bb.at<half_t>(L.w_arsb)[((size_t)(w * 18 + f) * 64 + l) * 8 + e] = (half_t)v;
+                }
+            }
+        }
+}
+
 static float scalar_of(const moe_net& n, const std::string& name) { return n.get(name)->data[0]; }
 
 static int build_device_weights(moe_net& n, int precision)
@@ -296,6 +319,8 @@ static int build_device_weights(moe_net& n, int precision)
         // the debug path keeps the plain weights and applies the scale in its epilogue; the MFMA kernels get it pre-multiplied
         pack_conv(*n.get(wname), b, r, L, bb, lo, plain, per_plane, plain ? 1.f : scale);
         L.slope = slope; L.scale = plain ? scale : 1.f; L.per_plane = per_plane;
+        if (!plain && r == 1 && L.taps == 9 && L.nseg == 1 && L.nchunks == 1 && (key.compare(0, 3, "c1_") == 0 || key.compare(0, 3, "c2_") == 0))
+            pack_arsb(*n.get(wname), L, bb, scale);
         n.conv_index[key] = (int)n.convs.size();
         n.convs.push_back(L);
     };
@@ -747,7 +772,7 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         // add (see Fwd::conv).  DESIGN.md section 5 has the error budget behind this choice.
         const bool mixed = f.mixed;
         const int nx = mixed ? exact_blocks_of(n) : 0;
-        Act A = f.act(P, 64, mixed), Bb = f.act(P, 64, mixed), Cc = f.act(P, 64, mixed && nx > 0);
+        Act A = f.act(P, 64, mixed), Bb = f.act(P, 64, mixed), Cc = f.act(P, 64, mixed);
         stem(A);
         f.tap("stem", A, h, w, 64, n.C);
         auto trunk_conv = [&](const std::string& key, const Act& in, const Act& out, const Act* res, bool exact) {
@@ -757,16 +782,48 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         };
         if (int rc = trunk_conv("input2", A, Bb, nullptr, mixed)) return rc;
         f.tap("input2", Bb, h, w, 64, n.C);
+        // single-pass ARSBs run as ONE kernel (arsb_fused.hip: conv_1's output never leaves the CU) that streams cur -> oth;
+        // split-operand / debug blocks use the two-launch form, conv_1 into `oth`, conv_2 back onto `cur`
+        const char* fuse_env = getenv("MOE_ARSB_FUSE");          // (read per forward: the tests switch it inside one process)
+        const bool arsb_fuse = !(fuse_env && !strcmp(fuse_env, "0")) && !f.x3 && !f.direct && conv_impl() == 2;
+        Act cur = Bb, oth = Cc;
         for (int i = 1; i <= 6; ++i) {
             const bool ex = mixed && i <= nx;
-            Act m = Cc;
+            const std::string k1 = "c1_" + std::to_string(i), k2 = "c2_" + std::to_string(i);
+            if (arsb_fuse && !ex && (!mixed || (cur.lo && oth.lo)) && n.convs[n.conv_index.at(k1)].w_arsb) {
+                bool done = f.dry();
+                if (!done) {
+                    const ConvLayer& L1 = n.convs[n.conv_index.at(k1)];
+                    const ConvLayer& L2 = n.convs[n.conv_index.at(k2)];
+                    ArsbArgs q{};
+                    q.x_hi = cur.hi; q.x_lo = mixed ? cur.lo : nullptr; q.y_hi = oth.hi; q.y_lo = mixed ? oth.lo : nullptr;
+                    q.w1 = f.blob<half_t>(L1.w_arsb); q.w2 = f.blob<half_t>(L2.w_arsb); q.zero = f.small<half_t>("zero");
+                    q.slope = L1.slope; q.B = B; q.H = h; q.W = w;
+                    static const bool trace = getenv("MOE_ARSB_TRACE") != nullptr;   // with a -DARSB_TRACE build: stamps of ARSB 3 -> /tmp/arsb_trace.bin
+                    const size_t tb = 8 * 16 * 4 * 40 * 8;
+                    if (trace && i == 3 && hipMalloc((void**)&q.trace, tb) == hipSuccess) (void)hipMemsetAsync(q.trace, 0, tb, s);
+                    const int rec = f.prof_begin("arsb" + std::to_string(i), 2.0 * 2.0 * (double)B * h * w * L1.cout * L1.cin * 9);
+                    done = launch_arsb_fused(q, n.max_groups, s);
+                    f.prof_end(rec);
+                    if (q.trace) {
+                        std::vector<unsigned long long> host(tb / 8);
+                        (void)hipStreamSynchronize(s);
+                        (void)hipMemcpy(host.data(), q.trace, tb, hipMemcpyDeviceToHost);
+                        if (FILE* fp = fopen("/tmp/arsb_trace.bin", "wb")) { fwrite(host.data(), 1, tb, fp); fclose(fp); }
+                        (void)hipFree(q.trace);
+                    }
+                }
+                if (done) { std::swap(cur, oth); f.tap("arsb" + std::to_string(i), cur, h, w, 64, n.C); continue; }
+            }
+            Act m = oth;
             if (mixed && !ex) m.lo = nullptr;                    // single-pass ARSB: conv_1's output is an fp16 operand only
-            Act bin = Bb;
+            Act bin = cur;
             if (mixed && !ex) bin.lo = nullptr;
-            if (int rc = trunk_conv("c1_" + std::to_string(i), bin, m, nullptr, ex)) return rc;
-            if (int rc = trunk_conv("c2_" + std::to_string(i), m, Bb, &Bb, ex)) return rc;
-            f.tap("arsb" + std::to_string(i), Bb, h, w, 64, n.C);
+            if (int rc = trunk_conv(k1, bin, m, nullptr, ex)) return rc;
+            if (int rc = trunk_conv(k2, m, cur, &cur, ex)) return rc;
+            f.tap("arsb" + std::to_string(i), cur, h, w, 64, n.C);
         }
+        Bb = cur;
         if (n.arch == MOE_ARCH_NETDN) { tail(&Bb, &A, h, w, false); return MOE_OK; }
         if (mixed) { A.lo = nullptr; Bb.lo = nullptr; }          // the upsampler convs take the fp16 parts
         // two upsampler branches: R on the trunk output, U on the stem output (models.py:117-123)

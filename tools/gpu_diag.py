@@ -73,7 +73,7 @@ def nets():
     for key in os.environ.get('DIAG_KEYS', 'a2,a4,a3,dn_lite5,l25,lite2,lite4').split(','):
         arch = gd.MODELS[key][0]
         sd = gd.state_dict_for(key, load_state_dict_file)
-        for prec in os.environ.get('DIAG_PREC', 'debug_direct,fp16,fp16x3').split(','):
+        for prec in os.environ.get('DIAG_PREC', 'auto,fp16,fp16x3').split(','):
             try:
                 m = make(key, prec).set_debug(True)
                 for kind in ('natural', 'noise'):
@@ -99,7 +99,8 @@ def nets():
 
 
 def layer_timing():
-    m = make('a4', 'fp16')
+    m = make('a4', os.environ.get('DIAG_LAYER_PREC', 'auto'))
+    say('precision', m.resolved_precision())
     RES['layers'] = {}
     for B in (3, 12):
         x = torch.from_numpy(gd.natural_image(1, (B, 256, 256))[:, None]).to(dev).half()

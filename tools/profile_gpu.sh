@@ -14,7 +14,7 @@ echo "stats rc=$?" >> $OUT/stats_stdout.log
 timeout 120 rocprofv3-avail list > $OUT/counters_avail.txt 2>&1 || timeout 120 rocprofv3 -L > $OUT/counters_avail.txt 2>&1
 pass() {  # name, counters...
   name=$1; shift
-  timeout 300 rocprofv3 --pmc "$@" --kernel-include-regex "conv3x3_sp" -d $OUT/pmc_$name -o pmc -f csv -- python tools/prof_workload.py > $OUT/pmc_$name.log 2>&1
+  timeout 300 rocprofv3 --pmc "$@" --kernel-include-regex "${PROF_KERNEL_RE:-conv3x3_sp}" -d $OUT/pmc_$name -o pmc -f csv -- python tools/prof_workload.py > $OUT/pmc_$name.log 2>&1
   echo "pmc $name rc=$?" >> $OUT/pmc_$name.log
 }
 pass sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_F16

@@ -30,7 +30,7 @@ only = os.environ.get('TM_ONLY')          # e.g. TM_ONLY='SR a3' TM_PREC=fp16 un
 for name, mk in cases:
     if only and name != only:
         continue
-    for prec in os.environ.get('TM_PREC', 'fp16,fp16x3').split(','):
+    for prec in os.environ.get('TM_PREC', 'auto,fp16,fp16x3').split(','):
         ip.modelCache.clear()
         opt = mk()
         opt.modelCached.set_precision(prec)
