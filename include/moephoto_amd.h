@@ -181,6 +181,14 @@ int moe_to_float(const void* src, int src_dtype, int bits, int H, int W, int C, 
 /* src: C planes H x W (MOE_F32/MOE_F16); dst: H x W x C interleaved, v*2^bits clamped to [0, 2^bits-1], truncated */
 int moe_to_output(const void* src, int src_dtype, int H, int W, int C, int bits, void* dst, int dst_dtype, int device, void* stream);
 
+/* the pipeline's `resize` step: resizeByTorch = F.interpolate(x[None], size=(h, w), mode, align_corners=False)
+ * (python/imageProcess.py:174-195, 555-556; python/procedure.py:104-107).  src: C planes H x W, dst: C planes h x w, same dtype
+ * (MOE_F32 / MOE_F16); arithmetic in fp32 in torch's operation order. */
+#define MOE_RESIZE_NEAREST 0
+#define MOE_RESIZE_BILINEAR 1
+#define MOE_RESIZE_BICUBIC 2
+int moe_resize(const void* src, void* dst, int dtype, int C, int H, int W, int h, int w, int mode, int device, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,7 @@ OK, EINVAL, ENOMEM, EHIP, ESTATE = 0, -1, -2, -3, -4
 ARCH_NET2X, ARCH_NET3X, ARCH_NET4X, ARCH_NETDN, ARCH_SEDN, ARCH_LITE = range(6)
 F32, F16, U8, U16 = range(4)
 PREC_FP16, PREC_FP16X3, PREC_DEBUG_DIRECT, PREC_MIXED = range(4)
+RESIZE_MODES = {'nearest': 0, 'bilinear': 1, 'bicubic': 2}
 PRECISIONS = {'fp16': PREC_FP16, 'fp16x3': PREC_FP16X3, 'debug_direct': PREC_DEBUG_DIRECT, 'mixed': PREC_MIXED}
 
 _lib = None
@@ -68,6 +69,7 @@ def lib():
         'moe_run_plan_tiles': (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_i64, c_int, c_vp, P(c_i64), c_int, c_vp]),
         'moe_to_float': (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp]),
         'moe_to_output': (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp]),
+        'moe_resize': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)   # AttributeError here = header/library mismatch: fail loudly
@@ -82,7 +84,7 @@ EXPORTS = ['moe_last_error', 'moe_abi_version', 'moe_device_count', 'moe_net_cre
            'moe_net_num_params', 'moe_net_param_info', 'moe_net_set_param', 'moe_net_finalize', 'moe_net_workspace_bytes',
            'moe_net_max_tile_pixels', 'moe_net_forward', 'moe_net_set_profile', 'moe_net_get_profile', 'moe_net_get_profile_at', 'moe_net_set_exact_blocks', 'moe_net_set_debug', 'moe_net_debug_tap', 'moe_plan_create', 'moe_plan_destroy', 'moe_plan_info',
            'moe_plan_tiles', 'moe_plan_ramp', 'moe_plan_pool_elems', 'moe_plan_tile_offsets', 'moe_stitch', 'moe_run_plan',
-           'moe_run_plan_ex', 'moe_run_plan_frames', 'moe_run_plan_tiles', 'moe_to_float', 'moe_to_output']
+           'moe_run_plan_ex', 'moe_run_plan_frames', 'moe_run_plan_tiles', 'moe_to_float', 'moe_to_output', 'moe_resize']
 
 
 def check(rc):

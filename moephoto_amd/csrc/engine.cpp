@@ -1602,6 +1602,18 @@ int moe_to_float(const void* src, int src_dtype, int bits, int H, int W, int C, 
     return MOE_OK;
 }
 
+int moe_resize(const void* src, void* dst, int dtype, int C, int H, int W, int h, int w, int mode, int device, void* stream)
+{
+    if (!src || !dst || C < 1 || H < 1 || W < 1 || h < 1 || w < 1) return fail(MOE_EINVAL, "moe_resize: bad argument");
+    if (dtype != MOE_F32 && dtype != MOE_F16) return fail(MOE_EINVAL, "moe_resize: dtype must be MOE_F32 or MOE_F16");
+    if (mode < MOE_RESIZE_NEAREST || mode > MOE_RESIZE_BICUBIC) return fail(MOE_EINVAL, "moe_resize: unknown mode %d", mode);
+    HIP_TRY(hipSetDevice(device));
+    launch_resize(src, dst, dtype, C, H, W, h, w, mode, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MOE_EHIP, "resize launch failed: %s", hipGetErrorString(e));
+    return MOE_OK;
+}
+
 int moe_to_output(const void* src, int src_dtype, int H, int W, int C, int bits, void* dst, int dst_dtype, int device, void* stream)
 {
     if (!src || !dst || H < 1 || W < 1 || C < 1 || bits < 1 || bits > 16) return fail(MOE_EINVAL, "moe_to_output: bad argument");

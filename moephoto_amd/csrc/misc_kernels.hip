@@ -892,6 +892,82 @@ void launch_to_output(const void* src, int src_dtype, int H, int W, int C, float
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// resize: F.interpolate(x[None], size=(h, w), mode=..., align_corners=False)[0]  (python/imageProcess.py:555-556, the `resize`
+// step of the pipeline builder, python/procedure.py:104-107).  Planar (C, H, W) in, (C, h, w) out, arithmetic in fp32 exactly as
+// torch's upsample kernels order it: scale = in / out (float), src = scale * (dst + 0.5) - 0.5; bilinear clamps src at 0, bicubic
+// (A = -0.75) clamps the four tap indices; nearest takes floor(dst * scale).  __f*_rn keeps the compiler from contracting the index
+// arithmetic into FMAs (a contracted src can land on the other side of an integer).
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void resize_kernel(const T* src, T* dst, int C, int H, int W, int h, int w, float sy, float sx)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)C * h * w;
+    if (idx >= total) return;
+    const int x = (int)(idx % w);
+    const long long t = idx / w;
+    const int y = (int)(t % h), c = (int)(t / h);
+    const T* p = src + (long long)c * H * W;
+    float out;
+    if (MODE == 0) {            // nearest: min(floor(dst * scale), in - 1)
+        const int iy = min((int)floorf(__fmul_rn((float)y, sy)), H - 1), ix = min((int)floorf(__fmul_rn((float)x, sx)), W - 1);
+        out = (float)p[(long long)iy * W + ix];
+    } else if (MODE == 1) {     // bilinear
+        float fy = __fsub_rn(__fmul_rn(sy, __fadd_rn((float)y, 0.5f)), 0.5f), fx = __fsub_rn(__fmul_rn(sx, __fadd_rn((float)x, 0.5f)), 0.5f);
+        fy = fy < 0.f ? 0.f : fy; fx = fx < 0.f ? 0.f : fx;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+        const float ly = __fsub_rn(fy, (float)y0), lx = __fsub_rn(fx, (float)x0);
+        const float hy = __fsub_rn(1.f, ly), hx = __fsub_rn(1.f, lx);
+        const float v00 = (float)p[(long long)y0 * W + x0], v01 = (float)p[(long long)y0 * W + x1];
+        const float v10 = (float)p[(long long)y1 * W + x0], v11 = (float)p[(long long)y1 * W + x1];
+        // h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11), left to right, no contraction
+        const float r0 = __fadd_rn(__fmul_rn(hx, v00), __fmul_rn(lx, v01)), r1 = __fadd_rn(__fmul_rn(hx, v10), __fmul_rn(lx, v11));
+        out = __fadd_rn(__fmul_rn(hy, r0), __fmul_rn(ly, r1));
+    } else {                    // bicubic, A = -0.75
+        const float A = -0.75f;
+        const float fy = __fsub_rn(__fmul_rn(sy, __fadd_rn((float)y, 0.5f)), 0.5f), fx = __fsub_rn(__fmul_rn(sx, __fadd_rn((float)x, 0.5f)), 0.5f);
+        const float gy = floorf(fy), gx = floorf(fx);
+        const int iy = (int)gy, ix = (int)gx;
+        const float ty = __fsub_rn(fy, gy), tx = __fsub_rn(fx, gx);
+        float cy[4], cx[4];
+        cy[0] = cubic2(ty + 1.f, A); cy[1] = cubic1(ty, A); cy[2] = cubic1(1.f - ty, A); cy[3] = cubic2(2.f - ty, A);
+        cx[0] = cubic2(tx + 1.f, A); cx[1] = cubic1(tx, A); cx[2] = cubic1(1.f - tx, A); cx[3] = cubic2(2.f - tx, A);
+        out = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int yy = min(max(iy - 1 + i, 0), H - 1);
+            float r = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int xx = min(max(ix - 1 + j, 0), W - 1);
+                r += (float)p[(long long)yy * W + xx] * cx[j];
+            }
+            out += r * cy[i];
+        }
+    }
+    dst[idx] = (T)out;
+}
+
+}  // namespace
+
+void launch_resize(const void* src, void* dst, int dtype, int C, int H, int W, int h, int w, int mode, hipStream_t s)
+{
+    const long long n = (long long)C * h * w;
+    const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+    const float sy = (float)H / (float)h, sx = (float)W / (float)w;
+#define MOE_RZ(T, M) hipLaunchKernelGGL((resize_kernel<T, M>), grid, blk, 0, s, (const T*)src, (T*)dst, C, H, W, h, w, sy, sx)
+    if (dtype == MOE_F16) { if (mode == 0) MOE_RZ(half_t, 0); else if (mode == 1) MOE_RZ(half_t, 1); else MOE_RZ(half_t, 2); }
+    else { if (mode == 0) MOE_RZ(float, 0); else if (mode == 1) MOE_RZ(float, 1); else MOE_RZ(float, 2); }
+#undef MOE_RZ
+}
+
 void launch_nhwc_to_nchw_f32(const half_t* in, const half_t* in_lo, float* out, int B, int H, int W, int cs, int C, hipStream_t s)
 {
     const long long n = (long long)B * C * H * W;

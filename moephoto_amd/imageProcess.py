@@ -257,6 +257,59 @@ def doCrop(opt, x, *args, **_):
     return out
 
 
+# ---- resize step (python/imageProcess.py:174-214, 555-556) --------------------------------------------------
+def resizeByTorch(x, width, height, mode='bilinear'):
+    """The reference's `resizeByTorch` = F.interpolate(x[None], size=(height, width), mode=mode, align_corners=False)[0]; the name
+    is kept for the callers, the work is moe_resize on the device (nearest / bilinear / bicubic)."""
+    if mode not in _lib.RESIZE_MODES:
+        raise ValueError('resize: interpolation method "{}" is not supported (nearest, bilinear, bicubic)'.format(mode))
+    if x.device.type != 'cuda':
+        raise _lib.EngineError('resize: input must live on a HIP device (moephoto_amd has no CPU path)')
+    if x.dtype not in _DT:
+        x = x.to(config.dtype())
+    x = x.contiguous()
+    C, H, W = x.shape
+    out = torch.empty((C, int(height), int(width)), dtype=x.dtype, device=x.device)
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    _lib.check(_lib.lib().moe_resize(x.data_ptr(), out.data_ptr(), _DT[x.dtype], C, H, W, int(height), int(width),
+                                     _lib.RESIZE_MODES[mode], x.device.index or 0, stream))
+    x.record_stream(torch.cuda.current_stream(x.device))
+    return out
+
+
+def resize(opt, out=None, pos=0, nodes=(), h=1, w=1):
+    """The `resize` step: target size from scaleH / scaleW (rounded like the reference) or height / width; once the size is known
+    for a stream source it is kept (opt['update'])."""
+    opt['update'] = True
+    opt.setdefault('method', 'bilinear')
+
+    def f(im):
+        nonlocal h, w
+        if opt['update']:
+            _, ih, iw = im.shape
+            h = round(ih * opt['scaleH']) if 'scaleH' in opt else opt['height']
+            w = round(iw * opt['scaleW']) if 'scaleW' in opt else opt['width']
+            if out and out.get('source'):
+                opt['update'] = False
+        return resizeByTorch(im, w, h, opt['method'])
+    return f
+
+
+def restrictSize(width, height=0, method='bilinear'):
+    """Shrink to fit width x height keeping the aspect ratio; images that already fit pass through (python/imageProcess.py:197-214)."""
+    height = height or width
+    st = {}
+
+    def f(im):
+        if not st:
+            _, ih, iw = im.shape
+            st['fit'] = ih <= height and iw <= width
+            sh, sw = height / ih, width / iw
+            st['hw'] = (height, round(iw * sh)) if sh < sw else (round(ih * sw), width)
+        return im if st['fit'] else resizeByTorch(im, st['hw'][1], st['hw'][0], method)
+    return f
+
+
 # ---- self-ensemble (python/imageProcess.py:563-572) -------------------------------------------------
 transpose = lambda x: x.transpose(-1, -2)
 flip = lambda x: x.flip(-1)

@@ -7,17 +7,18 @@
 into one callable: image in (HWC uint8/uint16 numpy array, a file when the first step is 'file', or a raw video frame
 `(bytes, height, width)` when it is {'op': 'buffer', 'bitDepth': 16} -- python/video.py:23, procedure.py:141-142) -> image out, with
 everything between the upload (toTorch) and the download (toOutput) resident on the device: DN through RGBFilter
-(python/procedure.py:52-55), SR through runSR.sr (:63-73), output = toFloat -> toOutput (:128-136).  The progress/ETA
+(python/procedure.py:52-55), SR through runSR.sr (:63-73), resize through moe_resize (:104-107), output = toFloat -> toOutput (:128-136).  The progress/ETA
 nodes of the reference are observability only and are not reproduced; `nodes` lists the resolved
-steps.  Ops other than file / DN / SR / output belong to other model families and raise.
+steps.  Ops other than file / buffer / DN / SR / resize / output belong to other model families and raise.
 """
 from functools import reduce
 
 from . import runDN, runSR
 from .config import config
-from .imageProcess import RGBFilter, apply, readFile, toBuffer, toFloat, toNumPy, toOutput, toTorch, writeFile
+from .imageProcess import RGBFilter, apply, readFile, resize, toBuffer, toFloat, toNumPy, toOutput, toTorch, writeFile
 
-stepOpts = dict(SR={'toInt': ['scale', 'ensemble'], 'getOpt': runSR}, DN={'toFloat': ['strength'], 'getOpt': runDN})
+stepOpts = dict(SR={'toInt': ['scale', 'ensemble'], 'getOpt': runSR}, DN={'toFloat': ['strength'], 'getOpt': runDN},
+                resize={'toInt': ['width', 'height'], 'toFloat': ['scaleW', 'scaleH']})
 
 
 def convertValues(T, o, keys):
@@ -52,6 +53,10 @@ def genProcess(steps, bitDepth=8, outFile=None):
         so = stepOpts[op]
         convertValues(int, opt, so.get('toInt', []))
         convertValues(float, opt, so.get('toFloat', []))
+        if op == 'resize':      # procResize (python/procedure.py:104-107)
+            funcs.append(resize(opt, dict(source=has_buffer)))
+            nodes.append(dict(op='resize', mode=opt['method']))
+            continue
         o = so['getOpt'].getOpt(opt)
         if o is None:
             raise ValueError('unknown model for step {}'.format(opt))

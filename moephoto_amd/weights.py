@@ -12,7 +12,9 @@ legacy layout:
 `torch.load`'s default (weights_only=True, torch>=2.6) rejects them.  This module parses them
 itself with a *closed* unpickler: the only globals it resolves are the three the zoo uses
 (collections.OrderedDict, torch._utils._rebuild_tensor_v2, torch.<T>Storage), each mapped to a
-local stand-in, so no arbitrary code can run and torch is not needed to read weights.
+local stand-in, and the four auxiliary pickles (magic, protocol, sys_info, storage keys) go through an unpickler
+that refuses every global -- so no arbitrary code can run -- and torch is not needed to read weights.  Tensor views are
+bounds-checked against their storage before they are materialised.
 Returns `OrderedDict[str, np.ndarray]` (fp32, C-contiguous) -- what `load_state_dict` of the
 engine-backed modules in `moephoto_amd.models` consumes.
 """
@@ -54,10 +56,20 @@ class _LazyTensor:
         if base is None:
             raise ValueError('storage {} has no data in the file'.format(self.storage.key))
         if len(self.size) == 0:
+            if not 0 <= self.offset < base.size:
+                raise ValueError('scalar view of storage {} is out of range'.format(self.storage.key))
             return np.array(base[self.offset], dtype=base.dtype)
+        # size / stride / offset come from the file: the view must stay inside the storage (as_strided checks nothing)
+        if len(self.stride) != len(self.size) or self.offset < 0 or any(int(d) < 0 for d in self.size) or any(int(t) < 0 for t in self.stride):
+            raise ValueError('tensor view of storage {} has a negative size, stride or offset'.format(self.storage.key))
+        if any(int(d) == 0 for d in self.size):
+            return np.zeros(self.size, dtype=base.dtype)
+        last = self.offset + sum((int(d) - 1) * int(t) for d, t in zip(self.size, self.stride))
+        if last >= base.size:
+            raise ValueError('tensor view of storage {} reaches element {} of {}'.format(self.storage.key, last, base.size))
         v = np.lib.stride_tricks.as_strided(
             base[self.offset:], shape=self.size,
-            strides=tuple(s * base.dtype.itemsize for s in self.stride), writeable=False)
+            strides=tuple(int(t) * base.dtype.itemsize for t in self.stride), writeable=False)
         return np.array(v)   # writable, C-contiguous copy
 
 
@@ -97,6 +109,24 @@ class _ZooUnpickler(pickle.Unpickler):
         return self.storages[key]
 
 
+class _PlainUnpickler(pickle.Unpickler):
+    """For the file's four auxiliary pickles (magic, protocol, sys_info, storage keys): plain ints / strs / dicts / lists only.
+    Resolving ANY global is refused, so none of them can run code either."""
+
+    def find_class(self, module, name):
+        raise pickle.UnpicklingError('global {}.{} is not allowed in a model-zoo file'.format(module, name))
+
+    def persistent_load(self, pid):
+        raise pickle.UnpicklingError('unexpected persistent id {!r}'.format(pid))
+
+
+def _plain(f, kind, what):
+    v = _PlainUnpickler(f).load()
+    if not isinstance(v, kind) or isinstance(v, bool):
+        raise ValueError('malformed legacy file: {} is a {}'.format(what, type(v).__name__))
+    return v
+
+
 def _strip(sd):
     """Accept the common wrappings: {'state_dict': ...} and DataParallel's 'module.' prefix
     (python/pytoch_to_onnx.py:14-20 strips the same prefix)."""
@@ -116,21 +146,30 @@ def load_state_dict_file(path_or_file):
         f.seek(-len(head), io.SEEK_CUR)
         if head == b'PK':
             raise ValueError('zip-format checkpoint: the MoePhoto zoo uses the legacy format; convert it first')
-        magic = pickle.load(f)
+        magic = _plain(f, int, 'the magic number')
         if magic != MAGIC_NUMBER:
             raise ValueError('not a torch legacy-format file (bad magic)')
-        proto = pickle.load(f)
+        proto = _plain(f, int, 'the protocol version')
         if proto != PROTOCOL_VERSION:
             raise ValueError('unsupported legacy protocol {}'.format(proto))
-        sys_info = pickle.load(f)
+        sys_info = _plain(f, dict, 'sys_info')
         if not sys_info.get('little_endian', True):
             raise ValueError('big-endian checkpoints are not supported')
         up = _ZooUnpickler(f)
         obj = up.load()
-        keys = pickle.load(f)
+        if not isinstance(obj, dict):
+            raise ValueError('malformed legacy file: the payload is a {}, not a state dict'.format(type(obj).__name__))
+        keys = _plain(f, list, 'the storage key list')
         for key in keys:
+            if not isinstance(key, str):
+                raise ValueError('malformed legacy file: storage key {!r}'.format(key))
             st = up.storages.get(key)
-            (numel,) = struct.unpack('<q', f.read(8))
+            head8 = f.read(8)
+            if len(head8) != 8:
+                raise ValueError('truncated storage header {}'.format(key))
+            (numel,) = struct.unpack('<q', head8)
+            if numel < 0 or (st is not None and numel != st.numel):
+                raise ValueError('storage {} holds {} elements, the state dict announced {}'.format(key, numel, st.numel if st is not None else '?'))
             dt = st.stype.dtype if st is not None else np.dtype('<f4')
             raw = f.read(numel * dt.itemsize)
             if len(raw) != numel * dt.itemsize:

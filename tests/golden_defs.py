@@ -16,6 +16,7 @@ ZOO = os.path.join(GOLDEN, 'zoo')            # copies of the reference's weight 
 # model key -> (arch name used by oracle/engine, zoo-relative path or None when synthetic, scale)
 MODELS = OrderedDict([
     ('a2', ('net2x', 'model/a2/model_new.pth', 2)),
+    ('p2', ('net2x', 'model/p2/model_new.pth', 2)),
     ('a3', ('net3x', None, 3)),
     ('a4', ('net4x', None, 4)),
     ('dn_lite5', ('netdn', 'model/dn_lite5/model_new.pth', 1)),

@@ -692,3 +692,66 @@ def test_fused_arsb_matches_two_launch_form(dev):
             os.environ.pop('MOE_ARSB_FUSE', None)
         else:
             os.environ['MOE_ARSB_FUSE'] = old
+
+
+RESIZE = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(G, 'resize', '*.npz')) if 'scale_factors' not in p)
+
+
+@pytest.mark.parametrize('name', RESIZE)
+def test_resize_kernel_vs_reference_golden(name, dev):
+    """moe_resize (the `resize` step, python/imageProcess.py:555-556) against the reference's outputs: fp32 I/O to 3e-6 (the index
+    arithmetic is not contracted, so neighbours and weights are the reference's), fp16 I/O to half an ulp of the result."""
+    from moephoto_amd import imageProcess as ip
+    z = np.load(os.path.join(G, 'resize', name + '.npz'))
+    shape = tuple(int(v) for v in z['shape'])
+    h, w = [int(v) for v in z['hw']]
+    x = gd.natural_image(77, shape) if str(z['kind']) == 'natural' else gd.noise_image(77, shape)
+    y = ip.resizeByTorch(torch.from_numpy(x).to(dev), w, h, str(z['method']))
+    assert tuple(y.shape) == z['y'].shape and y.dtype == torch.float32
+    assert np.abs(y.cpu().numpy() - z['y']).max() <= 3e-6
+    y16 = ip.resizeByTorch(torch.from_numpy(x).to(dev).half(), w, h, str(z['method']))
+    assert y16.dtype == torch.float16
+    from oracle import resize as oresize
+    want16 = oresize.resize(x.astype(np.float16).astype(np.float32), w, h, str(z['method']))
+    assert np.abs(y16.float().cpu().numpy() - want16).max() <= 1e-3          # fp16 result: half an ulp of values up to 2
+
+
+def test_resize_step_in_chain(dev, tmp_path):
+    """§8(f)3: the step chain [SR, resize] through procedure.genProcess -- the reference's `resize` closure with scale factors
+    (target size rounded like python/imageProcess.py:185-186), device resident between upload and download."""
+    from moephoto_amd import imageProcess as ip, procedure
+    from moephoto_amd.config import config
+    from oracle import resize as oresize
+    z = np.load(os.path.join(G, 'resize', 'scale_factors.npz'))
+    x = gd.natural_image(78, (3, 33, 47))
+    f = ip.resize({'scaleH': 1.7, 'scaleW': 0.6}, {'source': False})
+    y = f(torch.from_numpy(x).to(dev))
+    assert tuple(y.shape) == z['y'].shape == (3, 56, 28)
+    assert np.abs(y.cpu().numpy() - z['y']).max() <= 3e-6
+    config.modelRoot, config.crop_sr, config.fp16, config.deviceId = gd.ZOO, 64, False, 0
+    ip.modelCache.clear()
+    img = gd.to_u8(gd.natural_image(35, (3, 72, 88)))
+    process, nodes = procedure.genProcess([{'op': 'SR', 'model': 'a', 'scale': 2, 'ensemble': 0}, {'op': 'resize', 'width': '100', 'height': '90', 'method': 'bilinear'}])
+    assert [n['op'] for n in nodes] == ['SR', 'resize']
+    out = process(img)
+    assert out.shape == (90, 100, 3) and out.dtype == np.uint8
+    xf = oio.to_float_image(img)
+    pl = oplanner.prepare((3, 72, 88), 1 << 40, 1e-3, 5, 2, 8, 64)
+    sr = ostitch.do_crop(xf, pl, 2, onets.model_fn('net2x', gd.state_dict_for('a2', load_state_dict_file)))
+    want = oio.to_output(oio.to_hwc(oresize.resize(sr, 100, 90, 'bilinear')))
+    d = np.abs(out.astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 0.1
+    with pytest.raises(ValueError):
+        ip.resizeByTorch(torch.from_numpy(x).to(dev), 10, 10, 'area')
+
+
+def test_p2_through_plugin_table(dev):
+    """`p2` (the second real Net2x weight file of the zoo) through runSR's table: {'model': 'p', 'scale': 2} -> ./model/p2/model_new.pth."""
+    from moephoto_amd import runSR
+    opt = _opt_sr('p', 2, 48)
+    x = gd.natural_image(103, (3, 60, 72))
+    y = runSR.sr(opt)(torch.from_numpy(x).to(dev)).cpu().numpy()
+    sd = gd.state_dict_for('p2', load_state_dict_file)
+    pl = oplanner.prepare((3, 60, 72), 1 << 40, 1e-3, 5, 2, 8, 48)
+    want = ostitch.do_crop(x, pl, 2, onets.model_fn('net2x', sd))
+    assert np.abs(y - want).max() <= TOL

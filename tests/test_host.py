@@ -50,6 +50,34 @@ def test_reader_rejects_foreign_globals(tmp_path):
         pickle.dump(os.getcwd, f, protocol=2)
     with pytest.raises(pickle.UnpicklingError):
         load_state_dict_file(str(p))
+    # ... nor in the auxiliary pickles around the state dict (magic / protocol / sys_info / key list)
+    for slot in range(3):
+        e = tmp_path / 'evil_aux{}.pth'.format(slot)
+        with open(e, 'wb') as f:
+            for i, good in enumerate((0x1950a86a20f9469cfc6c, 1001, {'little_endian': True})):
+                pickle.dump(os.getcwd if i == slot else good, f, protocol=2)
+        with pytest.raises(pickle.UnpicklingError):
+            load_state_dict_file(str(e))
+    # a tensor view that reaches past its storage is refused (as_strided would read out of bounds)
+    good = os.path.join(gd.ZOO, 'model', 'dn_lite5', 'model_new.pth')
+    raw = bytearray(open(good, 'rb').read())
+    sd = load_state_dict_file(good)
+    first = next(iter(sd.values()))
+    import struct as _st
+    # the first storage's element count sits right after the key-list pickle: shrink it -> the announced and stored counts disagree
+    idx = raw.rfind(_st.pack('<q', first.size))
+    assert idx > 0
+    bad = tmp_path / 'short.pth'
+    bad.write_bytes(bytes(raw[:idx]) + _st.pack('<q', first.size - 1) + bytes(raw[idx + 8:]))
+    with pytest.raises(ValueError):
+        load_state_dict_file(str(bad))
+    from moephoto_amd.weights import _LazyStorage, _LazyTensor, _StorageType
+    st = _LazyStorage(_StorageType('FloatStorage'), 'k', 6)
+    st.data = np.arange(6, dtype='<f4')
+    assert _LazyTensor(st, 0, (2, 3), (3, 1)).materialize().tolist() == [[0, 1, 2], [3, 4, 5]]
+    for off, size, stride in ((1, (2, 3), (3, 1)), (0, (2, 4), (3, 1)), (0, (2, 3), (-3, 1)), (7, (), ())):
+        with pytest.raises(ValueError):
+            _LazyTensor(st, off, size, stride).materialize()
     q = tmp_path / 'notzoo.pth'
     q.write_bytes(b'PK\x03\x04 zip')
     with pytest.raises(ValueError):

@@ -167,3 +167,19 @@ def test_to_output_known_answers():
     assert oio.to_output(v, 8).reshape(-1).tolist() == m['to_output_known'] == [255, 128, 0, 255, 1, 0]
     v16 = np.array([[[0.5, 0.99999, 1.2]]], np.float32)
     assert oio.to_output(v16, 16).reshape(-1).tolist() == m['to_output16_known']
+
+
+RESIZE = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(gd.GOLDEN, 'resize', '*.npz')) if 'scale_factors' not in p)
+
+
+@pytest.mark.parametrize('name', RESIZE)
+def test_resize_oracle_vs_reference_golden(name):
+    """oracle.resize (numpy restatement of torch's upsample arithmetic) against the reference's resizeByTorch outputs."""
+    from oracle import resize as oresize
+    z = np.load(os.path.join(gd.GOLDEN, 'resize', name + '.npz'))
+    shape = tuple(int(v) for v in z['shape'])
+    h, w = [int(v) for v in z['hw']]
+    x = gd.natural_image(77, shape) if str(z['kind']) == 'natural' else gd.noise_image(77, shape)
+    y = oresize.resize(x, w, h, str(z['method']))
+    assert y.shape == z['y'].shape
+    assert np.abs(y - z['y']).max() <= (3e-6 if str(z['method']) == 'bicubic' else 2e-7)

@@ -5,6 +5,7 @@ own tests pin nothing on this path, so these vectors -- ou
 reference's PyTorch-CPU fp32 path -- are what the oracle, and through it the HIP path, is pinned to.
 
     python tools/gen_golden.py            # regenerate everything (about a minute)
+    python tools/gen_golden.py nets:p2 resize   # only the named sections (manifest.json is merged, not rewritten)
 
 Stored: outputs only (inputs/weights are re-derived from seeds, see tests/golden_defs.py).
 While generating, the oracle restatement is compared against the reference (final outputs and
@@ -106,13 +107,15 @@ def gen_planner(r):
 
 
 NET_CASES = [  # key, seed, (h, w)
-    ('a2', 11, (40, 48)), ('a3', 12, (40, 48)), ('a4', 13, (40, 48)), ('dn_lite5', 14, (40, 48)), ('dn_lite10', 15, (40, 48)),
+    ('a2', 11, (40, 48)), ('p2', 21, (40, 48)), ('a3', 12, (40, 48)), ('a4', 13, (40, 48)), ('dn_lite5', 14, (40, 48)), ('dn_lite10', 15, (40, 48)),
     ('dn_lite15', 16, (40, 48)), ('l25', 17, (40, 48)), ('lite2', 18, (40, 48)), ('lite4', 19, (40, 48)), ('lite8', 20, (16, 24)),
 ]
 
 
-def gen_nets(r):
+def gen_nets(r, only=None):
     for key, seed, (h, w) in NET_CASES:
+        if only and key not in only:
+            continue
         arch = gd.MODELS[key][0]
         sd = gd.state_dict_for(key, load_state_dict_file)
         m = ref_model(r, key, sd)
@@ -268,16 +271,71 @@ def gen_e2e(r):
     manifest['to_output16_known'] = q16.reshape(-1).tolist()
 
 
+RESIZE_CASES = [  # name, (C, H, W), (h, w), method, input kind
+    ('bilinear_up', (3, 24, 40), (50, 77), 'bilinear', 'natural'), ('bilinear_down', (3, 45, 64), (20, 31), 'bilinear', 'noise'),
+    ('bilinear_2x', (3, 16, 24), (32, 48), 'bilinear', 'natural'), ('nearest_up', (3, 17, 23), (40, 50), 'nearest', 'noise'),
+    ('nearest_down', (4, 40, 56), (13, 19), 'nearest', 'natural'), ('bicubic_up', (3, 20, 28), (45, 61), 'bicubic', 'natural'),
+    ('bicubic_down', (3, 48, 40), (21, 18), 'bicubic', 'noise'), ('bilinear_720p_row', (1, 9, 1920), (6, 1280), 'bilinear', 'natural'),
+]
+
+
+def gen_resize(r):
+    """The `resize` step (python/imageProcess.py:174-195 through resizeByTorch :555-556) on seeded inputs, plus one pass through the
+    reference's own `resize(opt, out)` closure with scale factors (rounding of the target size)."""
+    from oracle import resize as oresize
+    ip = r.imageProcess
+    worst = 0.0
+    for name, shape, (h, w), method, kind in RESIZE_CASES:
+        x = gd.natural_image(77, shape) if kind == 'natural' else gd.noise_image(77, shape)
+        if method == 'nearest':
+            # the reference passes align_corners=False with every method, which torch refuses for 'nearest' (ValueError): its UI's
+            # "nearest" choice cannot run.  The vector is torch's own nearest (no align_corners), which is what the option means.
+            try:
+                ip.resizeByTorch(torch.from_numpy(x), w, h, method)
+                manifest['reference_nearest_raises'] = False
+            except ValueError:
+                manifest['reference_nearest_raises'] = True
+            y = torch.nn.functional.interpolate(torch.from_numpy(x).unsqueeze(0), size=(h, w), mode='nearest').squeeze(0).numpy()
+        else:
+            y = ip.resizeByTorch(torch.from_numpy(x), w, h, method).numpy().reshape(shape[0], h, w)
+        save_npz('resize/{}.npz'.format(name), y=y, shape=np.array(shape), hw=np.array([h, w]), method=np.array(method), kind=np.array(kind))
+        d = float(np.abs(oresize.resize(x, w, h, method) - y).max())
+        worst = max(worst, d)
+        print('resize {:18s} oracle-vs-ref {:.2e}'.format(name, d))
+    x = gd.natural_image(78, (3, 33, 47))
+    f = ip.resize({'scaleH': 1.7, 'scaleW': 0.6}, {'source': False})
+    y = f(torch.from_numpy(x)).numpy()
+    save_npz('resize/scale_factors.npz', y=y, shape=np.array([3, 33, 47]), scale=np.array([1.7, 0.6]))
+    manifest['oracle_vs_reference']['resize'] = worst
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     r = load_reference()
     tmp = tempfile.mkdtemp()
     with_synth_zoo(r, tmp)
+    sel = sys.argv[1:]
+    if sel:       # partial regeneration: merge into the existing manifest
+        old = json.load(open(os.path.join(OUT, 'manifest.json')))
+        for s_ in sel:
+            if s_.startswith('nets:'):
+                gen_nets(r, only=s_[5:].split(','))
+            elif s_ == 'resize':
+                gen_resize(r)
+            else:
+                raise SystemExit('unknown section ' + s_)
+        old['files'].update(manifest['files'])
+        old['oracle_vs_reference'].update(manifest['oracle_vs_reference'])
+        with open(os.path.join(OUT, 'manifest.json'), 'w') as f:
+            json.dump(old, f, indent=1, sort_keys=True)
+        print('updated', OUT)
+        return
     gen_planner(r)
     gen_nets(r)
     gen_stitch_only(r)
     gen_stitched(r)
     gen_e2e(r)
+    gen_resize(r)
     with open(os.path.join(OUT, 'manifest.json'), 'w') as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     print('wrote', OUT)
