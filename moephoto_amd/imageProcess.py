@@ -141,26 +141,24 @@ def prepare(shape, ram, opt, pad, sc, align=8, cropsize=0):
 
 
 class Option(object):
-    """python/imageProcess.py:379-395."""
+    """The per-op settings bag of python/imageProcess.py:379-395: the adapters (runSR / runDN .getOpt) fill in the fields, doCrop and
+    the pipeline builder read them, and calling it runs the net on one tile batch (a list result means "take the last entry")."""
+    _DEFAULTS = dict(ramCoef=1e-3, count=0, padding=1, cropsize=0, align=8, fixChannel=1, scale=1, ensemble=0, strength=1.0,
+                     outShape=None, oShape=None, iterClip=None, modelCached=None)
 
     def __init__(self, path=''):
-        self.ramCoef, self.count = 1e-3, 0
-        self.padding, self.cropsize, self.align, self.fixChannel = 1, 0, 8, 1
-        self.scale, self.ensemble, self.strength = 1, 0, 1.0
+        for name, value in self._DEFAULTS.items():
+            setattr(self, name, value)
         self.model = path
-        self.outShape, self.oShape = None, None
-        self.iterClip = None
         self.prepare = identity
-        self.squeeze = lambda x: x.squeeze(0)
-        self.unsqueeze = lambda x: x.unsqueeze(0)
-        self.modelCached = None
-        self._plans = {}
+        # planes-as-batch adapters; the SR / DN tables replace them with dim-1 versions
+        self.squeeze = lambda t: t.squeeze(0)
+        self.unsqueeze = lambda t: t.unsqueeze(0)
+        self._plans = {}          # image shape -> [TilePlan, uses]  (LRU, see _plan_for)
 
     def __call__(self, x, *args, **kwargs):
-        out = self.modelCached(x, *args, **kwargs)
-        if type(out) == list:
-            out = out[-1]
-        return out
+        result = self.modelCached(x, *args, **kwargs)
+        return result[-1] if isinstance(result, list) else result
 
 
 def getStateDict(path):
@@ -178,21 +176,21 @@ def castModel(model):
 
 
 def initModel(opt, weights=None, key=None, f=lambda opt: opt.modelDef(), args=[]):
-    """python/imageProcess.py:319-334."""
-    if key and key in modelCache:
-        return castModel(modelCache[key])
-    log.info('loading model {}'.format(opt.model))
-    model = f(opt, *args)
-    if weights:
-        log.info('reloading weights')
-        if type(weights) == str:
-            weights = getStateDict(weights)
-        model.load_state_dict(weights)
-    for param in model.parameters():
-        param.requires_grad_(False)
-    model.eval()
-    if key:
-        modelCache[key] = model
+    """python/imageProcess.py:319-334: one instance per cache key for the life of the process; construction = constructor slot of
+    the plugin table, strict load_state_dict (a path is read through the zoo parser), frozen, eval; every call re-casts to the
+    configured dtype / device (castModel)."""
+    model = modelCache.get(key) if key else None
+    if model is None:
+        log.info('loading model {}'.format(opt.model))
+        model = f(opt, *args)
+        if weights:
+            log.info('reloading weights')
+            model.load_state_dict(getStateDict(weights) if isinstance(weights, str) else weights)
+        for p in model.parameters():
+            p.requires_grad_(False)
+        model.eval()
+        if key:
+            modelCache[key] = model
     return castModel(model)
 
 
@@ -311,12 +309,28 @@ def restrictSize(width, height=0, method='bilinear'):
 
 
 # ---- self-ensemble (python/imageProcess.py:563-572) -------------------------------------------------
-transpose = lambda x: x.transpose(-1, -2)
-flip = lambda x: x.flip(-1)
-flip2 = lambda x: x.flip(-1, -2)
-combine = lambda *fs: lambda x: reduce(apply, fs, x)
-trans = [transpose, flip, flip2, combine(flip, transpose), combine(transpose, flip), combine(transpose, flip, transpose), combine(flip2, transpose)]
-transInv = [transpose, flip, flip2, trans[4], trans[3], trans[5], trans[6]]
+def _dihedral(t, fh, fv):
+    """One element of the square's symmetry group as (transpose first?, flip width?, flip height?), and its inverse."""
+    def fwd(x):
+        if t:
+            x = x.transpose(-1, -2)
+        dims = ([-1] if fh else []) + ([-2] if fv else [])
+        return x.flip(*dims) if dims else x
+
+    def inv(x):
+        dims = ([-1] if fh else []) + ([-2] if fv else [])
+        if dims:
+            x = x.flip(*dims)
+        return x.transpose(-1, -2) if t else x
+    return fwd, inv
+
+
+# the seven non-identity symmetries in the reference's order (python/imageProcess.py:563-569: transpose, flip, flip2, flip.transpose,
+# transpose.flip, transpose.flip.transpose, flip2.transpose -- "a.b" applies a first); transpose.flip.transpose is a height flip
+_SYMMETRIES = [_dihedral(True, False, False), _dihedral(False, True, False), _dihedral(False, True, True), _dihedral(True, False, True),
+               _dihedral(True, True, False), _dihedral(False, False, True), _dihedral(True, True, True)]
+trans = [f for f, _ in _SYMMETRIES]
+transInv = [g for _, g in _SYMMETRIES]
 
 
 def ensemble(opt):
@@ -331,35 +345,36 @@ def ensemble(opt):
 
 
 # ---- DN wrapper (python/imageProcess.py:336-377, 562) -----------------------------------------------
-strengthOp = lambda x, inp, s=1: x if s == 1 else s * x + (1 - s) * inp
+def strengthOp(x, inp, s=1):
+    """Blend the denoised image with its input: s * x + (1 - s) * inp (python/imageProcess.py:562)."""
+    return x if s == 1 else s * x + (1 - s) * inp
 
 
 def extractAlpha(t):
+    """Splits a 4-plane image into RGB (returned) and alpha (kept in `t`); other plane counts pass through."""
     def f(im):
-        if im.shape[0] == 4:
-            t['im'] = im[3]
-            return im[:3]
-        return im
+        if im.shape[0] != 4:
+            return im
+        t['im'] = im[3]
+        return im[:3]
     return f
 
 
 def mergeAlpha(t):
+    """Re-attaches the alpha plane extractAlpha put aside (none: the image passes through)."""
     def f(im):
-        if len(t):
-            image = torch.empty((4, *im.shape[1:]), dtype=im.dtype, device=im.device)
-            image[:3] = im
-            image[3] = t['im']
-            return image
-        return im
+        if 'im' not in t:
+            return im
+        return torch.cat([im, t['im'].unsqueeze(0).to(im.dtype)], 0)
     return f
 
 
 def _RGBFilter(opt, img):
-    t = {}
-    imgIn = opt.prepare(extractAlpha(t)(img))
-    prediction = doCrop(opt, imgIn)
-    out = strengthOp(prediction, imgIn, opt.strength)
-    return mergeAlpha(t)(out)
+    """The DN wrapper (python/imageProcess.py:350-377): the denoiser sees the colour planes only, `strength` blends its result
+    with the input, alpha rides around it."""
+    alpha = {}
+    rgb = opt.prepare(extractAlpha(alpha)(img))
+    return mergeAlpha(alpha)(strengthOp(doCrop(opt, rgb), rgb, opt.strength))
 
 
 RGBFilter = lambda opt: lambda img: _RGBFilter(opt, img)

@@ -19,16 +19,18 @@ mode_switch = {
 
 
 def getOpt(optDN):
-    model = optDN['model']
-    path, ctor, sd, padding, align = mode_switch[model]
-    opt = Option(os.path.join(config.modelRoot, path))
+    """python/runDN.py:25-38: step dict {'model': 'lite5', 'strength': 1.0} -> Option.  cropsize = config.crop_dn for the lite nets,
+    crop_dns for SEDN; planes become the batch along the table's squeeze dim."""
+    name = optDN['model']
+    rel_path, ctor, sq_dim, padding, align = mode_switch[name]
+    opt = Option(os.path.join(config.modelRoot, rel_path))
     opt.modelDef, opt.padding, opt.align = ctor, padding, align
     opt.strength = optDN.get('strength', 1.0)
-    opt.cropsize = config.getConfig()[1 if model[:4] == 'lite' else 2]
-    opt.modelCached = initModel(opt, opt.model, 'DN' + model)
+    crops = config.getConfig()
+    opt.cropsize = crops[1] if name.startswith('lite') else crops[2]
+    opt.modelCached = initModel(opt, opt.model, 'DN' + name)
     opt.ramCoef = engineRamCoef(opt.modelCached, 1)
-    if sd:
+    if sq_dim:
         opt.fixChannel = 0
-        opt.squeeze = lambda x: x.squeeze(sd)
-        opt.unsqueeze = lambda x: x.unsqueeze(sd)
+        opt.squeeze, opt.unsqueeze = (lambda t: t.squeeze(sq_dim)), (lambda t: t.unsqueeze(sq_dim))
     return opt

@@ -37,20 +37,21 @@ sr = lambda opt: (lambda x: ensemble(opt)(x) / (opt.ensemble + 1)) if opt.ensemb
 
 
 def getOpt(optSR):
-    opt = Option()
-    opt.mode = optSR['model']
-    opt.scale = optSR['scale']
-    nmode = opt.mode + str(opt.scale)
-    if nmode not in mode_switch:
+    """python/runSR.py:30-48: step dict {'model': 'a', 'scale': 4, 'ensemble': 0} -> Option, or None for an unknown model/scale pair.
+    Colour planes become the batch (dim-1 squeeze / unsqueeze), padding 9 for the x3 nets and 5 otherwise, cropsize = config.crop_sr."""
+    key = '{}{}'.format(optSR['model'], optSR['scale'])
+    entry = mode_switch.get(key)
+    if entry is None:
         return None
+    rel_path, ctor = entry
+    opt = Option(os.path.join(config.modelRoot, rel_path))
+    opt.mode, opt.scale, opt.modelDef = optSR['model'], optSR['scale'], ctor
     opt.fixChannel = 0
-    opt.squeeze = lambda x: x.squeeze(1)
-    opt.unsqueeze = lambda x: x.unsqueeze(1)
-    opt.padding = 9 if opt.scale == 3 else 5
-    opt.model = os.path.join(config.modelRoot, mode_switch[nmode][0])
-    opt.modelDef = mode_switch[nmode][1]
-    opt.ensemble = optSR['ensemble'] if 'ensemble' in optSR and (0 <= optSR['ensemble'] <= 7) else config.ensembleSR
+    opt.squeeze, opt.unsqueeze = (lambda t: t.squeeze(1)), (lambda t: t.unsqueeze(1))
+    opt.padding = {3: 9}.get(opt.scale, 5)
+    ens = optSR.get('ensemble')
+    opt.ensemble = ens if isinstance(ens, int) and 0 <= ens <= 7 else config.ensembleSR
     opt.cropsize = config.getConfig()[0]
-    opt.modelCached = initModel(opt, opt.model, 'SR' + nmode)
+    opt.modelCached = initModel(opt, opt.model, 'SR' + key)
     opt.ramCoef = engineRamCoef(opt.modelCached, opt.scale)
     return opt
