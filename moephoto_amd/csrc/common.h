@@ -79,6 +79,20 @@ struct ArsbArgs {
 bool launch_arsb_fused(ArsbArgs a, int max_groups, hipStream_t s);   // false: not applicable (caller runs the two convs)
 hipError_t arsb_fused_init();
 
+// One 3x3 64->64 conv with split operands, three products in one launch (conv64_x3.hip); weights in the fused-ARSB order
+struct ConvX3Args {
+    const half_t* in_hi; const half_t* in_lo;     // [B][H][W][64], low part in units of 2^-11
+    half_t* out_hi; half_t* out_lo;               // may alias res (never in)
+    const half_t* res_hi; const half_t* res_lo;   // residual (both or none)
+    const half_t* w_hi; const half_t* w_lo;       // [wave 4][fragment 18][lane 64][8]
+    const half_t* zero;
+    float slope;                                  // PReLU slope (1: none; <= 1)
+    int B, H, W;
+    int px, py;                                   // set by the launcher
+};
+bool launch_conv64_x3(ConvX3Args a, int max_groups, hipStream_t s);   // false: not applicable (caller uses the three-launch form)
+hipError_t conv64_x3_init();
+
 struct DirectConvArgs {
     const half_t* in; half_t* out; const half_t* res;
     const float* w;       // plain fp32 OIHW weights [cout][cin][k][k] (original channel counts)

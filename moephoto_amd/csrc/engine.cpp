@@ -55,6 +55,7 @@ struct ConvLayer {               // one MFMA convolution
     float slope = 1.f, scale = 1.f;
     bool per_plane = false;      // SEDN trans: weights rebuilt per plane by the SE kernel
     size_t w_hi = 0, w_lo = 0, bias = 0, bias_img = 0, w_plain = 0, bias_plain = 0, w_pk32 = 0;   // offsets into the device blob
+    size_t w_arsb_lo = 0;        // ... and their low parts ((w - fp16(w)) * 2^11) in the same order, for conv64_x3.hip
     size_t w_arsb = 0;           // 3x3 64->64 trunk convs: A fragments of v_mfma_f32_16x16x32_f16 in the fused ARSB kernel's order (arsb_fused.hip)
     size_t w_x3 = 0;             // 1x1, one segment, split precision: [chunk][w_lo | w_hi | w_hi] for the single-launch path (acc_mode 4)
     bool has_x3 = false;
@@ -284,10 +285,11 @@ void pack_conv(const Param& W, const Param* bias, int r, ConvLayer& L, BlobBuild
 // Fused-ARSB weight order (arsb_fused.hip): [wave w][fragment f = tap * 2 + kh][lane l][e], lane l = (m = l & 15, kq = l >> 4) holds
 // W[cout = 16w + m][cin = 8 * SL(kh, kq) + e][tap] with SL(kh, kq) = (2kh + (kq >> 1)) ^ 4(kq & 1) -- the k order in which that kernel's
 // bank-conflict-free LDS image delivers the activations
-static void pack_arsb(const Param& W, ConvLayer& L, BlobBuilder& bb, float fold)
+static void pack_arsb(const Param& W, ConvLayer& L, BlobBuilder& bb, float fold, bool want_lo)
 {
     const int cout = (int)W.shape[0], cin = (int)W.shape[1];
     L.w_arsb = bb.take((size_t)4 * 18 * 512 * 2);
+    if (want_lo) L.w_arsb_lo = bb.take((size_t)4 * 18 * 512 * 2);
     for (int w = 0; w < 4; ++w)
         for (int f = 0; f < 18; ++f) {
             const int tap = f >> 1, kh = f & 1;
@@ -297,7 +299,9 @@ static void pack_arsb(const Param& W, ConvLayer& L, BlobBuilder& bb, float fold)
                 for (int e = 0; e < 8; ++e) {
                     const int oc = 16 * w + m, ci = 8 * slot + e;
                     const float v = (oc < cout && ci < cin) ? W.data[((size_t)oc * cin + ci) * 9 + tap] * fold : 0.f;
-                    bb.at<half_t>(L.w_arsb)[((size_t)(w * 18 + f) * 64 + l) * 8 + e] = (half_t)v;
+                    const half_t hv = (half_t)v;
+                    bb.at<half_t>(L.w_arsb)[((size_t)(w * 18 + f) * 64 + l) * 8 + e] = hv;
+                    if (want_lo) bb.at<half_t>(L.w_arsb_lo)[((size_t)(w * 18 + f) * 64 + l) * 8 + e] = (half_t)((v - (float)hv) * 2048.f);
                 }
             }
         }
@@ -319,8 +323,8 @@ static int build_device_weights(moe_net& n, int precision)
         // the debug path keeps the plain weights and applies the scale in its epilogue; the MFMA kernels get it pre-multiplied
         pack_conv(*n.get(wname), b, r, L, bb, lo, plain, per_plane, plain ? 1.f : scale);
         L.slope = slope; L.scale = plain ? scale : 1.f; L.per_plane = per_plane;
-        if (!plain && r == 1 && L.taps == 9 && L.nseg == 1 && L.nchunks == 1 && (key.compare(0, 3, "c1_") == 0 || key.compare(0, 3, "c2_") == 0))
-            pack_arsb(*n.get(wname), L, bb, scale);
+        if (!plain && r == 1 && L.taps == 9 && L.nseg == 1 && L.nchunks == 1 && (key == "input2" || key.compare(0, 3, "c1_") == 0 || key.compare(0, 3, "c2_") == 0))
+            pack_arsb(*n.get(wname), L, bb, scale, lo);
         n.conv_index[key] = (int)n.convs.size();
         n.convs.push_back(L);
     };
@@ -629,6 +633,20 @@ struct Fwd {
             ConvArgs f4 = a; f4.wpk = blob<half_t>(L.w_x3); f4.acc_mode = 4; f4.in_lo = in.lo; f4.out_lo = out.lo; f4.res_lo = res ? res->lo : nullptr;
             launch_conv_mfma(f4, 1, 3, s);
             return true;
+        }
+        {   // 3x3 64->64 with both weight parts packed for it: all three products in ONE launch (conv64_x3.hip)
+            const char* e1 = getenv("MOE_X3_FUSE");
+            if (!(e1 && !strcmp(e1, "0")) && fast && L.w_arsb_lo && in.lo && out.lo && (!res || res->lo) && !tplanes && !L.has_bias) {
+                ConvX3Args q{};
+                q.in_hi = in.hi; q.in_lo = in.lo; q.out_hi = out.hi; q.out_lo = out.lo;
+                q.res_hi = res ? res->hi : nullptr; q.res_lo = res ? res->lo : nullptr;
+                q.w_hi = blob<half_t>(L.w_arsb); q.w_lo = blob<half_t>(L.w_arsb_lo); q.zero = small<half_t>("zero");
+                q.slope = L.slope; q.B = B; q.H = H; q.W = W;
+                const int rec = prof_begin(key, 3 * 2.0 * (double)B * H * W * L.cout * L.cin * L.taps);
+                const bool ok = launch_conv64_x3(q, n.max_groups, s);
+                prof_end(rec);
+                if (ok) return true;
+            }
         }
         if (fast && L.nchunks <= 16) {
             // 3x3 conv: the two low-order products run on the fast kernel as ordinary fp16-output convolutions --

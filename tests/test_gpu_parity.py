@@ -684,7 +684,10 @@ def test_fused_arsb_matches_two_launch_form(dev):
                     # same operands, same rounding points; only the fp32 summation order inside a conv differs, which flips an fp16 rounding
                     # of conv_1's output now and then -- and, in 'fp16' mode, of the stream itself (one ulp of a value near 1 is 5e-4,
                     # amplified ~2x by the upsampler).  The trunk taps of the two forms agree to four digits (tools/diag_arsb.py).
-                    assert np.abs(y1 - y0).max() <= (1e-3 if prec == 'fp16' else 5e-4), (key, shape, kind, prec, nb, float(np.abs(y1 - y0).max()))
+                    # White noise drives a2 to +-1.9 and every flipped rounding is amplified: there the two forms may differ by as much as
+                    # either differs from the oracle (with nb = 0 on noise that is itself ~1e-3); on natural images they agree to 2e-4.
+                    bound = 2.5e-4 if kind == 'natural' else 1e-3
+                    assert np.abs(y1 - y0).max() <= bound, (key, shape, kind, prec, nb, float(np.abs(y1 - y0).max()))
                     if prec == 'mixed' and nb == -1:
                         assert np.abs(y1 - want).max() <= TOL, (key, shape, kind, float(np.abs(y1 - want).max()))
     finally:
@@ -755,3 +758,36 @@ def test_p2_through_plugin_table(dev):
     pl = oplanner.prepare((3, 60, 72), 1 << 40, 1e-3, 5, 2, 8, 48)
     want = ostitch.do_crop(x, pl, 2, onets.model_fn('net2x', sd))
     assert np.abs(y - want).max() <= TOL
+
+
+def test_split_operand_conv_single_launch(dev):
+    """conv64_x3.hip (the three split-operand products of a 3x3 64->64 layer in one launch, both weight parts in registers) against the
+    three-launch form (MOE_X3_FUSE=0) and the oracle: every epilogue (plain = conv_input2, PReLU = conv_1, residual = conv_2), ragged
+    shapes, 48- and 64-channel nets.  With all six ARSBs split the trunk is ~fp32: the taps must agree with the oracle to ~1e-6."""
+    old = os.environ.get('MOE_X3_FUSE')
+    try:
+        for key, shape in (('a2', (3, 8, 16)), ('a2', (3, 24, 40)), ('a2', (2, 40, 264)), ('a2', (3, 9, 35)), ('dn_lite5', (3, 33, 31)), ('dn_lite5', (5, 88, 64))):
+            arch = gd.MODELS[key][0]
+            sd = gd.state_dict_for(key, load_state_dict_file)
+            x = gd.noise_image(19, shape)[:, None]
+            taps = {}
+            want = onets.forward(arch, sd, x, 'torch', taps).numpy()
+            xd = torch.from_numpy(x).to(dev)
+            m = module_for(key, 'mixed').set_exact_blocks(6).set_debug(True)
+            res = {}
+            for fuse in ('0', '1'):
+                os.environ['MOE_X3_FUSE'] = fuse
+                y = m(xd)[-1].cpu().numpy()
+                res[fuse] = (y, {k: m.debug_tap(k) for k in ('input2', 'arsb1', 'arsb6')})
+            m.set_debug(False).set_exact_blocks(-1)
+            for k in ('input2', 'arsb1', 'arsb6'):
+                w = taps[k].numpy()
+                scale = max(1.0, float(np.abs(w).max()))
+                assert np.abs(res['1'][1][k] - w).max() <= 2e-6 * scale, (key, shape, k, float(np.abs(res['1'][1][k] - w).max()))
+                assert np.abs(res['1'][1][k] - res['0'][1][k]).max() <= 2e-6 * scale, (key, shape, k)
+            assert np.abs(res['1'][0] - want).max() <= TOL
+    finally:
+        if old is None:
+            os.environ.pop('MOE_X3_FUSE', None)
+        else:
+            os.environ['MOE_X3_FUSE'] = old

@@ -86,3 +86,24 @@ for prec, nb in (('fp16', None), ('mixed', 0), ('mixed', 1)):
                  for k, p in zip(('arsb', 'c1_', 'c2_'), pr)]
         print('a4 B=12 256x256 {} nb={} fuse={}: forward {:.3f} ms | {}'.format(prec, nb, fuse, e0.elapsed_time(e1) / 5, ' | '.join(parts)))
         del m
+
+# ---- split-operand layers: one launch (conv64_x3.hip) vs three ----------------------------------------------------------------
+for fuse in ('0', '1'):
+    os.environ['MOE_X3_FUSE'] = fuse
+    m = make('a4', 'mixed', 1)
+    for _ in range(2):
+        m(x)
+    m.set_profile('input2,c1_1,c2_1')
+    for _ in range(3):
+        m(x)
+    pr = m.get_profile(all_keys=True)
+    m.set_profile(None)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        m(x)
+    e1.record()
+    torch.cuda.synchronize()
+    parts = ['{} {} launches avg {:.4f} ms'.format(k, p['launches'], p['total_ms'] / max(1, p['launches'])) for k, p in zip(('input2', 'c1_1', 'c2_1'), pr)]
+    print('a4 B=12 256x256 mixed nb=1 x3-fuse={}: forward {:.3f} ms | {}'.format(fuse, e0.elapsed_time(e1) / 5, ' | '.join(parts)))
+    del m
