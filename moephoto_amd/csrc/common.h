@@ -55,6 +55,7 @@ struct ConvArgs {
     // fused tail (conv3x3_sp EPI 3): A fragments of the 64->1 tail conv and the planar fp32 per-tap sums [9][B][H*r][W*r]
     const half_t* tail_w;
     float* tplanes;
+    int tail_split;       // fused tail: also split the activation operand (EPI 7; tail_w then holds eight fragments, the second four = fp16 weights in rows 16..24)
     int dbg;              // timing ablations (MOE_DBG env; results are wrong when set): 1 no patch DMA, 2 no MFMA, 4 no stores, 8 no epilogue
 };
 

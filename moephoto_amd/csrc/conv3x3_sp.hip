@@ -207,7 +207,10 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
     //   4  split-precision FINAL pass: + side16 * 2^-11 (the two low-order products), PReLU in fp32, hi AND lo outputs
     //   5  the same with the residual add (its low part was folded into side16 by the engine)
     //   6  LeakyReLU/PReLU in fp32, THEN the residual add; per-plane weights (see PLANEW above)
-    constexpr bool ACT = (EPI == 1) || (EPI == 3), RES = (EPI == 2) || (EPI == 5) || (EPI == 6), TAIL = (EPI == 3), X3 = (EPI == 4) || (EPI == 5);
+    //   7  = 3 with the tail conv's ACTIVATION operand split as well: PReLU in fp32, act = hi + lo 2^-11, a second 8-MFMA GEMM multiplies lo by
+    //      the fp16 tail weights placed in rows 16..24 (where the low-order sums of the weight split already accumulate): MOE_PREC_MIXED, R branch
+    constexpr bool ACT = (EPI == 1) || (EPI == 3), RES = (EPI == 2) || (EPI == 5) || (EPI == 6), TAIL = (EPI == 3) || (EPI == 7), X3 = (EPI == 4) || (EPI == 5);
+    constexpr bool TAIL2 = (EPI == 7);
     constexpr int DRAIN0 = 0;      // first of the eight k-steps that carry a slice of the previous tile's epilogue
     unsigned slope2;               // {slope, slope} as packed halves
     {
@@ -216,11 +219,13 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         slope2 = __builtin_bit_cast(unsigned, s2);
     }
     // fused tail: A fragments of the 64->1 conv for the four 16-channel k-slices, rows = taps (9 of 32 used)
-    half8_t tailw[4];
+    half8_t tailw[4], tailw2[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         tailw[i] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        tailw2[i] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
         if (TAIL) tailw[i] = *(const half8_t*)(a.tail_w + i * 512 + lane * 8);
+        if (TAIL2) tailw2[i] = *(const half8_t*)(a.tail_w + (4 + i) * 512 + lane * 8);     // rows 16..24 = fp16 tail weights (engine.cpp)
     }
     float16_t Gacc[2];
 #pragma unroll
@@ -284,7 +289,23 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         // v_pk_* per register pair instead of v_mul_f32 + v_max_f32 per value (-64 VALU per tile).  The negative branch is rounded
         // three times instead of once; on the goldens the end-to-end error is unchanged (a2 7.0e-4 -> 6.6e-4, a4 5.3e-4 -> 5.5e-4).
         unsigned hv[4];            // the eight values as four half2 registers (v[2k], v[2k+1])
-        if (!RES && !X3) {
+        unsigned lv[4];            // TAIL2: their rounding remainders (v - hi) * 2^11
+        if (TAIL2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t = v[e] * a.slope;
+                asm("v_max_f32 %0, %1, %2" : "=v"(v[e]) : "v"(v[e]), "v"(t));       // PReLU in fp32 (slope <= 1)
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+                const half2_t pr = {(half_t)v[2 * k], (half_t)v[2 * k + 1]};
+                hv[k] = __builtin_bit_cast(unsigned, pr);
+                const half2_t lo = {(half_t)__builtin_fmaf((float)pr[0], -2048.f, v[2 * k] * 2048.f), (half_t)__builtin_fmaf((float)pr[1], -2048.f, v[2 * k + 1] * 2048.f)};
+                lv[k] = __builtin_bit_cast(unsigned, lo);
+            }
+        }
+        if (!RES && !X3 && !TAIL2) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
@@ -300,6 +321,10 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         if (TAIL) {
             const half8_t bf = __builtin_bit_cast(half8_t, make_uint4(hv[0], hv[1], hv[2], hv[3]));   // k = 8*hh + e  <->  channel nb*32 + 16*gp + perm(hh, e)
             Gacc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tailw[nb * 2 + gp], bf, Gacc[o], 0, 0, 0);
+            if (TAIL2) {
+                const half8_t bl = __builtin_bit_cast(half8_t, make_uint4(lv[0], lv[1], lv[2], lv[3]));
+                Gacc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tailw2[nb * 2 + gp], bl, Gacc[o], 0, 0, 0);
+            }
             if ((s8 & 3) == 3) {     // row o complete: lane (j, hh) holds taps 4*hh .. 4*hh+3 in regs 0..3 and tap 8 + 4*hh in reg 4
                 // rows 16..24 of the A fragments hold the rounding remainders of the tail weights (units of 2^-11, engine.cpp): the
                 // same MFMAs formed the low-order sums in regs 8..12 -- fold them in (5 FMAs per row for ~22-bit tail weights)
@@ -549,6 +574,10 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, SGB_VALU_B, 0);
             }
+            if (TAIL2 && s >= DRAIN0 && s < DRAIN0 + 8) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, SGB_VALU_B, 0);
+            }
             // Nothing moves across a k-step boundary.  As ONE region the sched_group_barrier slot pattern drifts whenever the amount of
             // filler work per step changes (a 13th MFMA in the fused-tail variant, fewer VALU after an epilogue diet ...) until the
             // LDS reads sit right in front of their consumers: 39-83 of 100 reads with < 6 MFMAs of distance and +15 % cycles were
@@ -619,6 +648,7 @@ hipError_t conv3x3_sp_init()
     if ((e = set_limit<4>()) != hipSuccess) return e;
     if ((e = set_limit<5>()) != hipSuccess) return e;
     if ((e = set_limit<6>()) != hipSuccess) return e;
+    if ((e = set_limit<7>()) != hipSuccess) return e;
     return hipSuccess;
 }
 
@@ -636,7 +666,7 @@ bool launch_conv3x3_sp(const ConvArgs& a, hipStream_t s)
     if (tail && 36ll * a.B * a.H * a.r * a.W * a.r >= (1ll << 32) - 8192) return false;
     const bool planew = a.plane_w != 0;                                 // per-plane weights: act + residual only (SEDN fused block tail)
     if (planew && (!res || tail || x3 || a.r != 1)) return false;
-    const int epi = planew ? 6 : x3 ? (res ? 5 : 4) : tail ? 3 : (res ? 2 : (act ? 1 : 0));
+    const int epi = planew ? 6 : x3 ? (res ? 5 : 4) : tail ? (a.tail_split ? 7 : 3) : (res ? 2 : (act ? 1 : 0));
     const int blocks = planew ? a.G : a.nchunks * ((a.G + 7) / 8) * 8;          // per-plane weights: a.G is the TOTAL number of workgroups
     const dim3 grid(blocks), blk(256);
     switch (epi) {
@@ -646,6 +676,7 @@ bool launch_conv3x3_sp(const ConvArgs& a, hipStream_t s)
         case 4: conv3x3_sp_kernel<4><<<grid, blk, LDS_BYTES, s>>>(a); break;
         case 5: conv3x3_sp_kernel<5><<<grid, blk, LDS_BYTES, s>>>(a); break;
         case 6: conv3x3_sp_kernel<6><<<grid, blk, LDS_BYTES, s>>>(a); break;
+        case 7: conv3x3_sp_kernel<7><<<grid, blk, LDS_BYTES, s>>>(a); break;
         default: conv3x3_sp_kernel<2><<<grid, blk, LDS_BYTES, s>>>(a); break;
     }
     return true;

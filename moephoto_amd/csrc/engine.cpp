@@ -323,7 +323,9 @@ static int build_device_weights(moe_net& n, int precision)
         // the debug path keeps the plain weights and applies the scale in its epilogue; the MFMA kernels get it pre-multiplied
         pack_conv(*n.get(wname), b, r, L, bb, lo, plain, per_plane, plain ? 1.f : scale);
         L.slope = slope; L.scale = plain ? scale : 1.f; L.per_plane = per_plane;
-        if (!plain && r == 1 && L.taps == 9 && L.nseg == 1 && L.nchunks == 1 && (key == "input2" || key.compare(0, 3, "c1_") == 0 || key.compare(0, 3, "c2_") == 0))
+        // every bias-free 3x3 conv with <= 64 channels in and out (the trunks of Net*x / NetDN, lite's LB convs, SEDN's rblock.0/2) also gets
+        // the register-resident weight order of arsb_fused.hip / conv64_x3.hip (+ its low part where split operands may be asked for)
+        if (!plain && r == 1 && L.taps == 9 && L.nseg == 1 && L.nchunks == 1 && !b && !per_plane)
             pack_arsb(*n.get(wname), L, bb, scale, lo);
         n.conv_index[key] = (int)n.convs.size();
         n.convs.push_back(L);
@@ -358,18 +360,21 @@ static int build_device_weights(moe_net& n, int precision)
             // Rows 0..8 carry the fp16 weights of the nine taps, rows 16..24 their rounding remainders (w - fp16(w)) * 2^11: the same
             // MFMA that forms the tap sums also forms the low-order sums (23 of the 32 rows were idle), and the epilogue adds
             // row 16+t * 2^-11 to row t -- the tail conv sees its weights to ~22 bits at no extra matrix work.
-            const size_t of = bb.take(4 * 512 * 2);
-            for (int i = 0; i < 4; ++i)
+            // Fragments 4..7 (EPI 7, the activation operand split as well): the fp16 weights again, but in rows 16..24 -- multiplied by the
+            // activations' low parts (units of 2^-11) they accumulate into the same low-order rows.
+            const size_t of = bb.take(8 * 512 * 2);
+            for (int i = 0; i < 8; ++i)
                 for (int l = 0; l < 64; ++l)
                     for (int e8 = 0; e8 < 8; ++e8) {
                         const int row = l & 31, hh = l >> 5;
                         const int tap = row < 9 ? row : (row >= 16 && row < 25 ? row - 16 : -1);
-                        const int ch = i * 16 + (e8 < 4 ? 4 * hh + e8 : 8 + 4 * hh + (e8 - 4));
+                        const int ch = (i & 3) * 16 + (e8 < 4 ? 4 * hh + e8 : 8 + 4 * hh + (e8 - 4));
                         float v = 0.f;
                         if (tap >= 0 && ch < C) {
                             const float wv = W.data[(size_t)ch * taps + tap];
                             const half_t hv = (half_t)wv;
-                            v = row < 9 ? (float)hv : (wv - (float)hv) * 2048.f;
+                            if (i < 4) v = row < 9 ? (float)hv : (wv - (float)hv) * 2048.f;
+                            else v = row < 9 ? 0.f : (float)hv;
                         }
                         bb.at<half_t>(of)[(i * 64 + l) * 8 + e8] = (half_t)v;
                     }
@@ -518,6 +523,14 @@ struct Fwd {
         launch_nhwc_to_nchw_f32(a.hi, a.lo, t.dev, B, H, W, cs, C, s);
     }
 
+    // MIXED: which fused-tail launches also split the activation operand.  The R branch (trunk -> upsampler -> tail) carries the larger
+    // share of the remaining error (emulation: r.tail activations 3.8e-4 vs u.tail 1.3e-4 on noise); MOE_TAIL_SPLIT = 0 | r (default) | ru
+    static bool tail_split_for(const std::string& key)
+    {
+        static const int mode = [] { const char* e = getenv("MOE_TAIL_SPLIT"); return !e ? 1 : (!strcmp(e, "0") ? 0 : (!strcmp(e, "ru") ? 2 : 1)); }();
+        return mode == 2 || (mode == 1 && key.compare(0, 8, "convt_R1") == 0);
+    }
+
     // live timing (bench.py's roofline legs): a hipEvent pair on the launch stream around the launches of a layer whose key matches
     // one of the profile substrings.  Returns the record index or -1.
     int prof_begin(const std::string& key, double flops)
@@ -584,6 +597,7 @@ struct Fwd {
         static const int dbg = [] { const char* e = getenv("MOE_DBG"); return e ? atoi(e) : 0; }();
         a.dbg = dbg;
         a.tail_w = tail_w; a.tplanes = tplanes;
+        a.tail_split = (tplanes && mixed && tail_split_for(key)) ? 1 : 0;
         a.tail1_w = tail1_w; a.tail1_out = tail1_out;
         // 3x3 / 64-input-channel layers with shared weights run on the software-pipelined kernel (conv3x3_sp.hip); everything else
         // (1x1 convs, SEDN's per-plane `trans`, epilogues that kernel does not compile, MOE_CONV_IMPL=v1) on the generic one

@@ -95,11 +95,12 @@ def mode_sets(arch, mode, n_exact=0):
         return L, L, True
     if mode == 'mixed':
         # exact: conv_input2 and the first n ARSBs (split operands); the tails' WEIGHTS (low-order rows of the fused tail GEMM, or the
-        # split-operand tail kernel of NetDN, which also takes the hi+lo activations); hi+lo stream
+        # split-operand tail kernel of NetDN, which also takes the hi+lo activations); the R-branch tail's ACTIVATIONS (EPI 7 of
+        # conv3x3_sp.hip: a second small GEMM on their low parts); hi+lo stream
         ex = {'input2'} | {'c%d_%d' % (j, i) for i in range(1, n_exact + 1) for j in (1, 2)}
         tails = {'r.tail', 'u.tail'}
         w16 = L - ex - tails
-        a16 = L - ex - (tails if arch == 'netdn' else set())
+        a16 = L - ex - (tails if arch == 'netdn' else {'r.tail'})
         return w16, a16, False
     raise ValueError(mode)
 

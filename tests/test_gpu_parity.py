@@ -684,10 +684,14 @@ def test_fused_arsb_matches_two_launch_form(dev):
                     # same operands, same rounding points; only the fp32 summation order inside a conv differs, which flips an fp16 rounding
                     # of conv_1's output now and then -- and, in 'fp16' mode, of the stream itself (one ulp of a value near 1 is 5e-4,
                     # amplified ~2x by the upsampler).  The trunk taps of the two forms agree to four digits (tools/diag_arsb.py).
-                    # White noise drives a2 to +-1.9 and every flipped rounding is amplified: there the two forms may differ by as much as
-                    # either differs from the oracle (with nb = 0 on noise that is itself ~1e-3); on natural images they agree to 2e-4.
-                    bound = 2.5e-4 if kind == 'natural' else 1e-3
-                    assert np.abs(y1 - y0).max() <= bound, (key, shape, kind, prec, nb, float(np.abs(y1 - y0).max()))
+                    # On natural images the two forms agree to 2.5e-4.  White noise drives a2 to +-1.9 and every flipped rounding is
+                    # amplified, so there each form is held against the ORACLE with the bound of its arithmetic (fp16: the documented
+                    # 1e-2 on noise; mixed with nb = 0: 2e-3; the default is asserted at TOL below) instead of against the other.
+                    if kind == 'natural':
+                        assert np.abs(y1 - y0).max() <= 2.5e-4, (key, shape, prec, nb, float(np.abs(y1 - y0).max()))
+                    else:
+                        for y in (y0, y1):
+                            assert np.abs(y - want).max() <= (1e-2 if prec == 'fp16' else 2e-3), (key, shape, prec, nb, float(np.abs(y - want).max()))
                     if prec == 'mixed' and nb == -1:
                         assert np.abs(y1 - want).max() <= TOL, (key, shape, kind, float(np.abs(y1 - want).max()))
     finally:
