@@ -28,6 +28,7 @@
 // as hi + lo * 2^-11 (MOE_PREC_MIXED): LO = true reads x_lo, adds in fp32 and stores y_hi and y_lo; only the MFMA operand is
 // the fp16 part.
 #include "common.h"
+#include "rowtile.h"
 
 namespace {
 
@@ -40,8 +41,6 @@ constexpr int MBYTES = MH * MP * 128;          // 43,520
 constexpr int LDS_BYTES = 2 * XBYTES + MBYTES; // 150,016
 static_assert(XW == MP, "x and m patches share the row pitch (one set of read offsets)");
 
-typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
-
 __device__ __forceinline__ void dma16(const half_t* src, char* lds_wave_base)
 {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -51,6 +50,9 @@ __device__ __forceinline__ void dma16(const half_t* src, char* lds_wave_base)
 struct Item { int b, pyi, pxi; };
 
 // cycle-level trace (tools/trace_arsb.sh builds a -DARSB_TRACE variant): s_memtime at the phase boundaries and after every input row
+#ifndef ARSB_ABL
+#define ARSB_ABL 0      // timing ablations for tools/trace_arsb.sh (results are wrong when set): 1 no DMA, 2 no epilogues, 4 no residual loads, 8 no LDS reads
+#endif
 #ifdef ARSB_TRACE
 #define ARSB_STAMP(SLOT)                                                                                  \
     if (a.trace && g < 8 && p < 16 && lane == 0) a.trace[((g * 16 + p) * 4 + w4) * 40 + (SLOT)] = __builtin_amdgcn_s_memtime();
@@ -157,31 +159,14 @@ __global__ __launch_bounds__(256) void arsb_fused_kernel(ArsbArgs a)
     const unsigned lane_ob = ((unsigned)ocol * 64u + (unsigned)(16 * w4 + 8 * (q >> 1))) * 2u;
     const unsigned trash_ob = (unsigned)a.B * a.H * a.W * 128u + lane * 16u;       // slack behind every activation buffer
 
-    Item it_cur = decode(g);
-#pragma unroll
-    for (int i = 0; i < NPIECE_W; ++i) issue_piece(it_cur, i, xbuf, true);         // prologue: the first patch
+    const RowConsts kc = {1.0f, 0.00048828125f, -2048.f};
 
-    for (int p = 0; p < K; ++p) {
-        const Item it = it_cur;
-        const bool has_next = p + 1 < K;
-        const Item itn = has_next ? decode(g + (p + 1) * G) : it;
-        const char* const xb = xbuf + (p & 1) * XBYTES;
-        char* const xn = xbuf + ((p + 1) & 1) * XBYTES;
-        const int y0 = it.pyi * TH, x0 = it.pxi * TW;
-
-        ARSB_STAMP(0)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ARSB_STAMP(1)
-        __builtin_amdgcn_s_barrier();                     // x[p] has landed for every wave; every wave is done reading m
-        asm volatile("" ::: "memory");
-        ARSB_STAMP(2)
-
-        // Both convs stream their input rows: the twelve B fragments (dx, kh, cb) of row r+1 are read into the second register set while
-        // the (up to) 36 MFMAs of row r run from the first; a sched_group_barrier pattern pins the interleave (one MFMA, at most one
-        // LDS read, a few VALU of the riding epilogue) -- left alone the compiler reads each fragment right in front of its first use
-        // and waits out the LDS latency 264 times per patch.
-        half8_t fr[2][12];
-        const char* pb[12];           // per-lane base of each of the twelve fragments in the buffer being read; rows are immediate offsets
+    // Both convs stream their input rows: the twelve B fragments (dx, kh, cb) of row r+1 are read into the second register set while
+    // the (up to) 36 MFMAs of row r run from the first; a sched_group_barrier pattern pins the interleave (one MFMA, at most one
+    // LDS read, a couple of VALU of the riding epilogue) -- left alone the compiler reads each fragment right in front of its first use
+    // and waits out the LDS latency 264 times per patch.
+    half8_t fr[2][12];
+    const char* pb[12];           // per-lane base of each of the twelve fragments in the buffer being read; rows are immediate offsets
 #define MOE_SET_BASE(PTR)                                                                                \
     _Pragma("unroll") for (int dx = 0; dx < 3; ++dx) _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)    \
         _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) pb[(dx * 2 + kh) * 2 + cb] = (PTR) + rd[cb][dx][kh];
@@ -193,6 +178,35 @@ __global__ __launch_bounds__(256) void arsb_fused_kernel(ArsbArgs a)
         if (i_ < (NREAD)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                             \
         __builtin_amdgcn_sched_group_barrier(0x002, (NVALU), 0);                                         \
     }
+
+    Item it_cur = decode(g);
+    {   // prologue: the first patch, and the B fragments of its first row
+        constexpr int p = 0;
+#pragma unroll
+        for (int i = 0; i < NPIECE_W; ++i) issue_piece(it_cur, i, xbuf, true);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        MOE_SET_BASE(xbuf)
+        MOE_READ_ROW(0, 0)
+        (void)p;
+    }
+
+    // Synchronisation per patch p (one wave per SIMD, four waves):
+    //   conv_1 rows 0..2           read x[p] only                                   (its row-0 fragments were read at the end of patch p-1)
+    //   barrier A                  every wave has finished conv_2 of patch p-1: the m buffer may be overwritten
+    //   conv_1 rows 3..11          m rows written as they complete; DMA of x[p+1] and the residual loads ride along
+    //   vmcnt(0), lgkmcnt(0), barrier B   m is complete, x[p+1] has landed for every wave
+    //   conv_2 rows 0..9           output rows stored as they complete; then the row-0 fragments of x[p+1] are read
+    for (int p = 0; p < K; ++p) {
+        const Item it = it_cur;
+        const bool has_next = p + 1 < K;
+        const Item itn = has_next ? decode(g + (p + 1) * G) : it;
+        const char* const xb = xbuf + (p & 1) * XBYTES;
+        char* const xn = xbuf + ((p + 1) & 1) * XBYTES;
+        const int y0 = it.pyi * TH, x0 = it.pxi * TW;
+        ARSB_STAMP(0)
+
         // residual of the eight output rows (hi / lo part, in the 16-byte store layout): fetched while conv_1 runs, one row per input row,
         // so that every load has landed long before conv_2's first finished row needs it
         uint4 resw[8], sidew[8];
@@ -207,7 +221,7 @@ __global__ __launch_bounds__(256) void arsb_fused_kernel(ArsbArgs a)
         // ================= conv_1: m rows 0 .. 9 (32 columns) from x rows 0 .. 11 ===========================================
         {
             float4_t acc[10][2];
-            // epilogue of a finished m row: PReLU on packed halves (slope <= 1), zero outside the image (conv_2's zero padding), to LDS
+            // epilogue of a finished m row: PReLU on packed halves (slope <= 1), to LDS (the zero padding of conv_2 is applied below)
             auto m_row = [&](const float4_t (&ac)[2], int mr) {
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb) {
@@ -228,11 +242,17 @@ __global__ __launch_bounds__(256) void arsb_fused_kernel(ArsbArgs a)
                 }
             };
             MOE_SET_BASE(xb)
-            MOE_READ_ROW(0, 0)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int xr = 0; xr < 12; ++xr) {
-                if (xr < 11) { MOE_READ_ROW((xr + 1) & 1, xr + 1) }
+                if (xr == 3) {
+                    ARSB_STAMP(1)
+                    __builtin_amdgcn_s_barrier();          // barrier A
+                    asm volatile("" ::: "memory");
+                    ARSB_STAMP(2)
+                }
+                if (xr < 11 && !(ARSB_ABL & 8)) { MOE_READ_ROW((xr + 1) & 1, xr + 1) }
+                if (xr < 11 && (ARSB_ABL & 8)) { _Pragma("unroll") for (int f_ = 0; f_ < 12; ++f_) fr[(xr + 1) & 1][f_] = fr[xr & 1][f_]; }
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
@@ -249,20 +269,23 @@ __global__ __launch_bounds__(256) void arsb_fused_kernel(ArsbArgs a)
                                 }
                             }
                         }
-                // the DMA of the next patch rides along: 13 pieces over the 12 input rows
-                issue_piece(itn, xr, xn, has_next);
-                if (xr == 11) issue_piece(itn, 12, xn, has_next);
-                if (xr >= 3) m_row(acc[xr - 3], xr - 3);     // complete since the end of the previous row: rides in this row's MFMA shadow
-                if (xr >= 4) {
-                    const unsigned off = row_off(xr - 4);
-                    resw[xr - 4] = *(const uint4*)((const char*)a.x_hi + off);
-                    if (LO) sidew[xr - 4] = *(const uint4*)((const char*)a.x_lo + off);
+                // the DMA of the next patch rides along in the first seven rows (2 + 2 + 2 + 2 + 2 + 2 + 1): early, so that the pieces have
+                // landed -- and stopped competing with the m-row writes for the LDS write port -- well before barrier B
+                if (!(ARSB_ABL & 1)) {
+                    if (xr < 6) { issue_piece(itn, 2 * xr, xn, has_next); issue_piece(itn, 2 * xr + 1, xn, has_next); }
+                    if (xr == 6) issue_piece(itn, 12, xn, has_next);
+                }
+                if (xr >= 3) { if (ARSB_ABL & 2) asm volatile("" ::"v"(acc[xr - 3][0]), "v"(acc[xr - 3][1])); else m_row(acc[xr - 3], xr - 3); }
+                if (xr < 8 && !(ARSB_ABL & 4)) {      // (rows 0..7: every load has landed when the vmcnt(0) in front of barrier B is reached)
+                    const unsigned off = row_off(xr);
+                    resw[xr] = *(const uint4*)((const char*)a.x_hi + off);
+                    if (LO) sidew[xr] = *(const uint4*)((const char*)a.x_lo + off);
                 }
                 MOE_PIN_ROW(((xr < 2 || xr > 9) ? (xr == 0 || xr == 11 ? 12 : 24) : 36), (xr < 11 ? 12 : 0), 2)
                 __builtin_amdgcn_sched_barrier(0);
                 ARSB_STAMP(3 + xr)
             }
-            m_row(acc[9], 9);         // the last row has no MFMAs left to hide behind
+            if (ARSB_ABL & 2) asm volatile("" ::"v"(acc[9][0]), "v"(acc[9][1])); else m_row(acc[9], 9);         // the last row has no MFMAs left to hide behind
         }
         // conv_2 pads with ZEROS: m pixels outside the image must be 0, not conv_1 evaluated there.  Only patches on the image border
         // have such pixels (wave-uniform test), so the fix-up is a separate pass over this wave's own channel slice instead of a
@@ -280,9 +303,9 @@ __global__ __launch_bounds__(256) void arsb_fused_kernel(ArsbArgs a)
                 }
         }
         ARSB_STAMP(15)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         ARSB_STAMP(16)
-        __builtin_amdgcn_s_barrier();                     // m is complete (LDS writes of all four waves)
+        __builtin_amdgcn_s_barrier();                     // barrier B: m is complete, x[p+1] has landed for every wave
         asm volatile("" ::: "memory");
         ARSB_STAMP(17)
 
@@ -291,65 +314,20 @@ __global__ __launch_bounds__(256) void arsb_fused_kernel(ArsbArgs a)
             float4_t acc[8][2];
             // epilogue of a finished output row o: + residual (hi [+ lo * 2^-11]) in fp32, hi [and lo] parts stored, 16 bytes per lane
             auto out_row = [&](const float4_t (&ac)[2], int o) {
-                    // v_permlane16_swap(X, Y) exchanges the odd 16-lane rows of X with the even rows of Y (an involution): applied to the
-                    // residual's two channel quads it yields this lane's own quad for tile cb = 0 (X) and cb = 1 (Y)
-                    float v[2][4];
+                float v[2][4];
 #pragma unroll
-                    for (int cb = 0; cb < 2; ++cb)
+                for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[cb][e] = ac[cb][e];
-                    if (LO) {
-                        const uint4 w = sidew[o];
-                        const auto s0 = __builtin_amdgcn_permlane16_swap(w.x, w.z, false, false);     // halves 0,1 | 4,5
-                        const auto s1 = __builtin_amdgcn_permlane16_swap(w.y, w.w, false, false);     // halves 2,3 | 6,7
-#pragma unroll
-                        for (int cb = 0; cb < 2; ++cb) {
-                            const half4_t qv = __builtin_bit_cast(half4_t, make_uint2(s0[cb], s1[cb]));
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[cb][e] = __builtin_fmaf((float)qv[e], 0.00048828125f, v[cb][e]);
-                        }
-                    }
-                    {
-                        const uint4 w = resw[o];
-                        const auto s0 = __builtin_amdgcn_permlane16_swap(w.x, w.z, false, false);
-                        const auto s1 = __builtin_amdgcn_permlane16_swap(w.y, w.w, false, false);
-#pragma unroll
-                        for (int cb = 0; cb < 2; ++cb) {
-                            const half4_t rv = __builtin_bit_cast(half4_t, make_uint2(s0[cb], s1[cb]));
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[cb][e] = __builtin_fmaf((float)rv[e], 1.0f, v[cb][e]);   // (v_fma_mix_f32: no separate conversion)
-                        }
-                    }
-                    uint2 hi[2], lo[2];
-#pragma unroll
-                    for (int cb = 0; cb < 2; ++cb) {
-                        half4_t h, l;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            h[e] = (half_t)v[cb][e];
-                            l[e] = (half_t)__builtin_fmaf((float)h[e], -2048.f, v[cb][e] * 2048.f);      // (v - hi) * 2^11, exact
-                        }
-                        hi[cb] = __builtin_bit_cast(uint2, h);
-                        lo[cb] = __builtin_bit_cast(uint2, l);
-                    }
-                    const unsigned off = row_off(o);
-                    {
-                        const auto s0 = __builtin_amdgcn_permlane16_swap(hi[0].x, hi[1].x, false, false);
-                        const auto s1 = __builtin_amdgcn_permlane16_swap(hi[0].y, hi[1].y, false, false);
-                        *(uint4*)((char*)a.y_hi + off) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-                    }
-                    if (LO) {
-                        const auto s0 = __builtin_amdgcn_permlane16_swap(lo[0].x, lo[1].x, false, false);
-                        const auto s1 = __builtin_amdgcn_permlane16_swap(lo[0].y, lo[1].y, false, false);
-                        *(uint4*)((char*)a.y_lo + off) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-                    }
+                    for (int e = 0; e < 4; ++e) v[cb][e] = ac[cb][e];
+                finish_row<LO, true, LO>(v, sidew[o], resw[o], kc, (char*)a.y_hi, (char*)a.y_lo, row_off(o));
             };
             MOE_SET_BASE(mbuf)
             MOE_READ_ROW(0, 0)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int xr = 0; xr < 10; ++xr) {
-                if (xr < 9) { MOE_READ_ROW((xr + 1) & 1, xr + 1) }
+                if (xr < 9 && !(ARSB_ABL & 8)) { MOE_READ_ROW((xr + 1) & 1, xr + 1) }
+                if (xr < 9 && (ARSB_ABL & 8)) { _Pragma("unroll") for (int f_ = 0; f_ < 12; ++f_) fr[(xr + 1) & 1][f_] = fr[xr & 1][f_]; }
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
@@ -366,19 +344,23 @@ __global__ __launch_bounds__(256) void arsb_fused_kernel(ArsbArgs a)
                                 }
                             }
                         }
-                if (xr >= 3) out_row(acc[xr - 3], xr - 3);   // complete since the end of the previous row
-                MOE_PIN_ROW(((xr < 2 || xr > 7) ? (xr == 0 || xr == 9 ? 12 : 24) : 36), (xr < 9 ? 12 : 0), 3)
+                if (xr >= 3) { if (ARSB_ABL & 2) asm volatile("" ::"v"(acc[xr - 3][0]), "v"(acc[xr - 3][1])); else out_row(acc[xr - 3], xr - 3); }
+                if (xr == 9) {        // row 0 of the NEXT patch's x (landed and published by barrier B): no LDS round trip at the top of conv_1
+                    MOE_SET_BASE(xn)
+                    MOE_READ_ROW(0, 0)
+                }
+                MOE_PIN_ROW(((xr < 2 || xr > 7) ? (xr == 0 || xr == 9 ? 12 : 24) : 36), (xr < 9 ? 12 : (xr == 9 ? 12 : 0)), 2)
                 __builtin_amdgcn_sched_barrier(0);
                 ARSB_STAMP(18 + xr)
             }
-            out_row(acc[7], 7);
+            if (ARSB_ABL & 2) asm volatile("" ::"v"(acc[7][0]), "v"(acc[7][1])); else out_row(acc[7], 7);
             ARSB_STAMP(28)
         }
+        it_cur = itn;
+    }
 #undef MOE_READ_ROW
 #undef MOE_SET_BASE
 #undef MOE_PIN_ROW
-        it_cur = itn;
-    }
 }
 
 }  // namespace

@@ -18,6 +18,7 @@
 // so its DMA for patch p is issued behind the barrier that opens patch p and lands while pass 1 runs.  2 x 45,056 + 45,056 B.
 // A patch is 8 x 32 outputs (no halo recompute: one conv), 864 MFMAs per wave.
 #include "common.h"
+#include "rowtile.h"
 
 namespace {
 
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(256) void conv64_x3_kernel(ConvX3Args a)
             for (int kh = 0; kh < 2; ++kh) rd[cb][dx][kh] = col * 128 + ((((2 * kh + (q >> 1)) ^ (4 * (q & 1))) ^ z) << 4);
         }
     const float4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+    const RowConsts kc = {1.0f, 0.00048828125f, -2048.f};
     const int ocol = 16 * (q & 1) + n;
     const unsigned lane_ob = ((unsigned)ocol * 64u + (unsigned)(16 * w4 + 8 * (q >> 1))) * 2u;
     const unsigned trash_ob = (unsigned)a.B * a.H * a.W * 128u + lane * 16u;
@@ -210,53 +212,7 @@ __global__ __launch_bounds__(256) void conv64_x3_kernel(ConvX3Args a)
                             asm("v_max_f32 %0, %1, %2" : "=v"(v[cb][e]) : "v"(v[cb][e]), "v"(t));
                         }
                 }
-                if (EPI == 2) {
-                    {
-                        const uint4 w = sidew[o & 3];
-                        const auto s0 = __builtin_amdgcn_permlane16_swap(w.x, w.z, false, false);
-                        const auto s1 = __builtin_amdgcn_permlane16_swap(w.y, w.w, false, false);
-#pragma unroll
-                        for (int cb = 0; cb < 2; ++cb) {
-                            const half4_t qv = __builtin_bit_cast(half4_t, make_uint2(s0[cb], s1[cb]));
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[cb][e] = __builtin_fmaf((float)qv[e], 0.00048828125f, v[cb][e]);
-                        }
-                    }
-                    {
-                        const uint4 w = resw[o & 3];
-                        const auto s0 = __builtin_amdgcn_permlane16_swap(w.x, w.z, false, false);
-                        const auto s1 = __builtin_amdgcn_permlane16_swap(w.y, w.w, false, false);
-#pragma unroll
-                        for (int cb = 0; cb < 2; ++cb) {
-                            const half4_t rv = __builtin_bit_cast(half4_t, make_uint2(s0[cb], s1[cb]));
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[cb][e] += (float)rv[e];
-                        }
-                    }
-                }
-                uint2 hi[2], lo[2];
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb) {
-                    half4_t h, l;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        h[e] = (half_t)v[cb][e];
-                        l[e] = (half_t)__builtin_fmaf((float)h[e], -2048.f, v[cb][e] * 2048.f);      // (v - hi) * 2^11, exact
-                    }
-                    hi[cb] = __builtin_bit_cast(uint2, h);
-                    lo[cb] = __builtin_bit_cast(uint2, l);
-                }
-                const unsigned off = row_off(o);
-                {
-                    const auto s0 = __builtin_amdgcn_permlane16_swap(hi[0].x, hi[1].x, false, false);
-                    const auto s1 = __builtin_amdgcn_permlane16_swap(hi[0].y, hi[1].y, false, false);
-                    *(uint4*)((char*)a.out_hi + off) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-                }
-                {
-                    const auto s0 = __builtin_amdgcn_permlane16_swap(lo[0].x, lo[1].x, false, false);
-                    const auto s1 = __builtin_amdgcn_permlane16_swap(lo[0].y, lo[1].y, false, false);
-                    *(uint4*)((char*)a.out_lo + off) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-                }
+                finish_row<EPI == 2, EPI == 2, true>(v, sidew[o & 3], resw[o & 3], kc, (char*)a.out_hi, (char*)a.out_lo, row_off(o));
             };
             MOE_SET_BASE(lbuf)
             MOE_READ_ROW(0, 0)

@@ -8,7 +8,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib, trace = os.path.join(ROOT, 'moephoto_amd', 'libmoephoto_amd.so'), os.path.join(ROOT, 'moephoto_amd', '_abl', 'lib_trace.so')
+lib, trace = os.path.join(ROOT, 'moephoto_amd', 'libmoephoto_amd.so'), os.path.join(ROOT, 'moephoto_amd', '_abl', sys.argv[1] if len(sys.argv) > 1 else 'lib_trace.so')
 shutil.copy(lib, '/tmp/lib_orig.so')
 try:
     shutil.copy(trace, lib)
@@ -19,8 +19,8 @@ finally:
 raw = open('/tmp/arsb_trace.bin', 'rb').read()
 v = struct.unpack('<{}Q'.format(len(raw) // 8), raw)
 names = ['top', 'vmcnt0', 'barrier1'] + ['c1.r%d' % r for r in range(12)] + ['m9+border', 'lgkm0', 'barrier2'] + ['c2.r%d' % r for r in range(10)] + ['out7']
-for g in (0, 3):
-    for p in (2, 5, 8):
+for g in (0,):
+    for p in (5, 8):
         print('workgroup {} patch {}'.format(g, p))
         for w in range(4):
             s = v[((g * 16 + p) * 4 + w) * 40:((g * 16 + p) * 4 + w) * 40 + 29]
