@@ -835,7 +835,13 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
                     const size_t tb = 8 * 16 * 4 * 40 * 8;
                     if (trace && i == 3 && hipMalloc((void**)&q.trace, tb) == hipSuccess) (void)hipMemsetAsync(q.trace, 0, tb, s);
                     const int rec = f.prof_begin("arsb" + std::to_string(i), 2.0 * 2.0 * (double)B * h * w * L1.cout * L1.cin * 9);
-                    done = launch_arsb_fused(q, n.max_groups, s);
+                    const char* impl = getenv("MOE_ARSB_IMPL");      // v1 (default): arsb_fused.hip | pc: conv_1 / conv_2 on different waves (arsb_pc.hip, experiment)
+                    if (!impl || strcmp(impl, "pc")) done = launch_arsb_fused(q, n.max_groups, s);
+                    else {
+                        ArsbArgs q2 = q;
+                        q2.w1 = f.blob<half_t>(L1.w_hi); q2.w2 = f.blob<half_t>(L2.w_hi);
+                        done = launch_arsb_pc(q2, n.max_groups, s);
+                    }
                     f.prof_end(rec);
                     if (q.trace) {
                         std::vector<unsigned long long> host(tb / 8);

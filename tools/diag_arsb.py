@@ -107,3 +107,27 @@ for fuse in ('0', '1'):
     parts = ['{} {} launches avg {:.4f} ms'.format(k, p['launches'], p['total_ms'] / max(1, p['launches'])) for k, p in zip(('input2', 'c1_1', 'c2_1'), pr)]
     print('a4 B=12 256x256 mixed nb=1 x3-fuse={}: forward {:.3f} ms | {}'.format(fuse, e0.elapsed_time(e1) / 5, ' | '.join(parts)))
     del m
+
+# ---- fused ARSB, two forms ------------------------------------------------------------------------------------------------------
+os.environ['MOE_ARSB_FUSE'] = '1'; os.environ['MOE_X3_FUSE'] = '1'
+for impl in ('v1', 'pc'):
+    os.environ['MOE_ARSB_IMPL'] = impl
+    for prec, nb in (('fp16', None), ('mixed', 1)):
+        m = make('a4', prec, nb)
+        for _ in range(2):
+            m(x)
+        m.set_profile('arsb')
+        for _ in range(3):
+            m(x)
+        pr = m.get_profile()
+        m.set_profile(None)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            m(x)
+        e1.record()
+        torch.cuda.synchronize()
+        print('a4 B=12 256x256 {} nb={} arsb impl {}: forward {:.3f} ms | arsb {} launches avg {:.4f} ms {:.0f} TF'.format(
+            prec, nb, impl, e0.elapsed_time(e1) / 5, pr['launches'], pr['total_ms'] / max(1, pr['launches']), pr['flops'] / max(1e-9, pr['total_ms']) / 1e9))
+        del m
+os.environ.pop('MOE_ARSB_IMPL')
