@@ -23,7 +23,7 @@ SURVEY 8(d) input (seed-0 uniform uint8 noise / 255) is timed and parity-checked
 Extra objects on the JSON line:
   roofline        the dominant kernel (3x3 64->256 implicit-GEMM conv at 2x resolution, 59.8 % of the FLOPs):
                   algorithmic FLOPs / launch time from hipEvents recorded on the launch stream inside the timed steps
-  roofline_trunk  the same for conv_2 of the single-pass ARSBs (the 64->64 implicit GEMM the north star names)
+  roofline_trunk  the same for the one-launch ARSBs with fp16 operands (two 64->64 implicit GEMMs, the shape the north star names)
   sustained       a >= --sustain second leg after the timed steps (the part is power-capped: short bursts run faster)
   cpu_baseline    the oracle (a port of the reference's PyTorch-CPU fp32 path, proven equal to it on the goldens) timed on
                   this host with one socket's physical cores on a full tile row (8 tiles) + the ragged corner of the same
@@ -143,7 +143,7 @@ def main():
     in_mp = nframes * FRAME[1] * FRAME[2] / 1e6
     for _ in range(args.warmup):
         step(frames)
-    model.set_profile('up1,c2_')      # hipEvent pairs around the 64->256 @2x convs (both branches) and conv_2 of the ARSBs, on the launch stream
+    model.set_profile('up1,arsb')      # hipEvent pairs around the 64->256 @2x convs (both branches) and the one-launch ARSBs, on the launch stream
     dt = timed(frames, args.steps)
     prof_up1, prof_c2 = model.get_profile(all_keys=True)
     model.set_profile(None)
@@ -172,7 +172,7 @@ def main():
         res['roofline'] = roof(prof_up1, 'conv3x3_sp_kernel<3> (3x3 64->256 @2x res, +bias +PixelShuffle(2) +PReLU, fused 64->1 tail taps)')
         res['roofline']['traffic'] = _pmc_traffic()
     if prof_c2['launches'] > 0:
-        res['roofline_trunk'] = roof(prof_c2, 'ARSB conv_2 (3x3 64->64 @1x res, + hi/lo residual stream)')
+        res['roofline_trunk'] = roof(prof_c2, 'arsb_fused_kernel (one ARSB per launch: two 3x3 64->64 convs @1x res + PReLU + hi/lo residual stream)')
 
     # ---- sustained leg (power-capped part: a 0.5 s burst flatters the clock) -------------------------------
     if args.sustain > 0:
