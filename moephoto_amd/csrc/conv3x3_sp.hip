@@ -52,7 +52,7 @@ __device__ __forceinline__ Item decode(int item, int px, int py)
     return it;
 }
 
-struct PatchSrc { const half_t* base; int y0, x0; };
+struct PatchSrc { unsigned soff; int y0, x0; };      // byte offset of the patch origin behind the (padded) descriptor base
 
 // EPI selects the fused epilogue at compile time (no control flow inside the pipelined iteration):
 //   0  plain                  (conv_input2, SEDN rblock.4, lite conv_2)
@@ -78,6 +78,7 @@ struct PatchSrc { const half_t* base; int y0, x0; };
 template <int EPI>
 __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
 {
+#if defined(__HIP_DEVICE_COMPILE__)      // (the host pass only needs the launch stub; it drops an instantiation that uses the gfx950 buffer builtins)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const wlds = smem;
     char* const pbuf = smem + WBYTES;
@@ -102,17 +103,18 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
     const int K = (nitems - g + G - 1) / G;                       // this workgroup's items: g, g+G, ...
     if (K <= 0) return;
 
-    const half_t* const zsrc = a.zero + (lane & 7) * 8;
-    // launch-invariant per-lane source offsets of this wave's 11 DMA pieces (elements, relative to the patch origin)
-    int poff[NDMA_W];
-#pragma unroll
-    for (int i = 0; i < NDMA_W; ++i) {
-        const int q = (i * 4 + w4) * 8 + (lane >> 3);
-        const int r = (q * 241) >> 13;                            // q / 34 for q < 352
-        const int c = q - r * PW;
-        const int sl = (lane & 7) ^ ((c >> 1) & 7);               // logical 16-B slot behind this physical slot
-        poff[i] = (r * a.W + c) * a.in_cs + sl * 8;
-    }
+    // The 11 DMA pieces of a patch are raw-buffer loads to LDS: lane part of the source offset in a VGPR, patch origin in an SGPR.
+    // Per lane and piece: the byte offset of its pixel of the 34 x 10 patch from the patch origin.  A pixel outside the image gets an offset the buffer unit rejects -- it then writes ZEROS to LDS, which is the conv's
+    // zero padding (tools/micro/buffer_oor.hip) -- so only patches on the image border need per-lane work at all, and only when the
+    // border pattern differs from the previous patch's (`vkey`).  The descriptor starts one row + one pixel BEFORE the tensor, so
+    // that the origin (-1, -1) of the first patch is offset 0 (those bytes are never touched: their lanes are rejected).
+    constexpr unsigned kOOR = 0xFFFF0000u;                        // >= num_records for every launch (launcher: < 2^32 - 2^16)
+    const unsigned in_px = (unsigned)a.in_cs * 2u;                // bytes per input pixel
+    const unsigned in_pad = (unsigned)(a.W + 1) * in_px;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.in - in_pad), 0,
+                                                                         (unsigned)a.B * a.H * a.W * in_px + in_pad, 0x00020000);
+    unsigned vofs[NDMA_W];                                        // this lane's source offset in piece i, for the border pattern `vkey`
+    int vkey = -2;                                                // (0: interior patch, -1: nothing to fetch, -2: not built yet)
     // work items g, g+G, g+2G, ... are walked with carries instead of divisions
     const int Gx = G % a.px, Gy = (G / a.px) % a.py, Gb = G / (a.px * a.py);
     auto advance = [&](const Item& it) {
@@ -129,18 +131,31 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
     auto patch_src = [&](const Item& it) {
         PatchSrc ps;
         ps.y0 = it.pyi * kTileH - 1; ps.x0 = it.pxi * kTileW - 1;
-        ps.base = a.in + ((long long)((it.b + bofs) * a.H + ps.y0) * a.W + ps.x0) * a.in_cs;
+        ps.soff = (unsigned)(((it.b + bofs) * a.H + ps.y0) * a.W + ps.x0 + a.W + 1) * in_px;
         return ps;
     };
-    auto issue_piece = [&](const PatchSrc& ps, int i, char* dstbuf, bool live = true) {
+    // called once per patch, before its pieces are issued: rebuild `vofs` if the patch cuts the image border differently (the per-lane
+    // pixel coordinates are recomputed here rather than kept: 22 registers for a path that runs on border patches only)
+    auto prep_patch = [&](const PatchSrc& ps, bool live) {
+        const int xlo = ps.x0 < 0, ylo = ps.y0 < 0;
+        const int xhi = max(0, ps.x0 + PW - a.W), yhi = max(0, ps.y0 + PH - a.H);       // columns / rows beyond the right / bottom edge
+        const int key = live ? ((xhi * 16 + yhi) * 4 + xlo * 2 + ylo) : -1;
+        if (key != vkey) {
+            vkey = key;
+#pragma unroll
+            for (int i = 0; i < NDMA_W; ++i) {
+                const int q = (i * 4 + w4) * 8 + (lane >> 3);
+                const int r = (q * 241) >> 13;                        // q / 34 for q < 352
+                const int c = q - r * PW;
+                const int sl = (lane & 7) ^ ((c >> 1) & 7);           // logical 16-B slot behind this physical slot
+                const bool ok = ((unsigned)(ps.y0 + r) < (unsigned)a.H) & ((unsigned)(ps.x0 + c) < (unsigned)a.W) & (q < NPIX) & live;
+                vofs[i] = ok ? (unsigned)(r * a.W + c) * in_px + (unsigned)sl * 16u : kOOR;
+            }
+        }
+    };
+    auto issue_piece = [&](const PatchSrc& ps, int i, char* dstbuf) {
         const int n = i * 4 + w4;                                 // 0..43, no branch: piece 43 is pure padding
-        const int q = n * 8 + (lane >> 3);
-        const int r = (q * 241) >> 13;
-        const int c = q - r * PW;
-        const bool ok = ((unsigned)(ps.y0 + r) < (unsigned)a.H) & ((unsigned)(ps.x0 + c) < (unsigned)a.W) & (q < NPIX) & live;
-        const half_t* src = ps.base + poff[i];
-        src = ok ? src : zsrc;
-        dma16(src, dstbuf + n * 1024);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(dstbuf + n * 1024), 16, vofs[i], ps.soff, 0, 0);
     };
 
     {   // prologue: weights + the first patch.  Every workgroup of a chunk wants the same 72 KiB at the same moment: each starts
@@ -156,6 +171,7 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
             dma16(wsrc + f * 512 + lane * 8, wlds + f * 1024);
         }
         const PatchSrc ps = patch_src(decode(g, a.px, a.py));
+        prep_patch(ps, true);
 #pragma unroll
         for (int i = 0; i < NDMA_W; ++i) issue_piece(ps, i, pbuf);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -468,6 +484,7 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         const PatchSrc ps = patch_src(it_next);
         const char* abuf = pbuf + (p & 1) * PATCH_BYTES;
         char* nbuf = pbuf + ((p + 1) & 1) * PATCH_BYTES;
+        prep_patch(ps, fetch);
         MOE_STAMP(0)
         if (RES) {   // pin the compiler's wait for the residual registers here, before this iteration issues any memory operation
 #pragma unroll
@@ -517,8 +534,8 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
                 MOE_LOAD_STEP(0, 0, nbuf)
             }
             if (!(MOE_ABL & 1)) {   // compile-time timing ablation (tools/ablate_sp.sh); 0 in the product build
-                if (s < 5) { issue_piece(ps, 2 * s, nbuf, fetch); issue_piece(ps, 2 * s + 1, nbuf, fetch); }
-                if (s == 5) issue_piece(ps, 10, nbuf, fetch);
+                if (s < 5) { issue_piece(ps, 2 * s, nbuf); issue_piece(ps, 2 * s + 1, nbuf); }
+                if (s == 5) issue_piece(ps, 10, nbuf);
             }
 #pragma unroll
             for (int pr = 0; pr < 4; ++pr)
@@ -628,6 +645,7 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         if (a.dbg & 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         MOE_STAMP(13)
     }
+#endif
 }
 
 template <int EPI>
@@ -659,6 +677,7 @@ bool launch_conv3x3_sp(const ConvArgs& a, hipStream_t s)
     if ((a.acc_mode != 0 && !x3 && !(a.dbg & 64)) || a.slope > 1.f) return false;
     // 32-bit BYTE offsets for stores / residual loads (the fused-tail epilogue stores no tensor: its tap planes are checked below)
     if (!a.tplanes && 2ll * a.B * a.H * a.r * a.W * a.r * a.out_cs >= (1ll << 32) - 8192) return false;
+    if (2ll * a.B * a.H * a.W * a.in_cs + 2ll * (a.W + 1) * a.in_cs >= (1ll << 32) - 65536) return false;   // 32-bit buffer offsets of the patch DMA
     if (a.scale != 1.f || !a.bias_img) return false;           // the engine folds ScaleLayer into the weights and always passes a bias vector
     const bool act = a.slope != 1.f, res = a.res != nullptr, tail = a.tplanes != nullptr;
     if ((act || tail) && res && !a.plane_w) return false;
