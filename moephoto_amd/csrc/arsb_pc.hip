@@ -65,12 +65,13 @@ __device__ __forceinline__ void dma16(unsigned long long src, char* lds_wave_bas
 
 struct Item { int b, pyi, pxi; };
 
-// vector-memory operations a C wave issues in step s (the same whether the step is live or not): 3 DMA pieces of x, 2 (+2) DMA pieces of
-// residual words while rows 0..7 are fetched, 2 (+2) stores while rows 0..7 are drained
+// LOADS (LDS-DMA pieces) a C wave issues in step s, the same whether the step is live or not: 3 pieces of x, 2 (+2) of residual words while
+// rows 0..7 are fetched.  The stores are deliberately not counted: loads complete in order among themselves but not relative to stores, so
+// an allowance that included stores could be used up by loads still in flight.
 template <bool LO> constexpr int c_ops(int s)
 {
     const int j = (s + 7) % 12;
-    return 3 + ((j <= 7) ? (LO ? 4 : 2) : 0) + ((j >= 3 && j <= 10) ? (LO ? 4 : 2) : 0);
+    return 3 + ((j <= 7) ? (LO ? 4 : 2) : 0);
 }
 
 // s_waitcnt vmcnt(keep) lgkmcnt(0) with `keep` an immediate: the value is a compile-time constant at every call site after unrolling
@@ -78,7 +79,7 @@ __device__ __forceinline__ void wait_keep(int keep)
 {
     switch (keep) {
 #define PC_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory"); break;
-        PC_W(6) PC_W(8) PC_W(10) PC_W(12) PC_W(14) PC_W(16) PC_W(18) PC_W(22) PC_W(26)
+        PC_W(5) PC_W(6) PC_W(7) PC_W(8) PC_W(9) PC_W(10) PC_W(11) PC_W(12) PC_W(14) PC_W(16) PC_W(18)
 #undef PC_W
         default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
     }

@@ -59,6 +59,20 @@ struct ConvArgs {
     int dbg;              // timing ablations (MOE_DBG env; results are wrong when set): 1 no patch DMA, 2 no MFMA, 4 no stores, 8 no epilogue
 };
 
+// 1x1 convs of lite (conv1x1.hip): 64 (48 real) input channels, one chunk (r = 1) or four (r = 2, pixel shuffle folded into the store),
+// fp16 or split operands, optionally the 48->1 tail conv folded in (one fp32 plane [B][2H][2W] of complete dot products)
+struct Conv1x1Args {
+    const half_t* in_hi; const half_t* in_lo;     // [B][H][W][64]; in_lo != nullptr selects the three-product form
+    half_t* out_hi; half_t* out_lo;               // [B][H r][W r][out_cs] (not used with tail_out)
+    const half_t* w_hi; const half_t* w_lo;       // packed A fragments [chunk][8] (pack_conv order)
+    const float* bias;                            // [nchunks * 64] in packed output-channel order (zeros when the layer has none)
+    const float* tail_w; float* tail_out;         // fused tail: [64] fp32 weights in the chunk's channel order, fp32 plane out
+    float slope;                                  // PReLU slope (<= 1; 1: none)
+    int B, H, W, r, nchunks, out_cs;
+};
+bool launch_conv1x1(const Conv1x1Args& a, int max_groups, hipStream_t s);   // false: shape not compiled (caller uses conv_mfma_kernel)
+hipError_t conv1x1_init();
+
 void launch_conv_mfma(const ConvArgs& a, int taps, int nseg, hipStream_t s);
 int conv_mfma_max_groups();  // persistent workgroups the device holds (1 per CU)
 hipError_t conv_mfma_init(); // raise dynamic-LDS limits once per process
@@ -147,7 +161,8 @@ void launch_tapsum(const TapSumArgs& a, hipStream_t s);
 
 // y = sum of the four partial planes of the fused 1x1 tail (two branches x two channel halves), each [B][H][W] fp32
 struct Tail1SumArgs {
-    const float* p0; const float* p1;      // [2][B][H][W] per branch
+    const float* p0; const float* p1;      // [nparts][B][H][W] per branch
+    int nparts;                            // 2: two 32-channel halves per branch (conv_mfma_kernel), 1: complete dot products (conv1x1.hip)
     void* y; int y_dtype; const long long* y_off;
     int B, H, W;
 };

@@ -500,6 +500,7 @@ struct Fwd {
     size_t acc32_elems = 0;
     half_t* side16 = nullptr;    // fp16 sum of the two low-order products of a 3x3 conv (split precision), output layout
     bool dry() const { return ar.base == nullptr; }
+    int tail1_parts = 2;         // partial planes per branch the fused 1x1 tail wrote (conv_mfma_kernel: 2, conv1x1.hip: 1)
 
     Act act(long long pixels, int ch = 64, bool want_lo = false)
     {
@@ -609,6 +610,20 @@ struct Fwd {
             if (ca.tplanes) { fused_ok = false; return; }
             launch_conv_mfma(ca, L.taps, L.nseg, s);
         };
+        // lite's 1x1 convs (conv_input2, the upsampler stages with or without the folded 48->1 tail): the HBM-bound kernel of conv1x1.hip,
+        // in fp16 or with split operands; MOE_CONV1X1=0 keeps them on the generic kernel (A/B)
+        static const bool c1 = [] { const char* e = getenv("MOE_CONV1X1"); return !(e && !strcmp(e, "0")); }();
+        if (c1 && L.taps == 1 && L.nseg == 1 && !L.per_plane && !res && L.scale == 1.f && !tplanes && conv_impl() == 2 && (!x3 || (in.lo && L.has_x3))) {
+            Conv1x1Args q{};
+            q.in_hi = in.hi; q.in_lo = x3 ? in.lo : nullptr; q.out_hi = out.hi; q.out_lo = x3 ? out.lo : nullptr;
+            q.w_hi = blob<half_t>(L.w_hi); q.w_lo = x3 ? blob<half_t>(L.w_lo) : nullptr; q.bias = a.bias;
+            q.tail_w = tail1_w; q.tail_out = tail1_out; q.slope = L.slope;
+            q.B = B; q.H = H; q.W = W; q.r = L.r; q.nchunks = L.nchunks; q.out_cs = out_cs;
+            const int rec = prof_begin(key, (x3 ? 3 : 1) * 2.0 * (double)B * H * W * L.cout * L.cin);
+            const bool ok = launch_conv1x1(q, n.max_groups, s);
+            prof_end(rec);
+            if (ok) { if (tail1_out) tail1_parts = 1; return true; }
+        }
         static const std::string trace_key = [] { const char* e = getenv("MOE_TRACE_KEY"); return std::string(e ? e : "convt_R1.up1"); }();
         if (!x3 && (dbg & 64) && fast && key == trace_key) {   // timing trace of one launch -> /tmp/moe_trace.bin
             unsigned long long* tr = nullptr;
@@ -1024,7 +1039,7 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         if (fuse1) {
             if (!f.dry()) {
                 Tail1SumArgs t{};
-                t.p0 = part[0]; t.p1 = part[1]; t.y = y; t.y_dtype = y_dtype; t.y_off = y_off_dev; t.B = B; t.H = H; t.W = W;
+                t.p0 = part[0]; t.p1 = part[1]; t.nparts = f.tail1_parts; t.y = y; t.y_dtype = y_dtype; t.y_off = y_off_dev; t.B = B; t.H = H; t.W = W;
                 launch_tail1sum(t, s);
             }
             return MOE_OK;

@@ -350,8 +350,12 @@ __global__ __launch_bounds__(256) void tail1sum_kernel(Tail1SumArgs a)
     if (idx >= plane) return;
     const int b = (int)(idx / hw);
     const long long p = idx - (long long)b * hw;
-    float v = a.p0[idx] + a.p0[plane + idx];
-    if (a.p1) v += a.p1[idx] + a.p1[plane + idx];
+    float v = a.p0[idx];
+    if (a.nparts == 2) v += a.p0[plane + idx];
+    if (a.p1) {
+        v += a.p1[idx];
+        if (a.nparts == 2) v += a.p1[plane + idx];
+    }
     const long long yo = (a.y_off ? a.y_off[b] : (long long)b * hw) + p;
     if (a.y_dtype == MOE_F16) ((half_t*)a.y)[yo] = (half_t)v;
     else ((float*)a.y)[yo] = v;
