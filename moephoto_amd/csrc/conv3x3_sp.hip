@@ -327,10 +327,10 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
                 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
                 const half2_t pr = {(half_t)v[2 * k], (half_t)v[2 * k + 1]};
                 hv[k] = __builtin_bit_cast(unsigned, pr);
-                if (ACT) {         // plain instructions: the builtins would add a canonicalising max per operand
-                    unsigned t;
-                    asm("v_pk_mul_f16 %0, %1, %2" : "=v"(t) : "v"(hv[k]), "v"(slope2));
-                    asm("v_pk_max_f16 %0, %1, %2" : "=v"(hv[k]) : "v"(hv[k]), "v"(t));
+                if (ACT) {         // v_pk_mul_f16 + v_pk_max_f16 (the file is built with -fno-honor-nans: no canonicalising max per operand; as
+                                   // inline asm each pair cost an s_nop the hazard recogniser puts behind instructions it cannot see into)
+                    const half2_t t = pr * __builtin_bit_cast(half2_t, slope2);
+                    hv[k] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(pr, t));
                 }
             }
         }
@@ -512,6 +512,13 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
 #pragma unroll
         for (int s = 0; s < 12; ++s) {
             const int cb = s & 1;
+            // The fragments this step multiplies were read behind the first MFMAs of the previous step: they landed long ago.  Saying so
+            // once (lgkmcnt(0), the builtin so that the compiler's wait-count pass sees it) replaces the 7-8 counted waits per step it
+            // otherwise puts between the MFMAs -- it has to count the NEXT step's reads, issued in between, against every older one
+            // (91 s_waitcnt per 152 MFMAs in the PMC instruction mix, each an issue slot).
+#ifndef MOE_NO_STEP_WAIT
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
             switch (s + 1) {   // constant after unrolling
 #define MOE_CASE(N) case N: MOE_LOAD_STEP(N, ((N) & 1), abuf) break;
                 MOE_CASE(1) MOE_CASE(2) MOE_CASE(3) MOE_CASE(4) MOE_CASE(5) MOE_CASE(6)

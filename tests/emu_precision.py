@@ -113,6 +113,80 @@ def max_err(arch, sd, x, mode, n_exact=0, want=None):
         return float((forward(arch, sd, x, w16, a16, s16) - want).abs().max())
 
 
+def lite_layer_names(scale):
+    st = int(scale).bit_length() - 1
+    return ['input2'] + ['lb%d.c%d' % (k, j) for k in (1, 2, 3) for j in (1, 2)] + ['%s.up%d' % (t, k) for t in ('r', 'u') for k in range(st)]
+
+
+def forward_lite(sd, x, scale, exact=(), pairs=True):
+    """MoeNet_lite2.Net (python/MoeNet_lite2.py:22-54 of the reference) as the engine computes it: a conv in `exact` (or 'all') uses
+    fp32 operands (split operands on the GPU) and its output keeps its low part; any other conv rounds weights, input and output to fp16.
+    The stem is fp32 in every mode; `pairs`: the stem output and the stream t = o * g + t are kept as hi + lo (else fp16).  The last
+    upsampler stage feeds the 48->1 tail in fp32 (one kernel), so the tails add no rounding."""
+    T = lambda k: torch.from_numpy(np.asarray(sd[k], dtype=np.float32))
+    stages = int(scale).bit_length() - 1
+    ex = lambda name: 'all' in exact or name in exact
+
+    def conv(name, v, w, b=None, pad=1, keep32=False):
+        if ex(name):
+            return F.conv2d(v, w, b, padding=pad)
+        o = F.conv2d(r16(v), r16(w), b, padding=pad)
+        return o if keep32 else r16(o)
+    x = torch.from_numpy(np.asarray(x, dtype=np.float32))
+    out = prelu(F.conv2d(x, T('conv_input.weight'), padding=1), float(T('relu.weight')[0]))
+    if not pairs:
+        out = r16(out)
+    w = T('conv_input2.weight')
+    t = conv('input2', out, w, pad=w.shape[-1] // 2)
+    for k in (1, 2, 3):
+        p = 'convt_F1{}.'.format(k)
+        o = prelu(conv('lb%d.c1' % k, t, T(p + 'conv_1.weight')), float(T(p + 'relu.weight')[0]))
+        if not ex('lb%d.c1' % k):
+            o = r16(o)
+        o = conv('lb%d.c2' % k, o, T(p + 'conv_2.weight'))
+        g = o.mean(dim=(2, 3), keepdim=True)
+        g = torch.relu(F.conv2d(g, T(p + 'se.conv_du.0.weight'), T(p + 'se.conv_du.0.bias')))
+        g = torch.sigmoid(F.conv2d(g, T(p + 'se.conv_du.2.weight'), T(p + 'se.conv_du.2.bias')))
+        t = o * g + t
+        if not pairs:
+            t = r16(t)
+
+    def branch(v, pre, tag):
+        for k in range(stages):
+            p = '{}.{}.'.format(pre, k)
+            w = T(p + '0.weight')
+            last = k == stages - 1
+            v = conv('%s.up%d' % (tag, k), v, w, T(p + '0.bias'), pad=w.shape[-1] // 2, keep32=last)
+            v = prelu(shuffle(v, 2), float(T(p + '2.weight')[0]))
+            if not last and not ex('%s.up%d' % (tag, k)):
+                v = r16(v)
+        return v
+    wr, wi = T('convt_R1.weight'), T('convt_I1.weight')
+    return F.conv2d(branch(t, 'ures', 'r'), wr, padding=wr.shape[-1] // 2) + F.conv2d(branch(out, 'uim', 'u'), wi, padding=wi.shape[-1] // 2)
+
+
+LITE_RECIPES = [('fp16', None), ('pairs', ()), ('+input2', ('input2',)), ('+lb1', ('input2', 'lb1.c1', 'lb1.c2')),
+                ('+lb1+lb2', ('input2', 'lb1.c1', 'lb1.c2', 'lb2.c1', 'lb2.c2')),
+                ('+input2+r.up*', ('input2', 'r.up0', 'r.up1', 'r.up2')), ('+lb1+r.up*', ('input2', 'lb1.c1', 'lb1.c2', 'r.up0', 'r.up1', 'r.up2')),
+                ('+all c2', ('input2', 'lb1.c2', 'lb2.c2', 'lb3.c2')), ('+lb1+up*', ('input2', 'lb1.c1', 'lb1.c2', 'r.up0', 'r.up1', 'r.up2', 'u.up0', 'u.up1', 'u.up2')),
+                ('fp16x3', ('all',))]
+
+
+def lite_budget(keys=('lite2', 'lite4', 'lite8')):
+    for key in keys:
+        sd, scale = _load(key), int(key[4:])
+        for kind, shape, seed in (('natural', (3, 40, 264), 5), ('noise', (3, 96, 96), 5), ('noise-u8', (3, 128, 128), 0)):
+            x = gd.natural_image(seed, shape) if kind == 'natural' else gd.noise_image(seed, shape) if kind == 'noise' else gd.noise_u8(seed, shape).astype(np.float32) / 255.0
+            x = x[:, None]
+            with torch.no_grad():
+                want = forward_lite(sd, x, scale, ('all',))
+                line = '%-6s %-8s' % (key, kind)
+                for name, ex in LITE_RECIPES:
+                    got = forward_lite(sd, x, scale, (), pairs=False) if ex is None else forward_lite(sd, x, scale, ex, pairs=True)
+                    line += ' | %s %.2e' % (name, float((got - want).abs().max()))
+            print(line, flush=True)
+
+
 DEFAULT_EXACT = {'net2x': 6, 'net3x': 2, 'net4x': 1, 'netdn': 1}      # == exact_blocks_of() in engine.cpp
 
 
@@ -124,6 +198,9 @@ def _load(key):
 def main(argv):
     torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
     cmd = argv[1] if len(argv) > 1 else 'budget'
+    if cmd == 'lite':
+        lite_budget(tuple(argv[2:]) or ('lite2', 'lite4', 'lite8'))
+        return
     if cmd == 'layers':
         key = argv[2] if len(argv) > 2 else 'a2'
         arch, sd = gd.MODELS[key][0], _load(key)
