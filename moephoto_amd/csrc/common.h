@@ -79,6 +79,9 @@ hipError_t conv_mfma_init(); // raise dynamic-LDS limits once per process
 // 3x3 / 64-channel specialisation: one wave per SIMD with the epilogue software-pipelined into the MFMA stream (conv3x3_sp.hip)
 bool launch_conv3x3_sp(const ConvArgs& a, hipStream_t s);   // false: epilogue variant not compiled, use another kernel
 hipError_t conv3x3_sp_init();
+// the upsampler convs with register-resident weights (conv3x3_rw.hip): PReLU (+ fused tail) epilogues only
+bool launch_conv3x3_rw(const ConvArgs& a, hipStream_t s);   // false: not applicable, use conv3x3_sp
+hipError_t conv3x3_rw_init();
 
 // One fused ARSB  y = x + conv_2(PReLU(conv_1(x)))  (arsb_fused.hip; conv_2's weights carry the ScaleLayer factor)
 struct ArsbArgs {

@@ -605,7 +605,12 @@ struct Fwd {
         const bool fast = L.taps == 9 && L.nseg == 1 && !L.per_plane && conv_impl() == 2;
         if (tplanes && !(fast && !x3)) return false;
         bool fused_ok = true;
+        // PReLU-only epilogues (first upsampler stage of Net4x, SEDN's rblock convs) run on the register-resident-weights kernel
+        // (conv3x3_rw.hip: 6 % faster there); its fused-tail variant is 4 % slower than conv3x3_sp's and only used with MOE_SP_IMPL=rw;
+        // MOE_SP_IMPL=sp: everything on conv3x3_sp (A/B)
+        static const int rw_mode = [] { const char* e = getenv("MOE_SP_IMPL"); return !e ? 1 : !strcmp(e, "rw") ? 2 : !strcmp(e, "sp") ? 0 : 1; }();
         auto launch = [&](const ConvArgs& ca) {
+            if (fast && rw_mode && (rw_mode == 2 || !ca.tplanes) && launch_conv3x3_rw(ca, s)) return;
             if (fast && launch_conv3x3_sp(ca, s)) return;
             if (ca.tplanes) { fused_ok = false; return; }
             launch_conv_mfma(ca, L.taps, L.nseg, s);
