@@ -251,6 +251,9 @@ __global__ __launch_bounds__(256) void arsb_fused_kernel(ArsbArgs a)
                     asm volatile("" ::: "memory");
                     ARSB_STAMP(2)
                 }
+                // (this row's fragments were read during the previous row: one lgkmcnt(0) the compiler's count pass can see replaces the counted
+                // waits it otherwise puts between the MFMAs, conv3x3_sp.hip)
+                __builtin_amdgcn_s_waitcnt(0xC07F);
                 if (xr < 11 && !(ARSB_ABL & 8)) { MOE_READ_ROW((xr + 1) & 1, xr + 1) }
                 if (xr < 11 && (ARSB_ABL & 8)) { _Pragma("unroll") for (int f_ = 0; f_ < 12; ++f_) fr[(xr + 1) & 1][f_] = fr[xr & 1][f_]; }
 #pragma unroll
@@ -326,6 +329,7 @@ __global__ __launch_bounds__(256) void arsb_fused_kernel(ArsbArgs a)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int xr = 0; xr < 10; ++xr) {
+                __builtin_amdgcn_s_waitcnt(0xC07F);
                 if (xr < 9 && !(ARSB_ABL & 8)) { MOE_READ_ROW((xr + 1) & 1, xr + 1) }
                 if (xr < 9 && (ARSB_ABL & 8)) { _Pragma("unroll") for (int f_ = 0; f_ < 12; ++f_) fr[(xr + 1) & 1][f_] = fr[xr & 1][f_]; }
 #pragma unroll

@@ -162,6 +162,7 @@ __global__ __launch_bounds__(256) void conv64_x3_kernel(ConvX3Args a)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int xr = 0; xr < 10; ++xr) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);      // this row's fragments (read during the previous row) have landed: no counted waits between the MFMAs
             if (xr < 9) { MOE_READ_ROW((xr + 1) & 1, xr + 1) }
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx)
@@ -219,6 +220,7 @@ __global__ __launch_bounds__(256) void conv64_x3_kernel(ConvX3Args a)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int xr = 0; xr < 10; ++xr) {
+                __builtin_amdgcn_s_waitcnt(0xC07F);
                 if (xr < 9) { MOE_READ_ROW((xr + 1) & 1, xr + 1) }
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx)
