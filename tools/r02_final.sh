@@ -14,7 +14,7 @@ pass() {  # name, kernel regex, counters...
   timeout 300 rocprofv3 --pmc "$@" --kernel-include-regex "$re" -d $OUT/pmc_$name -o pmc -f csv -- python tools/prof_workload.py > $OUT/pmc_$name.log 2>&1
   echo "pmc $name rc=$?"
 }
-SP='conv3x3_sp_kernel<[37]>'
+SP='conv3x3_(sp|rw)_kernel<[137]>'
 AR='arsb_fused_kernel'
 pass sp_fetch "$SP" FETCH_SIZE
 pass sp_write "$SP" WRITE_SIZE
