@@ -608,7 +608,8 @@ struct Fwd {
         // PReLU-only epilogues (first upsampler stage of Net4x, SEDN's rblock convs) run on the register-resident-weights kernel
         // (conv3x3_rw.hip: 6 % faster there); its fused-tail variant is 4 % slower than conv3x3_sp's and only used with MOE_SP_IMPL=rw;
         // MOE_SP_IMPL=sp: everything on conv3x3_sp (A/B)
-        static const int rw_mode = [] { const char* e = getenv("MOE_SP_IMPL"); return !e ? 1 : !strcmp(e, "rw") ? 2 : !strcmp(e, "sp") ? 0 : 1; }();
+        const char* const sp_impl = getenv("MOE_SP_IMPL");          // (read per call: the parity tests switch forms in-process)
+        const int rw_mode = !sp_impl ? 1 : !strcmp(sp_impl, "rw") ? 2 : !strcmp(sp_impl, "sp") ? 0 : 1;
         auto launch = [&](const ConvArgs& ca) {
             if (fast && rw_mode && (rw_mode == 2 || !ca.tplanes) && launch_conv3x3_rw(ca, s)) return;
             if (fast && launch_conv3x3_sp(ca, s)) return;
@@ -617,7 +618,8 @@ struct Fwd {
         };
         // lite's 1x1 convs (conv_input2, the upsampler stages with or without the folded 48->1 tail): the HBM-bound kernel of conv1x1.hip,
         // in fp16 or with split operands; MOE_CONV1X1=0 keeps them on the generic kernel (A/B)
-        static const bool c1 = [] { const char* e = getenv("MOE_CONV1X1"); return !(e && !strcmp(e, "0")); }();
+        const char* const c1env = getenv("MOE_CONV1X1");
+        const bool c1 = !(c1env && !strcmp(c1env, "0"));
         if (c1 && L.taps == 1 && L.nseg == 1 && !L.per_plane && !res && L.scale == 1.f && !tplanes && conv_impl() == 2 && (!x3 || (in.lo && L.has_x3))) {
             Conv1x1Args q{};
             q.in_hi = in.hi; q.in_lo = x3 ? in.lo : nullptr; q.out_hi = out.hi; q.out_lo = x3 ? out.lo : nullptr;

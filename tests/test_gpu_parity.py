@@ -764,6 +764,49 @@ def test_p2_through_plugin_table(dev):
     assert np.abs(y - want).max() <= TOL
 
 
+def test_kernel_forms_agree(dev):
+    """The alternative forms of the hot kernels, switched in-process: the register-resident-weights upsampler conv (conv3x3_rw.hip; default
+    for PReLU epilogues, MOE_SP_IMPL=rw also for the fused tail, =sp not at all) and lite's 1x1 kernel (conv1x1.hip, MOE_CONV1X1=0:
+    generic kernel).  Forms of one layer use the same operands and rounding points: outputs agree to fp32 summation order, and every
+    form is inside the tolerance of its arithmetic against the oracle."""
+    def with_env(name, value, fn):
+        old = os.environ.get(name)
+        try:
+            if value is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = value
+            return fn()
+        finally:
+            if old is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = old
+    for key, shape, prec in (('a4', (3, 24, 72), 'mixed'), ('a4', (2, 41, 35), 'fp16'), ('a3', (3, 16, 40), 'mixed'), ('a2', (1, 9, 33), 'mixed')):
+        arch, sd = gd.MODELS[key][0], gd.state_dict_for(key, load_state_dict_file)
+        x = gd.natural_image(23, shape)[:, None]
+        want = onets.forward(arch, sd, x).numpy()
+        xd = torch.from_numpy(x).to(dev)
+        m = module_for(key, prec)
+        ys = {impl: with_env('MOE_SP_IMPL', impl, lambda: m(xd)[-1].cpu().numpy()) for impl in (None, 'sp', 'rw')}
+        for impl, y in ys.items():
+            assert np.abs(y - ys['sp']).max() <= 2.5e-4, (key, shape, prec, impl, float(np.abs(y - ys['sp']).max()))
+            if prec == 'mixed':
+                assert np.abs(y - want).max() <= TOL, (key, shape, impl, float(np.abs(y - want).max()))
+    for key, shape in (('lite2', (3, 24, 40)), ('lite4', (2, 16, 72)), ('lite8', (1, 9, 35))):
+        arch, sd = gd.MODELS[key][0], gd.state_dict_for(key, load_state_dict_file)
+        x = gd.noise_image(29, shape)[:, None]
+        want = onets.forward(arch, sd, x).numpy()
+        xd = torch.from_numpy(x).to(dev)
+        for prec in ('fp16x3', 'fp16'):
+            m = module_for(key, prec)
+            y1 = with_env('MOE_CONV1X1', None, lambda: m(xd)[-1].cpu().numpy())
+            y0 = with_env('MOE_CONV1X1', '0', lambda: m(xd)[-1].cpu().numpy())
+            assert np.abs(y1 - y0).max() <= (2e-5 if prec == 'fp16x3' else 1e-3), (key, prec, float(np.abs(y1 - y0).max()))
+            if prec == 'fp16x3':
+                assert np.abs(y1 - want).max() <= 2e-5, (key, float(np.abs(y1 - want).max()))
+
+
 def test_split_operand_conv_single_launch(dev):
     """conv64_x3.hip (the three split-operand products of a 3x3 64->64 layer in one launch, both weight parts in registers) against the
     three-launch form (MOE_X3_FUSE=0) and the oracle: every epilogue (plain = conv_input2, PReLU = conv_1, residual = conv_2), ragged

@@ -30,7 +30,7 @@ for key in os.environ.get('FUZZ_KEYS', 'a2,a3,a4,dn_lite5,l25,lite2,lite4').spli
         m = m.to(dtype=torch.float32, device='cuda:0')
         x3 = m.resolved_precision() == 'fp16x3'
         # single-pass fp16 is not the parity mode of NetDN / lite: only gross errors are flagged there
-        tol = 2e-5 if x3 else (8e-3 if arch.startswith('lite') else 3e-3)
+        tol = 2e-5 if x3 else (1e-3 if prec == 'auto' else (8e-3 if arch.startswith('lite') else 3e-3))     # default arithmetic: the product's 1e-3
         worst, wcase = 0.0, None
         for i in range(N):
             B = int(rng.integers(1, 8))
@@ -62,11 +62,11 @@ for i in range(int(os.environ.get('FUZZ_CROPS', '5'))):
         if kind == 'SR a2':
             config.crop_sr = crop
             opt = runSR.getOpt({'model': 'a', 'scale': 2, 'ensemble': 0})
-            arch, sd, pad, sc, tol = 'net2x', gd.state_dict_for('a2', load_state_dict_file), 5, 2, 3e-3
+            arch, sd, pad, sc, tol = 'net2x', gd.state_dict_for('a2', load_state_dict_file), 5, 2, 1e-3
         else:
             config.crop_dn = crop
             opt = runDN.getOpt({'model': 'lite5'})
-            arch, sd, pad, sc, tol = 'netdn', gd.state_dict_for('dn_lite5', load_state_dict_file), 7, 1, 2e-5
+            arch, sd, pad, sc, tol = 'netdn', gd.state_dict_for('dn_lite5', load_state_dict_file), 7, 1, 1e-3
         got = ip.doCrop(opt, torch.from_numpy(x).cuda()).cpu().numpy()
         pl = oplanner.prepare((C, H, W), 1 << 40, 1e-3, pad, sc, 8, crop)
         want = ostitch.do_crop(x, pl, sc, onets.model_fn(arch, sd))
