@@ -19,6 +19,7 @@
 // GEMM view, LDS image (column-keyed XOR swizzle), weight fragment order and the fused epilogue are those of
 // conv_mfma.hip; wave tile = 2 output rows x 32 pixels x 64 output channels.
 #include "common.h"
+#include "rowtile.h"
 
 #ifndef MOE_ABL
 #define MOE_ABL 0
@@ -308,18 +309,9 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
         unsigned lv[4];            // TAIL2: their rounding remainders (v - hi) * 2^11
         if (TAIL2) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float t = v[e] * a.slope;
-                asm("v_max_f32 %0, %1, %2" : "=v"(v[e]) : "v"(v[e]), "v"(t));       // PReLU in fp32 (slope <= 1)
-            }
+            for (int e = 0; e < 8; ++e) v[e] = __builtin_fmaxf(v[e], v[e] * a.slope);       // PReLU in fp32 (slope <= 1)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-                const half2_t pr = {(half_t)v[2 * k], (half_t)v[2 * k + 1]};
-                hv[k] = __builtin_bit_cast(unsigned, pr);
-                const half2_t lo = {(half_t)__builtin_fmaf((float)pr[0], -2048.f, v[2 * k] * 2048.f), (half_t)__builtin_fmaf((float)pr[1], -2048.f, v[2 * k + 1] * 2048.f)};
-                lv[k] = __builtin_bit_cast(unsigned, lo);
-            }
+            for (int k = 0; k < 4; ++k) split2(v[2 * k], v[2 * k + 1], -2048.f, hv[k], lv[k]);     // (rowtile.h: 5 instructions per pair with v_fma_mixlo/hi_f16; 9 before)
         }
         if (!RES && !X3 && !TAIL2) {
 #pragma unroll
