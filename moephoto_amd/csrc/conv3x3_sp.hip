@@ -229,6 +229,10 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
     constexpr bool ACT = (EPI == 1) || (EPI == 3), RES = (EPI == 2) || (EPI == 5) || (EPI == 6), TAIL = (EPI == 3) || (EPI == 7), X3 = (EPI == 4) || (EPI == 5);
     constexpr bool TAIL2 = (EPI == 7);
     constexpr int DRAIN0 = 0;      // first of the eight k-steps that carry a slice of the previous tile's epilogue
+#ifndef MOE_DRAIN2
+#define MOE_DRAIN2 0      // 1: measured +0.9 % on the launch (the early k-steps get too crowded); the wait it shortens is 300 of 6,260 cycles
+#endif
+    constexpr bool DRAIN2 = TAIL && MOE_DRAIN2;
     unsigned slope2;               // {slope, slope} as packed halves
     {
         typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
@@ -547,6 +551,10 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
                             cur[o][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cb][dy][nb], af[cb][pr], (s == 0 && dy == 0) ? biasv[nb] : cur[o][nb], 0, 0, 0);
                     }
                 }
+            if (DRAIN2) {      // fused tail: two slices per step in k-steps 0..3 -- the tap-plane stores (slices 3 and 7) then have eight k-steps
+                               // to be acknowledged before the vmcnt(0) in front of the barrier (traces: that wait was 300 cycles per patch)
+                if (!(MOE_ABL & 2) && s < 4) { drain_slice(prev, itp, top, 2 * s, drain, resw, sidew); drain_slice(prev, itp, top, 2 * s + 1, drain, resw, sidew); }
+            } else
             if (!(MOE_ABL & 2) && s >= DRAIN0 && s < DRAIN0 + 8) drain_slice(prev, itp, top, s - DRAIN0, drain, resw, sidew);
             if (RES && s >= DRAIN0 + 1 && s <= DRAIN0 + 8) fetch_res(toc, s - DRAIN0 - 1);   // slice s-1's registers were consumed in the previous step
             if (X3 && s >= DRAIN0 + 1 && s <= DRAIN0 + 8) fetch_side(toc, s - DRAIN0 - 1);
@@ -582,17 +590,16 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
                 if (RES && i == SGB_DMA_AT + 2 && s >= DRAIN0 + 1 && s <= DRAIN0 + 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 if (X3 && i == SGB_DMA_AT + 3 && s >= DRAIN0 + 1 && s <= DRAIN0 + 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 if (X3 && i == SGB_ST_AT + 1 && s >= DRAIN0 && s < DRAIN0 + 8) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
-                if (i == SGB_ST_AT && s >= DRAIN0 && s < DRAIN0 + 8) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+                if (i == SGB_ST_AT && (DRAIN2 ? (s == 1 || s == 3) : (s >= DRAIN0 && s < DRAIN0 + 8))) __builtin_amdgcn_sched_group_barrier(0x040, DRAIN2 ? 2 : 1, 0);
             }
             // the fused tail adds a 13th MFMA to k-steps 0..7: without a slot of its own it takes the next step's first MFMA slot
             // and every later group slides by one, until the LDS reads land right in front of their consumers
-            if (TAIL && s >= DRAIN0 && s < DRAIN0 + 8) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, SGB_VALU_B, 0);
-            }
-            if (TAIL2 && s >= DRAIN0 && s < DRAIN0 + 8) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, SGB_VALU_B, 0);
+            if (TAIL && (DRAIN2 ? s < 4 : (s >= DRAIN0 && s < DRAIN0 + 8))) {
+#pragma unroll
+                for (int i = 0; i < (DRAIN2 ? 2 : 1) * (TAIL2 ? 2 : 1); ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, SGB_VALU_B, 0);
+                }
             }
             // Nothing moves across a k-step boundary.  As ONE region the sched_group_barrier slot pattern drifts whenever the amount of
             // filler work per step changes (a 13th MFMA in the fused-tail variant, fewer VALU after an epilogue diet ...) until the
