@@ -110,6 +110,9 @@ struct ConvX3Args {
     float slope;                                  // PReLU slope (1: none; <= 1)
     int B, H, W;
     int px, py;                                   // set by the launcher
+    // optional (plain epilogue only): per-plane channel sums of the output, the global average pool of lite's FRM / LB (MoeNet_lite2.py:16-20,
+    // models.py:274) without a second pass over the tensor: pool[b][workgroup][64], zeroed by the caller, pool_slabs >= workgroups
+    float* pool; int pool_slabs;
 };
 bool launch_conv64_x3(ConvX3Args a, int max_groups, hipStream_t s);   // false: not applicable (caller uses the three-launch form)
 hipError_t conv64_x3_init();

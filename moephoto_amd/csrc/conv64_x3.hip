@@ -120,6 +120,23 @@ __global__ __launch_bounds__(256) void conv64_x3_kernel(ConvX3Args a)
 #pragma unroll
     for (int i = 0; i < NPIECE_W; ++i) issue_piece(a.in_hi, it_cur, i, hbuf, true);    // prologue: a_hi of the first patch
 
+    // EPI 3 = plain + pooled: this lane's partial channel sums of the plane being processed; when the workgroup moves on to another
+    // plane (and at the end) the 16 pixel lanes of a channel group are added up and lane n = 0 stores the workgroup's slab
+    constexpr bool POOL = EPI == 3;
+    float psum[4] = {0.f, 0.f, 0.f, 0.f};
+    int pool_b = it_cur.b;
+    auto pool_flush = [&](int b) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = psum[e];
+            t += __shfl_xor(t, 8); t += __shfl_xor(t, 4); t += __shfl_xor(t, 2); t += __shfl_xor(t, 1);
+            psum[e] = t;
+        }
+        if (n == 0) *(float4_t*)(a.pool + ((long long)b * a.pool_slabs + g) * 64 + 16 * w4 + 4 * q) = float4_t{psum[0], psum[1], psum[2], psum[3]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) psum[e] = 0.f;
+    };
+
     for (int p = 0; p < K; ++p) {
         const Item it = it_cur;
         const bool has_next = p + 1 < K;
@@ -127,6 +144,7 @@ __global__ __launch_bounds__(256) void conv64_x3_kernel(ConvX3Args a)
         const char* const hb = hbuf + (p & 1) * XBYTES;
         char* const hn = hbuf + ((p + 1) & 1) * XBYTES;
         const int y0 = it.pyi * TH, x0 = it.pxi * TW;
+        if (POOL && it.b != pool_b) { pool_flush(pool_b); pool_b = it.b; }
 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                     // a_hi[p] has landed; every wave is done with a_lo[p-1]
@@ -213,6 +231,15 @@ __global__ __launch_bounds__(256) void conv64_x3_kernel(ConvX3Args a)
                             asm("v_max_f32 %0, %1, %2" : "=v"(v[cb][e]) : "v"(v[cb][e]), "v"(t));
                         }
                 }
+                if (POOL) {      // channel sums over the pixels inside the image (v[cb][e]: pixel x0 + 16 cb + n, channel 16 w4 + 4 q + e)
+                    const bool oky = y0 + o < a.H;
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) {
+                        const float m = (oky & (x0 + 16 * cb + n < a.W)) ? 1.f : 0.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) psum[e] = __builtin_fmaf(v[cb][e], m, psum[e]);
+                    }
+                }
                 finish_row<EPI == 2, EPI == 2, true>(v, sidew[o & 3], resw[o & 3], kc, (char*)a.out_hi, (char*)a.out_lo, row_off(o));
             };
             MOE_SET_BASE(lbuf)
@@ -254,6 +281,7 @@ __global__ __launch_bounds__(256) void conv64_x3_kernel(ConvX3Args a)
 #undef MOE_PIN_ROW
         it_cur = itn;
     }
+    if (POOL) pool_flush(pool_b);
 }
 
 template <int EPI>
@@ -269,6 +297,7 @@ hipError_t conv64_x3_init()
     hipError_t e;
     if ((e = set_limit<0>()) != hipSuccess) return e;
     if ((e = set_limit<1>()) != hipSuccess) return e;
+    if ((e = set_limit<3>()) != hipSuccess) return e;
     return set_limit<2>();
 }
 
@@ -285,7 +314,9 @@ bool launch_conv64_x3(ConvX3Args a, int max_groups, hipStream_t s)
     const long long items = (long long)a.B * a.px * a.py;
     const int G = (int)std::min<long long>(items, max_groups);
     const dim3 grid(G), blk(256);
-    if (a.res_hi) conv64_x3_kernel<2><<<grid, blk, LDS_BYTES, s>>>(a);
+    if (a.pool && (a.res_hi || a.slope != 1.f || a.pool_slabs < G)) return false;
+    if (a.pool) conv64_x3_kernel<3><<<grid, blk, LDS_BYTES, s>>>(a);
+    else if (a.res_hi) conv64_x3_kernel<2><<<grid, blk, LDS_BYTES, s>>>(a);
     else if (a.slope != 1.f) conv64_x3_kernel<1><<<grid, blk, LDS_BYTES, s>>>(a);
     else conv64_x3_kernel<0><<<grid, blk, LDS_BYTES, s>>>(a);
     return true;

@@ -501,6 +501,9 @@ struct Fwd {
     half_t* side16 = nullptr;    // fp16 sum of the two low-order products of a 3x3 conv (split precision), output layout
     bool dry() const { return ar.base == nullptr; }
     int tail1_parts = 2;         // partial planes per branch the fused 1x1 tail wrote (conv_mfma_kernel: 2, conv1x1.hip: 1)
+    float* pool_out = nullptr;   // set around a conv() call: let the conv pool its output per plane (conv64_x3's pooled epilogue), [B][pool_slabs][64]
+    int pool_slabs = 0;
+    bool pool_done = false;      // the conv did
 
     Act act(long long pixels, int ch = 64, bool want_lo = false)
     {
@@ -678,10 +681,11 @@ struct Fwd {
                 q.res_hi = res ? res->hi : nullptr; q.res_lo = res ? res->lo : nullptr;
                 q.w_hi = blob<half_t>(L.w_arsb); q.w_lo = blob<half_t>(L.w_arsb_lo); q.zero = small<half_t>("zero");
                 q.slope = L.slope; q.B = B; q.H = H; q.W = W;
+                if (pool_out && !res && L.slope == 1.f) { q.pool = pool_out; q.pool_slabs = pool_slabs; }
                 const int rec = prof_begin(key, 3 * 2.0 * (double)B * H * W * L.cout * L.cin * L.taps);
                 const bool ok = launch_conv64_x3(q, n.max_groups, s);
                 prof_end(rec);
-                if (ok) return true;
+                if (ok) { pool_done = q.pool != nullptr; return true; }
             }
         }
         if (fast && L.nchunks <= 16) {
@@ -994,7 +998,11 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
     {
         Act A = f.act(P), Bb = f.act(P), Cc = f.act(P), Dd = f.act(P);
         const int nslab = (int)std::min<long long>(64, std::max<long long>(1, ((long long)h * w) / 256));
-        float* partial = (float*)f.ar.take((size_t)B * nslab * 64 * 4);
+        // the pooled sums of conv_2's output come out of conv64_x3's epilogue, one slab per workgroup (fp16x3, the default of lite); in the
+        // other modes a separate pass (pool_partial) forms nslab slabs per plane
+        const int pslabs = n.max_groups;
+        static const bool poolfuse = [] { const char* e = getenv("MOE_POOL_FUSE"); return !(e && !strcmp(e, "0")); }();
+        float* partial = (float*)f.ar.take((size_t)B * std::max(nslab, pslabs) * 64 * 4);
         float* gate = (float*)f.ar.take((size_t)B * 64 * 4);
         stem(A);
         f.tap("stem", A, h, w, 64, 48);
@@ -1003,11 +1011,17 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         for (int k = 1; k <= 3; ++k) {
             const std::string key = "lb" + std::to_string(k);
             f.conv(key + ".c1", Bb, Cc, nullptr, h, w);
+            f.pool_done = false;
+            if (!f.dry() && poolfuse && f.x3) {
+                (void)hipMemsetAsync(partial, 0, (size_t)B * pslabs * 64 * 4, s);      // (workgroups without a patch in a plane leave their slab untouched)
+                f.pool_out = partial; f.pool_slabs = pslabs;
+            }
             f.conv(key + ".c2", Cc, Dd, nullptr, h, w);
+            f.pool_out = nullptr;
             if (!f.dry()) {
-                launch_pool_partial(Dd.hi, Dd.lo, partial, B, (long long)h * w, 64, nslab, s);
+                if (!f.pool_done) launch_pool_partial(Dd.hi, Dd.lo, partial, B, (long long)h * w, 64, nslab, s);
                 FrmArgs a{};
-                a.partial = partial; a.nslab = nslab; a.HW = (long long)h * w;
+                a.partial = partial; a.nslab = f.pool_done ? pslabs : nslab; a.HW = (long long)h * w;
                 a.w0 = f.small<float>(key + ".w0"); a.b0 = f.small<float>(key + ".b0");
                 a.w2 = f.small<float>(key + ".w2"); a.b2 = f.small<float>(key + ".b2");
                 a.t = Dd.hi; a.x = Bb.hi; a.out = Bb.hi; a.t_lo = Dd.lo; a.x_lo = Bb.lo; a.out_lo = Bb.lo;

@@ -622,25 +622,30 @@ __global__ __launch_bounds__(256) void sedn_weff_kernel(SednFuseArgs a)
 // ---------------------------------------------------------------------------------------------------
 // lite FRM gate (models.py:270-287) + LB residual (MoeNet_lite2.py:16-20): out = t * gate + x
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void frm_gate_kernel(FrmArgs a)
+__global__ __launch_bounds__(256) void frm_gate_kernel(FrmArgs a)
 {
+    __shared__ float red[4][64];
     __shared__ float mean[64];
     __shared__ float hid[3];
-    const int b = blockIdx.x, t = threadIdx.x;
+    const int b = blockIdx.x, t = threadIdx.x & 63, part = threadIdx.x >> 6;
     float s = 0.f;
-    for (int k = 0; k < a.nslab; ++k) s += a.partial[((long long)b * a.nslab + k) * 64 + t];
-    mean[t] = s / (float)a.HW;
+    for (int k = part; k < a.nslab; k += 4) s += a.partial[((long long)b * a.nslab + k) * 64 + t];     // (fixed order: deterministic)
+    red[part][t] = s;
     __syncthreads();
-    if (t < 3) {
-        float h = a.b0[t];
-        for (int c = 0; c < 64; ++c) h += a.w0[t * 64 + c] * mean[c];
-        hid[t] = h > 0.f ? h : 0.f;
+    if (part == 0) mean[t] = ((red[0][t] + red[1][t]) + (red[2][t] + red[3][t])) / (float)a.HW;
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float h = a.b0[threadIdx.x];
+        for (int c = 0; c < 64; ++c) h += a.w0[threadIdx.x * 64 + c] * mean[c];
+        hid[threadIdx.x] = h > 0.f ? h : 0.f;
     }
     __syncthreads();
-    float u = a.b2[t];
+    if (part == 0) {
+        float u = a.b2[t];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) u += a.w2[t * 3 + k] * hid[k];
-    a.gate[b * 64 + t] = 1.f / (1.f + __expf(-u));
+        for (int k = 0; k < 3; ++k) u += a.w2[t * 3 + k] * hid[k];
+        a.gate[b * 64 + t] = 1.f / (1.f + __expf(-u));
+    }
 }
 
 __global__ __launch_bounds__(256) void frm_apply_kernel(FrmArgs a)
@@ -859,7 +864,7 @@ void launch_sedn_fuse(const SednFuseArgs& a, hipStream_t s)
 
 void launch_frm(const FrmArgs& a, hipStream_t s)
 {
-    hipLaunchKernelGGL(frm_gate_kernel, dim3(a.B), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(frm_gate_kernel, dim3(a.B), dim3(256), 0, s, a);
     const long long total = (long long)a.B * a.HW * 8;
     hipLaunchKernelGGL(frm_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
 }
