@@ -57,6 +57,9 @@ struct ConvArgs {
     float* tplanes;
     int tail_split;       // fused tail: also split the activation operand (EPI 7; tail_w then holds eight fragments, the second four = fp16 weights in rows 16..24)
     int dbg;              // timing ablations (MOE_DBG env; results are wrong when set): 1 no patch DMA, 2 no MFMA, 4 no stores, 8 no epilogue
+    // conv3x3_rw, PReLU epilogue, one chunk, r = 1 only: per-plane channel sums of the STORED (fp16) output, pool[b][slab][64] with
+    // slab = 2 * workgroup + row half, zeroed by the caller, pool_slabs >= 2 * G (SEDN's fused block tail needs them, sedn_fuse)
+    float* pool; int pool_slabs;
 };
 
 // 1x1 convs of lite (conv1x1.hip): 64 (48 real) input channels, one chunk (r = 1) or four (r = 2, pixel shuffle folded into the store),
@@ -192,6 +195,7 @@ void launch_sedn_se(const SednSeArgs& a, hipStream_t s);
 struct SednFuseArgs {
     const half_t* x;          // [B][H][W][64] input of rblock.4
     float* partial;           // [B][nslab][5][64]: total, first row, last row, first column, last column sums
+    const float* pooled; int pooled_slabs;   // optional: the totals, already formed by the producing conv ([B][pooled_slabs][64]); sedn_xsum then only visits the border pixels
     int nslab, B, H, W;
     const float* w256t;       // [576][256] fp32, k = tap*64 + ci   (rblock.4 weights, transposed)
     const float* w256;        // [256][576]

@@ -2,6 +2,7 @@
 // with the weights RESIDENT IN REGISTERS, second form of the hot kernel (conv3x3_sp.hip is the first and stays the fallback):
 //
 //   EPI 1   PReLU, pixel shuffle folded into the 16-byte stores
+//   EPI 4   = 1 + per-plane channel sums of the stored output (one chunk, r = 1: SEDN's rblock.2, whose sums feed the fused block tail)
 //   EPI 3   PReLU + the fused 64 -> 1 tail conv: per-tap partial sums to the phase-separated tap planes (see conv3x3_sp.hip)
 //
 // What the PMC passes of round 2 said about conv3x3_sp (profiles/r02/i_*): 72 % MFMA busy, 4.0 other instructions per MFMA and 120
@@ -24,6 +25,7 @@
 //
 // LDS: 2 x 45,056 (patches) + 3 x 20,480 (tail exchange) = 151,552 B.
 #include "common.h"
+#include "rowtile.h"
 #include <type_traits>
 
 namespace {
@@ -44,7 +46,7 @@ template <int EPI>
 __global__ __launch_bounds__(256) void conv3x3_rw_kernel(ConvArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)      // (the host pass only needs the launch stub)
-    constexpr bool TAIL = EPI == 3;
+    constexpr bool TAIL = EPI == 3, POOL = EPI == 4;
     constexpr bool PERM = !TAIL;         // EPI 1: channel order that makes registers 8g..8g+7 eight consecutive channels (16-byte stores)
     constexpr unsigned kOOR = 0xFFFF0000u;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -184,9 +186,44 @@ __global__ __launch_bounds__(256) void conv3x3_rw_kernel(ConvArgs a)
             hv[k] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(pr, t));
         }
     };
+    // EPI 4: this lane's sums of the 16 channels it stores (the fp16 values, as a second pass over the tensor would read them), for the plane
+    // `pool_b`; when a row of another plane arrives (and at the end) the 32 pixel lanes are added up and lane j = 0 stores the slab
+    float psum[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) psum[e] = 0.f;
+    int pool_b = -1;
+    auto pool_flush = [&]() {
+        if (pool_b >= 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float t = psum[e];
+                t += __shfl_xor(t, 16); t += __shfl_xor(t, 8); t += __shfl_xor(t, 4); t += __shfl_xor(t, 2); t += __shfl_xor(t, 1);
+                psum[e] = t;
+            }
+            if (j == 0) {
+                float* dst = a.pool + ((long long)pool_b * a.pool_slabs + 2 * g + h) * 64 + 32 * c + 8 * hh;
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    *(float4_t*)(dst + 16 * gp) = float4_t{psum[8 * gp], psum[8 * gp + 1], psum[8 * gp + 2], psum[8 * gp + 3]};
+                    *(float4_t*)(dst + 16 * gp + 4) = float4_t{psum[8 * gp + 4], psum[8 * gp + 5], psum[8 * gp + 6], psum[8 * gp + 7]};
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) psum[e] = 0.f;
+    };
     // EPI 1: the 16-byte stores of output row `orow` (0..7 in the patch) of tile `it`: channels cout0 + 32c + 16 gp + 8 hh .. +7 of pixel j
     auto store_row = [&](const Item& it, int orow, bool live, const unsigned (&h0)[4], const unsigned (&h1)[4]) {
         const int y = it.pyi * kTileH + orow, x = it.pxi * kTileW + j;
+        if (POOL) {
+            if (live && it.b != pool_b) { pool_flush(); pool_b = it.b; }       // (wave-uniform, once per plane)
+            const float m = (live & (y < a.H) & (x < a.W)) ? 1.f : 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                psum[2 * k] = mix_lo(h0[k], m, psum[2 * k]); psum[2 * k + 1] = mix_hi(h0[k], m, psum[2 * k + 1]);
+                psum[8 + 2 * k] = mix_lo(h1[k], m, psum[8 + 2 * k]); psum[8 + 2 * k + 1] = mix_hi(h1[k], m, psum[8 + 2 * k + 1]);
+            }
+        }
         const unsigned vo = (x < a.W) ? (unsigned)(j * r) * out_px + (unsigned)hh * 16u : kOOR;
         const unsigned so = (live & (y < a.H)) ? ((unsigned)(it.b * (int)Ho + y * r + si) * Wo + (unsigned)(it.pxi * kTileW * r + sj)) * out_px + (unsigned)(cout0 + 32 * c) * 2u : kOOR;
         const u4_t d0 = {h0[0], h0[1], h0[2], h0[3]}, d1 = {h1[0], h1[1], h1[2], h1[3]};
@@ -447,6 +484,7 @@ __global__ __launch_bounds__(256) void conv3x3_rw_kernel(ConvArgs a)
         act8(v3 + 8, hB);
         if (TAIL) tail_partial(hA, hB, (K + 2) % 3, 4 * h + 3);
         else store_row(it_prev, 4 * h + 3, true, hA, hB);
+        if (POOL) pool_flush();
         if (TAIL) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -474,6 +512,7 @@ hipError_t conv3x3_rw_init()
 {
     hipError_t e;
     if ((e = set_limit<1>()) != hipSuccess) return e;
+    if ((e = set_limit<4>()) != hipSuccess) return e;
     return set_limit<3>();
 }
 
@@ -489,7 +528,9 @@ bool launch_conv3x3_rw(const ConvArgs& a, hipStream_t s)
     if (!tail && 2ll * a.B * a.H * a.r * a.W * a.r * a.out_cs >= (1ll << 32) - 65536) return false;
     if (tail && 36ll * a.B * a.H * a.r * a.W * a.r >= (1ll << 32) - 8192) return false;
     const int blocks = a.nchunks * ((a.G + 7) / 8) * 8;
+    if (a.pool && (tail || a.nchunks != 1 || a.r != 1 || a.pool_slabs < 2 * a.G)) return false;
     if (tail) conv3x3_rw_kernel<3><<<dim3(blocks), dim3(256), LDS_BYTES, s>>>(a);
+    else if (a.pool) conv3x3_rw_kernel<4><<<dim3(blocks), dim3(256), LDS_BYTES, s>>>(a);
     else conv3x3_rw_kernel<1><<<dim3(blocks), dim3(256), LDS_BYTES, s>>>(a);
     return true;
 }

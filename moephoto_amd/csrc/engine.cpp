@@ -603,6 +603,7 @@ struct Fwd {
         a.tail_w = tail_w; a.tplanes = tplanes;
         a.tail_split = (tplanes && mixed && tail_split_for(key)) ? 1 : 0;
         a.tail1_w = tail1_w; a.tail1_out = tail1_out;
+        if (pool_out && !x3 && L.r == 1 && L.nchunks == 1 && !res) { a.pool = pool_out; a.pool_slabs = pool_slabs; }      // conv3x3_rw's pooled epilogue (SEDN rblock.2)
         // 3x3 / 64-input-channel layers with shared weights run on the software-pipelined kernel (conv3x3_sp.hip); everything else
         // (1x1 convs, SEDN's per-plane `trans`, epilogues that kernel does not compile, MOE_CONV_IMPL=v1) on the generic one
         const bool fast = L.taps == 9 && L.nseg == 1 && !L.per_plane && conv_impl() == 2;
@@ -614,7 +615,7 @@ struct Fwd {
         const char* const sp_impl = getenv("MOE_SP_IMPL");          // (read per call: the parity tests switch forms in-process)
         const int rw_mode = !sp_impl ? 1 : !strcmp(sp_impl, "rw") ? 2 : !strcmp(sp_impl, "sp") ? 0 : 1;
         auto launch = [&](const ConvArgs& ca) {
-            if (fast && rw_mode && (rw_mode == 2 || !ca.tplanes) && launch_conv3x3_rw(ca, s)) return;
+            if (fast && rw_mode && (rw_mode == 2 || !ca.tplanes) && launch_conv3x3_rw(ca, s)) { pool_done = ca.pool != nullptr; return; }
             if (fast && launch_conv3x3_sp(ca, s)) return;
             if (ca.tplanes) { fused_ok = false; return; }
             launch_conv_mfma(ca, L.taps, L.nseg, s);
@@ -943,16 +944,27 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         const bool sfuse = fuse_env && !f.x3 && !f.direct && !n.debug && conv_impl() == 2 && B <= n.max_groups &&
                            2ll * B * h * w * 64 < (1ll << 32) - 8192;
         float* xpart = (float*)f.ar.take((size_t)B * nslab * 5 * 64 * 4);
+        // the channel totals of rblock.2's output come out of that conv's epilogue (conv3x3_rw EPI 4), sedn_xsum then only visits the border
+        const int pslabs = 2 * n.max_groups;
+        float* xpool = (float*)f.ar.take((size_t)B * pslabs * 64 * 4);
+        static const bool spool = [] { const char* e = getenv("MOE_POOL_FUSE"); return !(e && !strcmp(e, "0")); }();
         float* fgate = (float*)f.ar.take((size_t)B * 256 * 4);
         half_t* weff = (half_t*)f.ar.take((size_t)B * 72 * 512 * 2);
         for (int b = 0; b < 16; ++b) {
             const std::string k = "b" + std::to_string(b);
             f.conv(k + ".rb0", A, Cc, nullptr, h, w);
+            f.pool_done = false;
+            if (sfuse && spool && !f.dry()) {
+                (void)hipMemsetAsync(xpool, 0, (size_t)B * pslabs * 64 * 4, s);
+                f.pool_out = xpool; f.pool_slabs = pslabs;
+            }
             f.conv(k + ".rb2", Cc, Dd, nullptr, h, w);
+            f.pool_out = nullptr;
             if (sfuse) {
                 if (!f.dry()) {
                     SednFuseArgs fa{};
                     fa.x = Dd.hi; fa.partial = xpart; fa.nslab = nslab; fa.B = B; fa.H = h; fa.W = w;
+                    if (f.pool_done) { fa.pooled = xpool; fa.pooled_slabs = pslabs; }
                     fa.w256t = f.small<float>(k + ".w256t"); fa.w256 = f.small<float>(k + ".w256"); fa.wt = f.small<float>(k + ".wt");
                     fa.w_down = f.small<float>(k + ".down"); fa.w_up = f.small<float>(k + ".up");
                     fa.gate = fgate; fa.weff = weff;

@@ -480,10 +480,25 @@ __global__ __launch_bounds__(256) void sedn_xsum_kernel(SednFuseArgs a)
     for (int c = 0; c < 5; ++c)
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[c][e] = 0.f;
-    for (long long p = p0 + pl; p < p1; p += 32) {
-        const int y = (int)(p / a.W), x = (int)(p - (long long)y * a.W);
+    // with the totals already formed by the producing conv only the border pixels are visited: index i in [0, 2W + 2H) = first row,
+    // last row, first column, last column (corner pixels appear in a row list and in a column list, as they must)
+    const long long nb = a.pooled ? 2ll * a.W + 2ll * a.H : HW;
+    const long long bper = (nb + a.nslab - 1) / a.nslab;
+    const long long q0 = a.pooled ? slab * bper : p0, q1 = a.pooled ? ((q0 + bper < nb) ? q0 + bper : nb) : p1;
+    for (long long i = q0 + pl; i < q1; i += 32) {
+        int y, x;
+        float f0 = 1.f, fr0, frl, fc0, fcl;
+        if (a.pooled) {
+            const long long w2 = 2ll * a.W;
+            if (i < w2) { y = i < a.W ? 0 : a.H - 1; x = (int)(i < a.W ? i : i - a.W); fr0 = i < a.W ? 1.f : 0.f; frl = 1.f - fr0; fc0 = fcl = 0.f; }
+            else { const long long k = i - w2; x = k < a.H ? 0 : a.W - 1; y = (int)(k < a.H ? k : k - a.H); fc0 = k < a.H ? 1.f : 0.f; fcl = 1.f - fc0; fr0 = frl = 0.f; }
+            f0 = 0.f;
+        } else {
+            y = (int)(i / a.W); x = (int)(i - (long long)y * a.W);
+            fr0 = y == 0 ? 1.f : 0.f; frl = y == a.H - 1 ? 1.f : 0.f; fc0 = x == 0 ? 1.f : 0.f; fcl = x == a.W - 1 ? 1.f : 0.f;
+        }
+        const long long p = (long long)y * a.W + x;
         const half8_t v = *(const half8_t*)(a.x + ((long long)b * HW + p) * 64 + cg * 8);
-        const float f0 = 1.f, fr0 = y == 0 ? 1.f : 0.f, frl = y == a.H - 1 ? 1.f : 0.f, fc0 = x == 0 ? 1.f : 0.f, fcl = x == a.W - 1 ? 1.f : 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float t = (float)v[e];
@@ -512,8 +527,26 @@ __global__ __launch_bounds__(256) void sedn_fmean_kernel(SednFuseArgs a)
     __shared__ float red[4][64];
     const int b = blockIdx.x, t = threadIdx.x;
     const long long HW = (long long)a.H * a.W;
+    if (a.pooled) {
+        // totals from the producing conv: [pooled_slabs][64] per plane (hundreds of slabs): thread = (slab class t / 16, channels 4 (t % 16) ..),
+        // 16-byte loads, eight in flight; then a fixed-order sum of the 16 classes
+        __shared__ float4_t pred[16][16];
+        const int cls = t >> 4, c4 = t & 15;
+        float4_t v = {0.f, 0.f, 0.f, 0.f};
+        const float4_t* src = (const float4_t*)(a.pooled + (long long)b * a.pooled_slabs * 64) + c4;
+#pragma unroll 8
+        for (int k = cls; k < a.pooled_slabs; k += 16) v = v + src[(long long)k * 16];
+        pred[cls][c4] = v;
+        __syncthreads();
+        if (t < 64) {
+            float u = 0.f;
+            for (int k = 0; k < 16; ++k) u += pred[k][t >> 2][t & 3];
+            sums[0][t] = u;
+        }
+    }
     for (int i = t; i < 5 * 64; i += 256) {
         const int c = i >> 6, ch = i & 63;
+        if (c == 0 && a.pooled) continue;
         float v = 0.f;
 #pragma unroll 8
         for (int k = 0; k < a.nslab; ++k) v += a.partial[(((long long)b * a.nslab + k) * 5 + c) * 64 + ch];
