@@ -170,7 +170,7 @@ def main():
                 'gflop_per_launch': round(prof['flops'] / prof['launches'] / 1e9, 2)}
     if prof_up1['launches'] > 0:
         res['roofline'] = roof(prof_up1, 'conv3x3_sp_kernel<3> (3x3 64->256 @2x res, +bias +PixelShuffle(2) +PReLU, fused 64->1 tail taps)')
-        res['roofline']['traffic'] = _pmc_traffic()
+        res['roofline']['traffic'] = _pmc_traffic(res['roofline']['gflop_per_launch'])
     if prof_c2['launches'] > 0:
         res['roofline_trunk'] = roof(prof_c2, 'arsb_fused_kernel (one ARSB per launch: two 3x3 64->64 convs @1x res + PReLU + hi/lo residual stream)')
 
@@ -293,11 +293,14 @@ def _one_socket_cores():
     return n, n
 
 
-def _pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), if present."""
+def _pmc_traffic(gflop_per_launch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), if present.  The counters were
+    collected on launches of 12 planes of 256^2 (tools/prof_workload.py); the benchmark's launches carry more planes (8 tiles per
+    launch set, split by the 32-bit offset range), so the figure is scaled by the launches' algorithmic FLOPs (traffic is linear in planes)."""
     p = os.path.join(ROOT, 'profiles', 'pmc_dominant.json')
     try:
-        return json.load(open(p)).get('hbm_bytes_per_launch')
+        d = json.load(open(p))
+        return int(d['hbm_bytes_per_launch'] * gflop_per_launch / d['gflop_per_launch'])
     except Exception:
         return None
 

@@ -1551,7 +1551,7 @@ int moe_run_plan_ex(moe_net* n, const moe_plan* pl, const void* img, int img_dty
         pool = p.pool;
     }
     if (max_tiles <= 0) {
-        max_tiles = 4;
+        max_tiles = 8;      // (tiles of 256^2 pixels per launch set; 8 measured 1.8 % faster than 4 on the 1080p x4 frame: fewer pipeline fills per pixel)
         if (const char* e = getenv("MOE_TILES_PER_BATCH")) { const int v = atoi(e); if (v > 0) max_tiles = v; }
     }
     for (size_t gi = 0; gi < p.groups.size(); ++gi) {
@@ -1635,7 +1635,7 @@ int moe_run_plan_tiles(moe_net* n, const moe_plan* pl, const void* imgs, int img
         d->n_frames = n_frames; d->tile_dst.assign(tile_dst, tile_dst + nt * n_frames);
     }
     if (max_tiles <= 0) {
-        max_tiles = 4;
+        max_tiles = 8;      // (tiles of 256^2 pixels per launch set; 8 measured 1.8 % faster than 4 on the 1080p x4 frame: fewer pipeline fills per pixel)
         if (const char* e = getenv("MOE_TILES_PER_BATCH")) { const int v = atoi(e); if (v > 0) max_tiles = v; }
     }
     for (size_t gi = 0; gi < p.groups.size(); ++gi) {
