@@ -77,6 +77,11 @@ int moe_abi_version(void);
 /* number of visible HIP devices (0 when none); never fails */
 int moe_device_count(void);
 
+/* info[0..7] = compute units, max engine clock (kHz), memory clock (kHz), memory bus width (bits), L2 bytes, total memory bytes,
+ * wall-clock rate (kHz), LDS bytes per CU -- what bench.py derives the MFMA / HBM peaks of the roofline from
+ * (the reference reads its device through NVML, python/readgpu.py; config.py:61-71) */
+int moe_device_info(int device, int64_t info[8]);
+
 /* ---- model ------------------------------------------------------------------------------------ */
 int moe_net_create(int arch, int scale, moe_net** out);
 void moe_net_destroy(moe_net* net);
@@ -115,6 +120,12 @@ int moe_net_get_profile(moe_net* net, double* total_ms, int64_t* launches, doubl
 /* MOE_PREC_MIXED only: how many leading ARSBs run with split operands (0..6; -1 = the architecture's default:
  * Net2x 6, Net3x 2, Net4x 1, NetDN 1).  Takes effect at the next forward. */
 int moe_net_set_exact_blocks(moe_net* net, int blocks);
+/* Kernel-form switches of one net, for A/B measurements and the parity tests that compare forms of one layer in-process
+ * ("sp_impl" = "auto" | "rw" | "sp", "arsb_fuse" / "x3_fuse" / "conv1x1" / "fuse_tail" / "sedn_fuse" / "pool_fuse" = "0" | "1",
+ * "tail_split" = "0" | "r" | "ru", "tail_form" = "sums" | "planes", "conv_impl" = "sp" | "v1", "tiles_per_batch", "max_groups").
+ * Defaults come from the MOE_* environment variables of the same names ONCE, at moe_net_create; the forward path itself reads no
+ * environment.  The reference has no such switches: its forward is torch.nn (python/imageProcess.py:391-395). */
+int moe_net_set_option(moe_net* net, const char* key, const char* value);
 /* keep fp32 copies of named intermediates during forwards (slow; debugging / layer-by-layer parity only) */
 int moe_net_set_debug(moe_net* net, int enable);
 /* copy a named intermediate of the LAST forward to host as fp32 NCHW (debug / layer-by-layer parity);
@@ -142,6 +153,10 @@ int moe_plan_ramp(const moe_plan* plan, float* ramp);
  * out: (C, out_h, out_w) contiguous, dtype MOE_F32/MOE_F16. */
 int moe_stitch(const moe_plan* plan, int device, const float* tiles_dev, const int64_t* tile_off, int C,
                void* out, int out_dtype, void* stream);
+/* The same with the tile offsets already on the device (n_tiles int64 elements): no table upload, no cache lookup --
+ * moephoto_amd/dist.py keeps one device table per frame it stitches. */
+int moe_stitch_dev(const moe_plan* plan, int device, const float* tiles_dev, const int64_t* tile_off_dev, int C,
+                   void* out, int out_dtype, void* stream);
 /* doCrop on device: img = (C, Hp, Wp) planes (already padded per moe_plan_info's pad_*_to, see
  * python wrapper), element (c,i,j) at img + c*sC + i*sH + j*sW; out as in moe_stitch.
  * max_tiles_per_batch <= 0 picks a default. */

@@ -54,6 +54,9 @@ def lib():
         'moe_net_get_profile_at': (c_int, [c_vp, c_int, P(c_dbl), P(c_i64), P(c_dbl)]),
         'moe_net_set_exact_blocks': (c_int, [c_vp, c_int]),
         'moe_net_set_debug': (c_int, [c_vp, c_int]),
+        'moe_net_set_option': (c_int, [c_vp, ctypes.c_char_p, ctypes.c_char_p]),
+        'moe_device_info': (c_int, [c_int, P(c_i64)]),
+        'moe_stitch_dev': (c_int, [c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_vp]),
         'moe_net_debug_tap': (c_i64, [c_vp, ctypes.c_char_p, c_vp, c_i64, P(c_i64), c_vp]),
         'moe_plan_create': (c_int, [P(c_i64), c_dbl, c_dbl, c_int, c_int, c_int, c_int, P(c_vp)]),
         'moe_plan_destroy': (None, [c_vp]),
@@ -82,7 +85,7 @@ def lib():
 
 EXPORTS = ['moe_last_error', 'moe_abi_version', 'moe_device_count', 'moe_net_create', 'moe_net_destroy', 'moe_net_scale',
            'moe_net_num_params', 'moe_net_param_info', 'moe_net_set_param', 'moe_net_finalize', 'moe_net_workspace_bytes',
-           'moe_net_max_tile_pixels', 'moe_net_forward', 'moe_net_set_profile', 'moe_net_get_profile', 'moe_net_get_profile_at', 'moe_net_set_exact_blocks', 'moe_net_set_debug', 'moe_net_debug_tap', 'moe_plan_create', 'moe_plan_destroy', 'moe_plan_info',
+           'moe_net_max_tile_pixels', 'moe_net_forward', 'moe_net_set_profile', 'moe_net_get_profile', 'moe_net_get_profile_at', 'moe_net_set_exact_blocks', 'moe_net_set_debug', 'moe_net_set_option', 'moe_device_info', 'moe_stitch_dev', 'moe_net_debug_tap', 'moe_plan_create', 'moe_plan_destroy', 'moe_plan_info',
            'moe_plan_tiles', 'moe_plan_ramp', 'moe_plan_pool_elems', 'moe_plan_tile_offsets', 'moe_stitch', 'moe_run_plan',
            'moe_run_plan_ex', 'moe_run_plan_frames', 'moe_run_plan_tiles', 'moe_to_float', 'moe_to_output', 'moe_resize']
 
@@ -97,6 +100,14 @@ def check(rc):
             raise MemoryError(msg)
         raise EngineError(msg)
     return rc
+
+
+def device_info(device=0):
+    """dict of the device properties the roofline figures are derived from (moe_device_info)."""
+    info = (ctypes.c_int64 * 8)()
+    check(lib().moe_device_info(int(device), info))
+    keys = ('compute_units', 'clock_khz', 'mem_clock_khz', 'mem_bus_bits', 'l2_bytes', 'total_mem_bytes', 'wall_clock_khz', 'lds_bytes_per_cu')
+    return dict(zip(keys, [int(v) for v in info]))
 
 
 def require_device():

@@ -41,11 +41,12 @@ class Config(object):
         free, _ = torch.cuda.mem_get_info(self.deviceId)
         return free - 2 ** 28
 
-    def calcFreeMem(self, ratio=.9):
+    def calcFreeMem(self, ratio=.9, emptyCache=False):
         # The engine allocates its workspace and tile pools with hipMalloc, outside torch's caching allocator: memory torch has
         # reserved but not handed out is NOT available to it (the reference adds it back because its nets allocate through torch,
-        # python/config.py:61-71), so the cache is released before asking the driver.
-        free = self.getFreeMem(emptyCache=torch.cuda.memory_reserved(self.deviceId) > torch.cuda.memory_allocated(self.deviceId)) * ratio
+        # python/config.py:61-71).  Releasing torch's cache costs a device synchronisation and the next frames' allocations, so it is
+        # done only on request -- by the caller whose plan or workspace did not fit (imageProcess._plan_for retries once with it).
+        free = self.getFreeMem(emptyCache=emptyCache) * ratio
         if self.maxGraphicMemoryUsage > 0:
             free = min(free, self.maxGraphicMemoryUsage * 2 ** 20 - torch.cuda.memory_allocated(self.deviceId))
         return int(free)

@@ -99,9 +99,6 @@ struct ArsbArgs {
 };
 bool launch_arsb_fused(ArsbArgs a, int max_groups, hipStream_t s);   // false: not applicable (caller runs the two convs)
 hipError_t arsb_fused_init();
-// second form (arsb_pc.hip): conv_1 and conv_2 on different waves, 32x32x16 MFMAs; w1 / w2 in the conv3x3_sp fragment order (w_hi)
-bool launch_arsb_pc(ArsbArgs a, int max_groups, hipStream_t s);
-hipError_t arsb_pc_init();
 
 // One 3x3 64->64 conv with split operands, three products in one launch (conv64_x3.hip); weights in the fused-ARSB order
 struct ConvX3Args {

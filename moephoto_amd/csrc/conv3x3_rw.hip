@@ -14,7 +14,7 @@
 //   rows stream   input row r of the wave's six (one ds_read_b128 per (dx, k-slice): 12 reads) feeds the up to three output rows it
 //                 touches: 72 reads for 144 MFMAs per patch and wave, nothing else is read from LDS in the matrix loop;
 //   epilogue      output row o is complete after input row o+2; its epilogue rides in the MFMA stream of the following rows (rows 2, 3: in
-//                 the first row steps of the next patch), in pieces of a few instructions per B fragment (the scheme of arsb_pc.hip);
+//                 the first row steps of the next patch), in pieces of a few instructions per B fragment;
 //   fused tail    the 64-channel contraction of the tail conv now spans two waves: each forms the partial sums of its 32 channels
 //                 (2 MFMAs per row), folds the low-order weight rows in and leaves 5 floats per lane in an LDS exchange area; two patches
 //                 later (one barrier per patch publishes them) wave (c, h) adds the two halves of rows 4h+2c, 4h+2c+1 and stores the

@@ -78,8 +78,72 @@ struct Arena {                   // bump allocator over the net's workspace (dry
 
 }  // namespace
 
+// Kernel-form switches of one net.  Process-wide defaults come from the environment ONCE, when the net is created (MOE_* variables,
+// kept for command-line A/B runs); after that only moe_net_set_option changes them -- the forward path reads no environment.
+struct NetOptions {
+    int conv_impl = 2;        // conv_impl   sp (2, default: the fast 3x3 kernels) | v1 (0: the generic kernel everywhere; debugging, not with 'mixed')
+    int sp_impl = 1;          // sp_impl     auto (1: conv3x3_rw where it wins) | rw (2: conv3x3_rw for every epilogue it compiles) | sp (0: conv3x3_sp only)
+    int tail_split = 1;       // tail_split  0 | r (1, default: the R branch's fused tail also splits its activation operand) | ru (2)
+    int tail_form = 0;        // tail_form   sums (1: phase-class sums + aprons from conv3x3_rw, tapsum4) | planes (0: nine tap planes per phase, tapsum2)
+    bool conv1x1 = true;      // conv1x1     lite's 1x1 layers on conv1x1.hip (0: generic kernel)
+    bool x3_fuse = true;      // x3_fuse     split-operand 3x3 64->64 layers as ONE launch (conv64_x3.hip; 0: three launches)
+    bool arsb_fuse = true;    // arsb_fuse   single-pass ARSBs as one launch (arsb_fused.hip; 0: two launches)
+    bool fuse_tail = true;    // fuse_tail   last upsampler conv + 64->1 / 48->1 tail conv in one kernel
+    bool sedn_fuse = true;    // sedn_fuse   SEDN's fused block tail
+    bool pool_fuse = true;    // pool_fuse   SE / FRM channel sums out of the producing conv's epilogue
+    int exact_blocks_env = -1;   // MOE_EXACT_BLOCKS (moe_net_set_exact_blocks overrides)
+    int tiles_per_batch = 0;  // tiles_per_batch   tiles of 256^2 pixels per launch set when the caller passes 0 (0: 8)
+    int max_groups = 0;       // max_groups  persistent workgroups per launch (0: one per CU), applied at finalize
+    int dbg = 0;              // dbg         timing-ablation bits of the conv kernels (results are wrong when set)
+    std::string trace_key = "convt_R1.up1";
+    bool arsb_trace = false;
+
+    static int tri(const char* v, const char* a0, const char* a1, const char* a2, int dflt)
+    {
+        if (!v) return dflt;
+        if (a0 && !strcmp(v, a0)) return 0;
+        if (a1 && !strcmp(v, a1)) return 1;
+        if (a2 && !strcmp(v, a2)) return 2;
+        return -1;
+    }
+    static int onoff(const char* v) { return !v ? -1 : (!strcmp(v, "0") || !strcmp(v, "off")) ? 0 : (!strcmp(v, "1") || !strcmp(v, "on")) ? 1 : -1; }
+    // false: unknown key or value
+    bool set(const std::string& key, const char* v)
+    {
+        if (!v) return false;
+        auto flag = [&](bool& dst) { const int b = onoff(v); if (b < 0) return false; dst = b != 0; return true; };
+        if (key == "conv_impl") { if (!strcmp(v, "sp")) conv_impl = 2; else if (!strcmp(v, "v1")) conv_impl = 0; else return false; return true; }
+        if (key == "sp_impl") { const int t = tri(v, "sp", "auto", "rw", -1); if (t < 0) return false; sp_impl = t; return true; }
+        if (key == "tail_split") { const int t = tri(v, "0", "r", "ru", -1); if (t < 0) return false; tail_split = t; return true; }
+        if (key == "tail_form") { const int t = tri(v, "planes", "sums", nullptr, -1); if (t < 0) return false; tail_form = t; return true; }
+        if (key == "conv1x1") return flag(conv1x1);
+        if (key == "x3_fuse") return flag(x3_fuse);
+        if (key == "arsb_fuse") return flag(arsb_fuse);
+        if (key == "fuse_tail") return flag(fuse_tail);
+        if (key == "sedn_fuse") return flag(sedn_fuse);
+        if (key == "pool_fuse") return flag(pool_fuse);
+        if (key == "dbg") { dbg = atoi(v); return true; }
+        if (key == "tiles_per_batch") { tiles_per_batch = atoi(v); return tiles_per_batch >= 0; }
+        if (key == "max_groups") { max_groups = atoi(v); return max_groups >= 0; }
+        if (key == "trace_key") { trace_key = v; return true; }
+        return false;
+    }
+    void from_env()
+    {
+        static const char* const names[][2] = {{"MOE_CONV_IMPL", "conv_impl"}, {"MOE_SP_IMPL", "sp_impl"}, {"MOE_TAIL_SPLIT", "tail_split"}, {"MOE_TAIL_FORM", "tail_form"},
+                                               {"MOE_CONV1X1", "conv1x1"}, {"MOE_X3_FUSE", "x3_fuse"}, {"MOE_ARSB_FUSE", "arsb_fuse"}, {"MOE_FUSE_TAIL", "fuse_tail"},
+                                               {"MOE_SEDN_FUSE", "sedn_fuse"}, {"MOE_POOL_FUSE", "pool_fuse"}, {"MOE_DBG", "dbg"}, {"MOE_TRACE_KEY", "trace_key"},
+                                               {"MOE_TILES_PER_BATCH", "tiles_per_batch"}, {"MOE_MAX_GROUPS", "max_groups"}};
+        for (const auto& nv : names)
+            if (const char* e = getenv(nv[0])) (void)set(nv[1], e);
+        if (const char* e = getenv("MOE_EXACT_BLOCKS")) exact_blocks_env = atoi(e);
+        arsb_trace = getenv("MOE_ARSB_TRACE") != nullptr;
+    }
+};
+
 struct moe_net {
     int arch = 0, scale = 1;
+    NetOptions opt;
     int C = 64;                  // real channel count (48 for NetDN / lite); tensors are padded to 64
     int stages = 1, r = 2;       // upsampler stages and their shuffle factor
     std::vector<Param> params;
@@ -103,6 +167,10 @@ struct moe_net {
     struct ProfRec { hipEvent_t e0 = nullptr, e1 = nullptr; int key = 0; double flops = 0; };
     std::vector<ProfRec> prof_ev;                // event pairs, reused across steps
     size_t prof_used = 0;
+    // moe_net_forward's host offset tables: a ring of pinned host slots + device slots, copied asynchronously on the launch stream
+    struct OffSlot { long long* host = nullptr; long long* dev = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool used = false; };
+    OffSlot off_ring[4];
+    int off_next = 0;
     // debug taps
     bool debug = false;
     struct Tap { float* dev = nullptr; int64_t shape[4] = {0, 0, 0, 0}; };
@@ -482,12 +550,6 @@ static int build_device_weights(moe_net& n, int precision)
 // =====================================================================================================
 namespace {
 
-static int conv_impl()   // MOE_CONV_IMPL = sp (default: conv3x3_sp.hip for the 3x3 / 64-channel layers) | v1 (the generic kernel everywhere; debugging)
-{
-    static const int impl = [] { const char* e = getenv("MOE_CONV_IMPL"); return (e && !strcmp(e, "v1")) ? 0 : 2; }();
-    return impl;
-}
-
 struct Fwd {
     moe_net& n;
     hipStream_t s;
@@ -529,9 +591,9 @@ struct Fwd {
 
     // MIXED: which fused-tail launches also split the activation operand.  The R branch (trunk -> upsampler -> tail) carries the larger
     // share of the remaining error (emulation: r.tail activations 3.8e-4 vs u.tail 1.3e-4 on noise); MOE_TAIL_SPLIT = 0 | r (default) | ru
-    static bool tail_split_for(const std::string& key)
+    bool tail_split_for(const std::string& key) const
     {
-        static const int mode = [] { const char* e = getenv("MOE_TAIL_SPLIT"); return !e ? 1 : (!strcmp(e, "0") ? 0 : (!strcmp(e, "ru") ? 2 : 1)); }();
+        const int mode = n.opt.tail_split;
         return mode == 2 || (mode == 1 && key.compare(0, 8, "convt_R1") == 0);
     }
 
@@ -598,7 +660,7 @@ struct Fwd {
         if (G > items) G = (int)items;
         a.G = G;
         a.slope = L.slope; a.scale = L.scale;
-        static const int dbg = [] { const char* e = getenv("MOE_DBG"); return e ? atoi(e) : 0; }();
+        const int dbg = n.opt.dbg;
         a.dbg = dbg;
         a.tail_w = tail_w; a.tplanes = tplanes;
         a.tail_split = (tplanes && mixed && tail_split_for(key)) ? 1 : 0;
@@ -606,14 +668,13 @@ struct Fwd {
         if (pool_out && !x3 && L.r == 1 && L.nchunks == 1 && !res) { a.pool = pool_out; a.pool_slabs = pool_slabs; }      // conv3x3_rw's pooled epilogue (SEDN rblock.2)
         // 3x3 / 64-input-channel layers with shared weights run on the software-pipelined kernel (conv3x3_sp.hip); everything else
         // (1x1 convs, SEDN's per-plane `trans`, epilogues that kernel does not compile, MOE_CONV_IMPL=v1) on the generic one
-        const bool fast = L.taps == 9 && L.nseg == 1 && !L.per_plane && conv_impl() == 2;
+        const bool fast = L.taps == 9 && L.nseg == 1 && !L.per_plane && n.opt.conv_impl == 2;
         if (tplanes && !(fast && !x3)) return false;
         bool fused_ok = true;
         // PReLU-only epilogues (first upsampler stage of Net4x, SEDN's rblock convs) run on the register-resident-weights kernel
         // (conv3x3_rw.hip: 6 % faster there); its fused-tail variant is 4 % slower than conv3x3_sp's and only used with MOE_SP_IMPL=rw;
         // MOE_SP_IMPL=sp: everything on conv3x3_sp (A/B)
-        const char* const sp_impl = getenv("MOE_SP_IMPL");          // (read per call: the parity tests switch forms in-process)
-        const int rw_mode = !sp_impl ? 1 : !strcmp(sp_impl, "rw") ? 2 : !strcmp(sp_impl, "sp") ? 0 : 1;
+        const int rw_mode = n.opt.sp_impl;
         auto launch = [&](const ConvArgs& ca) {
             if (fast && rw_mode && (rw_mode == 2 || !ca.tplanes) && launch_conv3x3_rw(ca, s)) { pool_done = ca.pool != nullptr; return; }
             if (fast && launch_conv3x3_sp(ca, s)) return;
@@ -622,9 +683,8 @@ struct Fwd {
         };
         // lite's 1x1 convs (conv_input2, the upsampler stages with or without the folded 48->1 tail): the HBM-bound kernel of conv1x1.hip,
         // in fp16 or with split operands; MOE_CONV1X1=0 keeps them on the generic kernel (A/B)
-        const char* const c1env = getenv("MOE_CONV1X1");
-        const bool c1 = !(c1env && !strcmp(c1env, "0"));
-        if (c1 && L.taps == 1 && L.nseg == 1 && !L.per_plane && !res && L.scale == 1.f && !tplanes && conv_impl() == 2 && (!x3 || (in.lo && L.has_x3))) {
+        const bool c1 = n.opt.conv1x1;
+        if (c1 && L.taps == 1 && L.nseg == 1 && !L.per_plane && !res && L.scale == 1.f && !tplanes && n.opt.conv_impl == 2 && (!x3 || (in.lo && L.has_x3))) {
             Conv1x1Args q{};
             q.in_hi = in.hi; q.in_lo = x3 ? in.lo : nullptr; q.out_hi = out.hi; q.out_lo = x3 ? out.lo : nullptr;
             q.w_hi = blob<half_t>(L.w_hi); q.w_lo = x3 ? blob<half_t>(L.w_lo) : nullptr; q.bias = a.bias;
@@ -635,8 +695,7 @@ struct Fwd {
             prof_end(rec);
             if (ok) { if (tail1_out) tail1_parts = 1; return true; }
         }
-        static const std::string trace_key = [] { const char* e = getenv("MOE_TRACE_KEY"); return std::string(e ? e : "convt_R1.up1"); }();
-        if (!x3 && (dbg & 64) && fast && key == trace_key) {   // timing trace of one launch -> /tmp/moe_trace.bin
+        if (!x3 && (dbg & 64) && fast && key == n.opt.trace_key) {   // timing trace of one launch -> /tmp/moe_trace.bin
             unsigned long long* tr = nullptr;
             const size_t nb = 8 * 32 * 4 * 16 * 8;
             if (hipMalloc((void**)&tr, nb) == hipSuccess) {
@@ -675,8 +734,7 @@ struct Fwd {
             return true;
         }
         {   // 3x3 64->64 with both weight parts packed for it: all three products in ONE launch (conv64_x3.hip)
-            const char* e1 = getenv("MOE_X3_FUSE");
-            if (!(e1 && !strcmp(e1, "0")) && fast && L.w_arsb_lo && in.lo && out.lo && (!res || res->lo) && !tplanes && !L.has_bias) {
+            if (n.opt.x3_fuse && fast && L.w_arsb_lo && in.lo && out.lo && (!res || res->lo) && !tplanes && !L.has_bias) {
                 ConvX3Args q{};
                 q.in_hi = in.hi; q.in_lo = in.lo; q.out_hi = out.hi; q.out_lo = out.lo;
                 q.res_hi = res ? res->hi : nullptr; q.res_lo = res ? res->lo : nullptr;
@@ -739,7 +797,7 @@ int exact_blocks_of(const moe_net& n)
     // of uniform-noise tiles: Net4x 7.6e-4 / 6.2e-4 / 5.1e-4 with 0 / 1 / 3 blocks; Net2x (whose trunk is 61 % of the net and whose
     // output swing is three times larger) 1.3e-3 / 9.1e-4 / 6.2e-4 / 3.7e-4 with 0 / 1 / 3 / 6; NetDN 7.8e-4 / 6.5e-4 / 5.0e-4 with 0 / 1 / 3
     if (n.exact_blocks >= 0) return n.exact_blocks > 6 ? 6 : n.exact_blocks;
-    static const int env = [] { const char* e = getenv("MOE_EXACT_BLOCKS"); return e ? atoi(e) : -1; }();
+    const int env = n.opt.exact_blocks_env;
     if (env >= 0) return env > 6 ? 6 : env;
     switch (n.arch) {
         case MOE_ARCH_NET2X: return 6;
@@ -772,8 +830,7 @@ constexpr long long kSpRange = (1ll << 32) - (1ll << 16);
 
 bool can_fuse_tail(const moe_net& n, const Fwd& f, int B, int h, int w)
 {
-    static const bool off = [] { const char* e = getenv("MOE_FUSE_TAIL"); return e && !strcmp(e, "0"); }();
-    if (off || f.x3 || f.direct || n.debug || conv_impl() != 2 || n.stages < 1) return false;
+    if (!n.opt.fuse_tail || f.x3 || f.direct || n.debug || n.opt.conv_impl != 2 || n.stages < 1) return false;
     if (!(n.arch == MOE_ARCH_NET2X || n.arch == MOE_ARCH_NET3X || n.arch == MOE_ARCH_NET4X)) return false;
     long long sc = 1;
     for (int s = 0; s < n.stages; ++s) sc *= n.r;
@@ -834,6 +891,8 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         Act A = f.act(P, 64, mixed), Bb = f.act(P, 64, mixed), Cc = f.act(P, 64, mixed);
         stem(A);
         f.tap("stem", A, h, w, 64, n.C);
+        if (mixed && n.opt.conv_impl != 2)
+            return fail(MOE_EINVAL, "precision 'mixed' runs on the fast 3x3 kernels only: conv_impl=v1 (MOE_CONV_IMPL=v1) is a debugging switch for 'fp16' / 'fp16x3'");
         auto trunk_conv = [&](const std::string& key, const Act& in, const Act& out, const Act* res, bool exact) {
             if (!f.conv(key, in, out, res, h, w, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, exact))
                 return fail(MOE_EINVAL, "layer %s: %d planes of %dx%d exceed the conv kernel's addressing range (use smaller tiles)", key.c_str(), B, h, w);
@@ -843,8 +902,7 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         f.tap("input2", Bb, h, w, 64, n.C);
         // single-pass ARSBs run as ONE kernel (arsb_fused.hip: conv_1's output never leaves the CU) that streams cur -> oth;
         // split-operand / debug blocks use the two-launch form, conv_1 into `oth`, conv_2 back onto `cur`
-        const char* fuse_env = getenv("MOE_ARSB_FUSE");          // (read per forward: the tests switch it inside one process)
-        const bool arsb_fuse = !(fuse_env && !strcmp(fuse_env, "0")) && !f.x3 && !f.direct && conv_impl() == 2;
+        const bool arsb_fuse = n.opt.arsb_fuse && !f.x3 && !f.direct && n.opt.conv_impl == 2;
         Act cur = Bb, oth = Cc;
         for (int i = 1; i <= 6; ++i) {
             const bool ex = mixed && i <= nx;
@@ -858,17 +916,11 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
                     q.x_hi = cur.hi; q.x_lo = mixed ? cur.lo : nullptr; q.y_hi = oth.hi; q.y_lo = mixed ? oth.lo : nullptr;
                     q.w1 = f.blob<half_t>(L1.w_arsb); q.w2 = f.blob<half_t>(L2.w_arsb); q.zero = f.small<half_t>("zero");
                     q.slope = L1.slope; q.B = B; q.H = h; q.W = w;
-                    static const bool trace = getenv("MOE_ARSB_TRACE") != nullptr;   // with a -DARSB_TRACE build: stamps of ARSB 3 -> /tmp/arsb_trace.bin
+                    const bool trace = n.opt.arsb_trace;   // MOE_ARSB_TRACE with a -DARSB_TRACE build: stamps of ARSB 3 -> /tmp/arsb_trace.bin
                     const size_t tb = 8 * 16 * 4 * 40 * 8;
                     if (trace && i == 3 && hipMalloc((void**)&q.trace, tb) == hipSuccess) (void)hipMemsetAsync(q.trace, 0, tb, s);
                     const int rec = f.prof_begin("arsb" + std::to_string(i), 2.0 * 2.0 * (double)B * h * w * L1.cout * L1.cin * 9);
-                    const char* impl = getenv("MOE_ARSB_IMPL");      // v1 (default): arsb_fused.hip | pc: conv_1 / conv_2 on different waves (arsb_pc.hip, experiment)
-                    if (!impl || strcmp(impl, "pc")) done = launch_arsb_fused(q, n.max_groups, s);
-                    else {
-                        ArsbArgs q2 = q;
-                        q2.w1 = f.blob<half_t>(L1.w_hi); q2.w2 = f.blob<half_t>(L2.w_hi);
-                        done = launch_arsb_pc(q2, n.max_groups, s);
-                    }
+                    done = launch_arsb_fused(q, n.max_groups, s);
                     f.prof_end(rec);
                     if (q.trace) {
                         std::vector<unsigned long long> host(tb / 8);
@@ -940,14 +992,13 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         stem(A);
         f.tap("stem", A, h, w, 64, 64);
         // fused block tail (see sedn_fuse in misc_kernels.hip): single-pass precision, fast kernel, planes fit the per-XCD split
-        static const bool fuse_env = [] { const char* e = getenv("MOE_SEDN_FUSE"); return !(e && !strcmp(e, "0")); }();
-        const bool sfuse = fuse_env && !f.x3 && !f.direct && !n.debug && conv_impl() == 2 && B <= n.max_groups &&
+        const bool sfuse = n.opt.sedn_fuse && !f.x3 && !f.direct && !n.debug && n.opt.conv_impl == 2 && B <= n.max_groups &&
                            2ll * B * h * w * 64 < (1ll << 32) - 8192;
         float* xpart = (float*)f.ar.take((size_t)B * nslab * 5 * 64 * 4);
         // the channel totals of rblock.2's output come out of that conv's epilogue (conv3x3_rw EPI 4), sedn_xsum then only visits the border
         const int pslabs = 2 * n.max_groups;
         float* xpool = (float*)f.ar.take((size_t)B * pslabs * 64 * 4);
-        static const bool spool = [] { const char* e = getenv("MOE_POOL_FUSE"); return !(e && !strcmp(e, "0")); }();
+        const bool spool = n.opt.pool_fuse;
         float* fgate = (float*)f.ar.take((size_t)B * 256 * 4);
         half_t* weff = (half_t*)f.ar.take((size_t)B * 72 * 512 * 2);
         for (int b = 0; b < 16; ++b) {
@@ -1013,7 +1064,7 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         // the pooled sums of conv_2's output come out of conv64_x3's epilogue, one slab per workgroup (fp16x3, the default of lite); in the
         // other modes a separate pass (pool_partial) forms nslab slabs per plane
         const int pslabs = n.max_groups;
-        static const bool poolfuse = [] { const char* e = getenv("MOE_POOL_FUSE"); return !(e && !strcmp(e, "0")); }();
+        const bool poolfuse = n.opt.pool_fuse;
         float* partial = (float*)f.ar.take((size_t)B * std::max(nslab, pslabs) * 64 * 4);
         float* gate = (float*)f.ar.take((size_t)B * 64 * 4);
         stem(A);
@@ -1046,8 +1097,7 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         int H = h, W = w;
         // The last upsampler stage and the 48->1 tail conv run as one kernel (the 64-channel HR tensor, 128 B per HR pixel written
         // and read back per branch, never exists): the conv's epilogue dots its fp32 activations with the tail weights.
-        static const bool nofuse1 = [] { const char* e = getenv("MOE_FUSE_TAIL"); return e && !strcmp(e, "0"); }();
-        const bool fuse1 = !nofuse1 && !f.direct && !n.debug && n.stages >= 1;
+        const bool fuse1 = n.opt.fuse_tail && !f.direct && !n.debug && n.stages >= 1;
         float* part[2] = {nullptr, nullptr};
         for (int br = 0; br < 2; ++br) {
             Act cur = br == 0 ? Bb : A;
@@ -1238,6 +1288,7 @@ int moe_net_create(int arch, int scale, moe_net** out)
     if (!out) return fail(MOE_EINVAL, "moe_net_create: out is NULL");
     auto n = std::make_unique<moe_net>();
     n->arch = arch;
+    n->opt.from_env();
     switch (arch) {
         case MOE_ARCH_NET2X: n->scale = 2; n->stages = 1; n->r = 2; break;
         case MOE_ARCH_NET3X: n->scale = 3; n->stages = 1; n->r = 3; break;
@@ -1265,6 +1316,11 @@ void moe_net_destroy(moe_net* n)
     if (n->ws) (void)hipFree(n->ws);
     for (auto& t : n->taps) if (t.second.dev) (void)hipFree(t.second.dev);
     for (auto& ev : n->prof_ev) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); }
+    for (auto& sl : n->off_ring) {
+        if (sl.host) (void)hipHostFree(sl.host);
+        if (sl.dev) (void)hipFree(sl.dev);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
     delete n;
 }
 
@@ -1317,7 +1373,7 @@ int moe_net_finalize(moe_net* n, int device, int precision)
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(conv_mfma_init());
     n->max_groups = conv_mfma_max_groups();
-    if (const char* e = getenv("MOE_MAX_GROUPS")) { const int v = atoi(e); if (v > 0) n->max_groups = v; }
+    if (n->opt.max_groups > 0) n->max_groups = n->opt.max_groups;
     n->device = device;
     n->precision = precision;
     int rc = build_device_weights(*n, precision);
@@ -1340,18 +1396,55 @@ int moe_net_forward(moe_net* n, const void* x, int x_dtype, int B, int h, int w,
     hipStream_t s = (hipStream_t)stream;
     long long* xo = nullptr;
     long long* yo = nullptr;
-    void* tmp = nullptr;
-    if (x_off || y_off) {   // slow path: blocking upload of the offset tables
+    if (x_off || y_off) {
+        // The host tables ride to the device on the launch stream: a slot of a small ring (pinned host copy + device copy) per call,
+        // reused once the event recorded behind its copy has fired -- no hipMalloc, no blocking copy, no stream synchronisation.
         HIP_TRY(hipSetDevice(n->device >= 0 ? n->device : 0));
-        HIP_TRY(hipMalloc(&tmp, (size_t)B * 16));
-        if (x_off) { xo = (long long*)tmp; HIP_TRY(hipMemcpy(xo, x_off, (size_t)B * 8, hipMemcpyHostToDevice)); }
-        if (y_off) { yo = (long long*)tmp + B; HIP_TRY(hipMemcpy(yo, y_off, (size_t)B * 8, hipMemcpyHostToDevice)); }
+        moe_net::OffSlot& sl = n->off_ring[n->off_next];
+        n->off_next = (n->off_next + 1) % 4;
+        if (sl.used) HIP_TRY(hipEventSynchronize(sl.done));          // (only when four such forwards are still in flight)
+        const size_t need = (size_t)B * 2;
+        if (need > sl.cap) {
+            if (sl.host) { (void)hipHostFree(sl.host); sl.host = nullptr; }
+            if (sl.dev) { (void)hipFree(sl.dev); sl.dev = nullptr; }
+            sl.cap = 0;
+            const size_t cap = std::max<size_t>(need, 256);
+            HIP_TRY(hipHostMalloc((void**)&sl.host, cap * 8, hipHostMallocDefault));
+            HIP_TRY(hipMalloc((void**)&sl.dev, cap * 8));
+            sl.cap = cap;
+        }
+        if (!sl.done) HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        for (int i = 0; i < B; ++i) { sl.host[i] = x_off ? x_off[i] : 0; sl.host[B + i] = y_off ? y_off[i] : 0; }
+        HIP_TRY(hipMemcpyAsync(sl.dev, sl.host, need * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipEventRecord(sl.done, s));
+        sl.used = true;
+        if (x_off) xo = sl.dev;
+        if (y_off) yo = sl.dev + B;
     }
     bool mult8 = true;
     if (y_off) for (int i = 0; i < B; ++i) mult8 = mult8 && (y_off[i] % 8 == 0);
-    int rc = forward_dev(*n, x, x_dtype, B, h, w, sB, sH, sW, xo, y, y_dtype, yo, s, mult8);
-    if (tmp) { (void)hipStreamSynchronize(s); (void)hipFree(tmp); }
-    return rc;
+    return forward_dev(*n, x, x_dtype, B, h, w, sB, sH, sW, xo, y, y_dtype, yo, s, mult8);
+}
+
+int moe_net_set_option(moe_net* n, const char* key, const char* value)
+{
+    if (!n || !key || !value) return fail(MOE_EINVAL, "moe_net_set_option: NULL argument");
+    if (!n->opt.set(key, value)) return fail(MOE_EINVAL, "moe_net_set_option: unknown option or value \"%s\" = \"%s\"", key, value);
+    if (!strcmp(key, "max_groups") && n->finalized) n->max_groups = n->opt.max_groups > 0 ? n->opt.max_groups : conv_mfma_max_groups();
+    return MOE_OK;
+}
+
+int moe_device_info(int device, int64_t info[8])
+{
+    if (!info) return fail(MOE_EINVAL, "moe_device_info: NULL argument");
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, device));
+    int wall = 0;
+    (void)hipDeviceGetAttribute(&wall, hipDeviceAttributeWallClockRate, device);
+    const int64_t v[8] = {p.multiProcessorCount, p.clockRate, p.memoryClockRate, p.memoryBusWidth, p.l2CacheSize, (int64_t)p.totalGlobalMem, wall,
+                          (int64_t)p.maxSharedMemoryPerMultiProcessor};
+    memcpy(info, v, sizeof v);
+    return MOE_OK;
 }
 
 int moe_net_set_profile(moe_net* n, const char* layer_substrings)
@@ -1526,6 +1619,21 @@ int moe_stitch(const moe_plan* p, int device, const float* tiles_dev, const int6
     return MOE_OK;
 }
 
+int moe_stitch_dev(const moe_plan* p, int device, const float* tiles_dev, const int64_t* tile_off_dev, int C, void* out, int out_dtype, void* stream)
+{
+    if (!p || !tiles_dev || !tile_off_dev || !out || C < 1) return fail(MOE_EINVAL, "moe_stitch_dev: bad argument");
+    HIP_TRY(hipSetDevice(device));
+    PlanDeviceCache* d = nullptr;
+    int rc = plan_device_tables(p->p, device, C, 0, 0, 0, 0, 1, &d);
+    if (rc) return rc;
+    StitchArgs a{};
+    fill_stitch(p->p, *d, a, tiles_dev, (const long long*)tile_off_dev, C, out, out_dtype);
+    launch_stitch(a, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MOE_EHIP, "stitch launch failed: %s", hipGetErrorString(e));
+    return MOE_OK;
+}
+
 int moe_run_plan_ex(moe_net* n, const moe_plan* pl, const void* img, int img_dtype, int64_t sC, int64_t sH, int64_t sW,
                     void* out, int out_dtype, int max_tiles, float* pool, int shard_index, int shard_count, int do_stitch, void* stream)
 {
@@ -1551,8 +1659,7 @@ int moe_run_plan_ex(moe_net* n, const moe_plan* pl, const void* img, int img_dty
         pool = p.pool;
     }
     if (max_tiles <= 0) {
-        max_tiles = 8;      // (tiles of 256^2 pixels per launch set; 8 measured 1.8 % faster than 4 on the 1080p x4 frame: fewer pipeline fills per pixel)
-        if (const char* e = getenv("MOE_TILES_PER_BATCH")) { const int v = atoi(e); if (v > 0) max_tiles = v; }
+        max_tiles = n->opt.tiles_per_batch > 0 ? n->opt.tiles_per_batch : 8;      // (tiles of 256^2 pixels per launch set; 8 measured 1.8 % faster than 4 on the 1080p x4 frame: fewer pipeline fills per pixel)
     }
     for (size_t gi = 0; gi < p.groups.size(); ++gi) {
         const auto& g = p.groups[gi];
@@ -1635,8 +1742,7 @@ int moe_run_plan_tiles(moe_net* n, const moe_plan* pl, const void* imgs, int img
         d->n_frames = n_frames; d->tile_dst.assign(tile_dst, tile_dst + nt * n_frames);
     }
     if (max_tiles <= 0) {
-        max_tiles = 8;      // (tiles of 256^2 pixels per launch set; 8 measured 1.8 % faster than 4 on the 1080p x4 frame: fewer pipeline fills per pixel)
-        if (const char* e = getenv("MOE_TILES_PER_BATCH")) { const int v = atoi(e); if (v > 0) max_tiles = v; }
+        max_tiles = n->opt.tiles_per_batch > 0 ? n->opt.tiles_per_batch : 8;      // (tiles of 256^2 pixels per launch set; 8 measured 1.8 % faster than 4 on the 1080p x4 frame: fewer pipeline fills per pixel)
     }
     for (size_t gi = 0; gi < p.groups.size(); ++gi) {
         const auto& g = p.groups[gi];

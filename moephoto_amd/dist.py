@@ -77,6 +77,15 @@ class TileExchange(object):
             assert (self.stitch_off[f] >= 0).all()
         self._tile_dst_c = (ctypes.c_int64 * self.tile_dst.size)(*self.tile_dst.reshape(-1).tolist())
         self._stitch_c = {f: (ctypes.c_int64 * nt)(*v.tolist()) for f, v in self.stitch_off.items()}
+        self._stitch_dev = None        # one device blob [len(mine)][n_tiles] of the tables above, uploaded on first use (stitch_tables)
+
+    def stitch_tables(self, device):
+        """{frame: device pointer of its n_tiles int64 stitch offsets}: ONE upload per layout, whatever the number of frames
+        this rank stitches (moe_stitch_dev reads the table in place)."""
+        if self._stitch_dev is None or self._stitch_dev[0].device != device:
+            blob = torch.from_numpy(np.stack([self.stitch_off[f] for f in self.mine]) if self.mine else np.zeros((1, self.n_tiles), np.int64)).to(device)
+            self._stitch_dev = (blob, {f: blob[i].data_ptr() for i, f in enumerate(self.mine)})
+        return self._stitch_dev[1]
 
     # ---- index arithmetic ----------------------------------------------------------------------------
     def owner(self, frame, tile):
@@ -148,9 +157,10 @@ def _agreed_plan(opt, shape, group, device):
     from .config import config
     from .imageProcess import EngineModule, prepare
     key = ('dist',) + tuple(int(v) for v in shape[-3:])
-    plan = opt._plans.get(key)
+    plans = opt.__dict__.setdefault('_dist_plans', {})      # kept apart from doCrop's LRU of plans (imageProcess._plan_for): an evicted plan
+    plan = plans.get(key)                                   # on ONE rank would leave that rank alone in the collectives below
     if plan is not None:
-        return plan[0]
+        return plan
     free = config.calcFreeMem()
     if dist.get_world_size(group) > 1:
         t = torch.tensor([float(free)], dtype=torch.float64, device=device if dist.get_backend(group) != 'gloo' else None)
@@ -160,7 +170,7 @@ def _agreed_plan(opt, shape, group, device):
     if isinstance(model, EngineModule):
         free = min(free, model.max_tile_pixels() * key[1] * key[1] / opt.ramCoef)
     it = prepare(key[1:], free, opt, opt.padding, opt.scale, opt.align, opt.cropsize)[0]
-    opt._plans[key] = [it.plan, 0]
+    plans[key] = it.plan
     return it.plan
 
 
@@ -176,8 +186,10 @@ def run_frames(opt, frames, group=None, out_dtype=None, max_tiles_per_batch=0):
     plan = _agreed_plan(opt, x0.shape, group, dev)
     C = x0.shape[0]
     cache = opt.__dict__.setdefault('_exchanges', {})
-    ck = (id(plan), len(frames), rank, world, C)
+    ck = (tuple(int(v) for v in x0.shape[-3:]), len(frames), rank, world, C)
     ent = cache.get(ck)
+    if ent is not None and ent[0] is not plan:               # the entry owns its plan: a layout is only ever used with the plan it was built from
+        ent = None
     if ent is None:
         off = plan.tile_offsets(C) + [plan.pool_elems(C)]
         ex = TileExchange([off[k + 1] - off[k] for k in range(plan.n_tiles)], len(frames), rank, world, group)
@@ -189,10 +201,10 @@ def run_frames(opt, frames, group=None, out_dtype=None, max_tiles_per_batch=0):
             if int(lo.item()) != int(hi.item()):
                 raise RuntimeError('run_frames: the ranks derived different tile plans (pass an explicit cropsize)')
         buf = torch.empty(ex.total_elems, dtype=torch.float32, device=dev)
-        ent = cache[ck] = (ex, buf)
+        ent = cache[ck] = (plan, ex, buf)
         while len(cache) > 4:
             cache.pop(next(iter(cache)))
-    ex, buf = ent
+    _, ex, buf = ent
     L = _lib.lib()
     stream = torch.cuda.current_stream(dev).cuda_stream
     padded = [plan.padImage(x) for x in frames]
@@ -214,8 +226,9 @@ def run_frames(opt, frames, group=None, out_dtype=None, max_tiles_per_batch=0):
     mine = ex.exchange(buf)
     out = {}
     odt = out_dtype if out_dtype is not None else x0.dtype
+    tables = ex.stitch_tables(dev)
     for f in mine:
         y = torch.empty((C, plan.outH, plan.outW), dtype=odt, device=dev)
-        _lib.check(L.moe_stitch(plan._h, dev.index or 0, buf.data_ptr(), ex._stitch_c[f], C, y.data_ptr(), _DT[odt], stream))
+        _lib.check(L.moe_stitch_dev(plan._h, dev.index or 0, buf.data_ptr(), ctypes.c_void_p(tables[f]), C, y.data_ptr(), _DT[odt], stream))
         out[f] = y
     return out

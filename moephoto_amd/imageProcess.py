@@ -201,16 +201,22 @@ def _plan_for(opt, shape):
     key = tuple(int(v) for v in shape[-3:])
     ent = opt._plans.pop(key, None)
     if ent is None or (opt.cropsize <= 0 and ent[1] > 28):
-        try:
-            freeMem = config.calcFreeMem()
-        except Exception:
-            raise MemoryError('Can not calculate free memory.')
         model = opt.modelCached
-        if isinstance(model, EngineModule):
-            # the planner's pixel budget is ram * ramCoef / C^2 (solveRam with fixChannel = 0): keep it within the largest
-            # tile the convolution kernels address, however much memory is free (288 GB would otherwise plan whole 8K images)
-            freeMem = min(freeMem, model.max_tile_pixels() * key[0] * key[0] / opt.ramCoef)
-        it, padImage, unpad, outShape, bl = prepare(key, freeMem, opt, opt.padding, opt.scale, opt.align, opt.cropsize)
+
+        def plan_with(emptyCache):
+            try:
+                freeMem = config.calcFreeMem(emptyCache=emptyCache)
+            except Exception:
+                raise MemoryError('Can not calculate free memory.')
+            if isinstance(model, EngineModule):
+                # the planner's pixel budget is ram * ramCoef / C^2 (solveRam with fixChannel = 0): keep it within the largest
+                # tile the convolution kernels address, however much memory is free (288 GB would otherwise plan whole 8K images)
+                freeMem = min(freeMem, model.max_tile_pixels() * key[0] * key[0] / opt.ramCoef)
+            return prepare(key, freeMem, opt, opt.padding, opt.scale, opt.align, opt.cropsize)
+        try:
+            it, padImage, unpad, outShape, bl = plan_with(False)
+        except MemoryError:          # the smallest tile did not fit: hand torch's cached blocks back to the driver and ask again, once
+            it, padImage, unpad, outShape, bl = plan_with(True)
         ent = [it.plan, 0]
         while len(opt._plans) >= PLAN_CACHE:       # each plan owns a device tile pool of ~1.1x its output image: keep a few, drop the
             opt._plans.pop(next(iter(opt._plans)))   # least recently used (the reference keeps exactly one, re-planning on a shape change)
@@ -248,8 +254,15 @@ def doCrop(opt, x, *args, **_):
     out = xp.new_empty((C, plan.outH, plan.outW))
     sC, sH, sW = xp.stride()
     stream = torch.cuda.current_stream(x.device).cuda_stream
-    _lib.check(_lib.lib().moe_run_plan(model._h, plan._h, xp.data_ptr(), _DT[xp.dtype], sC, sH, sW,
-                                       out.data_ptr(), _DT[out.dtype], int(config.tilesPerBatch), stream))
+
+    def run():
+        _lib.check(_lib.lib().moe_run_plan(model._h, plan._h, xp.data_ptr(), _DT[xp.dtype], sC, sH, sW,
+                                           out.data_ptr(), _DT[out.dtype], int(config.tilesPerBatch), stream))
+    try:
+        run()
+    except MemoryError:              # the engine's workspace / tile pool is hipMalloc'ed beside torch's caching allocator: release the
+        torch.cuda.empty_cache()     # cache and try once more before reporting "does not fit" (python/imageProcess.py:58-59)
+        run()
     # the engine reads xp asynchronously: keep it alive until the stream has consumed it
     xp.record_stream(torch.cuda.current_stream(x.device))
     return out

@@ -174,6 +174,12 @@ class EngineModule(object):
         _lib.check(_lib.lib().moe_net_set_exact_blocks(self._h, int(blocks)))
         return self
 
+    def set_option(self, key, value):
+        """A kernel-form switch of this net (moe_net_set_option): e.g. ('sp_impl', 'rw'), ('arsb_fuse', 0).  Takes effect at the next forward."""
+        v = value if isinstance(value, str) else str(int(value))
+        _lib.check(_lib.lib().moe_net_set_option(self._h, str(key).encode(), v.encode()))
+        return self
+
     def _finalize(self):
         key = (self._device.index, self.resolved_precision())
         if self._finalized_key == key:

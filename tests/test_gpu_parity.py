@@ -662,10 +662,10 @@ def test_rccl_path_world1(dev):
 
 def test_fused_arsb_matches_two_launch_form(dev):
     """The fused ARSB kernel (conv_1 -> PReLU -> conv_2 -> + x in one launch, weights in registers) against the two-launch form of
-    the same arithmetic (MOE_ARSB_FUSE=0) and the oracle: ragged shapes (patches are 8 x 30 outputs), 48- and 64-channel nets,
+    the same arithmetic (option arsb_fuse = 0) and the oracle: ragged shapes (patches are 8 x 30 outputs), 48- and 64-channel nets,
     with and without the hi+lo stream."""
     cases = [('a2', (3, 8, 16)), ('a2', (3, 24, 40)), ('a2', (2, 40, 264)), ('a2', (3, 9, 35)), ('a2', (5, 88, 64)), ('dn_lite5', (3, 16, 64)), ('dn_lite5', (3, 33, 31))]
-    old = os.environ.get('MOE_ARSB_FUSE')
+    touched = []
     try:
         for key, shape in cases:
             arch = gd.MODELS[key][0]
@@ -676,10 +676,9 @@ def test_fused_arsb_matches_two_launch_form(dev):
                 xd = torch.from_numpy(x).to(dev)
                 for prec, nb in (('fp16', -1), ('mixed', 0), ('mixed', -1)):
                     m = module_for(key, prec).set_exact_blocks(nb)
-                    os.environ['MOE_ARSB_FUSE'] = '0'
-                    y0 = m(xd)[-1].cpu().numpy()
-                    os.environ['MOE_ARSB_FUSE'] = '1'
-                    y1 = m(xd)[-1].cpu().numpy()
+                    touched.append(m)
+                    y0 = m.set_option('arsb_fuse', 0)(xd)[-1].cpu().numpy()
+                    y1 = m.set_option('arsb_fuse', 1)(xd)[-1].cpu().numpy()
                     m.set_exact_blocks(-1)
                     # same operands, same rounding points; only the fp32 summation order inside a conv differs, which flips an fp16 rounding
                     # of conv_1's output now and then -- and, in 'fp16' mode, of the stream itself (one ulp of a value near 1 is 5e-4,
@@ -695,10 +694,8 @@ def test_fused_arsb_matches_two_launch_form(dev):
                     if prec == 'mixed' and nb == -1:
                         assert np.abs(y1 - want).max() <= TOL, (key, shape, kind, float(np.abs(y1 - want).max()))
     finally:
-        if old is None:
-            os.environ.pop('MOE_ARSB_FUSE', None)
-        else:
-            os.environ['MOE_ARSB_FUSE'] = old
+        for m in touched:
+            m.set_option('arsb_fuse', 1).set_exact_blocks(-1)
 
 
 RESIZE = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(G, 'resize', '*.npz')) if 'scale_factors' not in p)
@@ -766,29 +763,21 @@ def test_p2_through_plugin_table(dev):
 
 def test_kernel_forms_agree(dev):
     """The alternative forms of the hot kernels, switched in-process: the register-resident-weights upsampler conv (conv3x3_rw.hip; default
-    for PReLU epilogues, MOE_SP_IMPL=rw also for the fused tail, =sp not at all) and lite's 1x1 kernel (conv1x1.hip, MOE_CONV1X1=0:
+    for PReLU epilogues, option sp_impl = rw also for the fused tail, = sp not at all) and lite's 1x1 kernel (conv1x1.hip, option conv1x1 = 0:
     generic kernel).  Forms of one layer use the same operands and rounding points: outputs agree to fp32 summation order, and every
     form is inside the tolerance of its arithmetic against the oracle."""
-    def with_env(name, value, fn):
-        old = os.environ.get(name)
+    def with_opt(m, name, value, default):
         try:
-            if value is None:
-                os.environ.pop(name, None)
-            else:
-                os.environ[name] = value
-            return fn()
+            return m.set_option(name, value)(xd)[-1].cpu().numpy()
         finally:
-            if old is None:
-                os.environ.pop(name, None)
-            else:
-                os.environ[name] = old
+            m.set_option(name, default)
     for key, shape, prec in (('a4', (3, 24, 72), 'mixed'), ('a4', (2, 41, 35), 'fp16'), ('a3', (3, 16, 40), 'mixed'), ('a2', (1, 9, 33), 'mixed')):
         arch, sd = gd.MODELS[key][0], gd.state_dict_for(key, load_state_dict_file)
         x = gd.natural_image(23, shape)[:, None]
         want = onets.forward(arch, sd, x).numpy()
         xd = torch.from_numpy(x).to(dev)
         m = module_for(key, prec)
-        ys = {impl: with_env('MOE_SP_IMPL', impl, lambda: m(xd)[-1].cpu().numpy()) for impl in (None, 'sp', 'rw')}
+        ys = {impl: with_opt(m, 'sp_impl', impl, 'auto') for impl in ('auto', 'sp', 'rw')}
         for impl, y in ys.items():
             assert np.abs(y - ys['sp']).max() <= 2.5e-4, (key, shape, prec, impl, float(np.abs(y - ys['sp']).max()))
             if prec == 'mixed':
@@ -800,8 +789,8 @@ def test_kernel_forms_agree(dev):
         xd = torch.from_numpy(x).to(dev)
         for prec in ('fp16x3', 'fp16'):
             m = module_for(key, prec)
-            y1 = with_env('MOE_CONV1X1', None, lambda: m(xd)[-1].cpu().numpy())
-            y0 = with_env('MOE_CONV1X1', '0', lambda: m(xd)[-1].cpu().numpy())
+            y1 = with_opt(m, 'conv1x1', 1, 1)
+            y0 = with_opt(m, 'conv1x1', 0, 1)
             assert np.abs(y1 - y0).max() <= (2e-5 if prec == 'fp16x3' else 1e-3), (key, prec, float(np.abs(y1 - y0).max()))
             if prec == 'fp16x3':
                 assert np.abs(y1 - want).max() <= 2e-5, (key, float(np.abs(y1 - want).max()))
@@ -809,9 +798,9 @@ def test_kernel_forms_agree(dev):
 
 def test_split_operand_conv_single_launch(dev):
     """conv64_x3.hip (the three split-operand products of a 3x3 64->64 layer in one launch, both weight parts in registers) against the
-    three-launch form (MOE_X3_FUSE=0) and the oracle: every epilogue (plain = conv_input2, PReLU = conv_1, residual = conv_2), ragged
+    three-launch form (option x3_fuse = 0) and the oracle: every epilogue (plain = conv_input2, PReLU = conv_1, residual = conv_2), ragged
     shapes, 48- and 64-channel nets.  With all six ARSBs split the trunk is ~fp32: the taps must agree with the oracle to ~1e-6."""
-    old = os.environ.get('MOE_X3_FUSE')
+    m = None
     try:
         for key, shape in (('a2', (3, 8, 16)), ('a2', (3, 24, 40)), ('a2', (2, 40, 264)), ('a2', (3, 9, 35)), ('dn_lite5', (3, 33, 31)), ('dn_lite5', (5, 88, 64))):
             arch = gd.MODELS[key][0]
@@ -823,8 +812,7 @@ def test_split_operand_conv_single_launch(dev):
             m = module_for(key, 'mixed').set_exact_blocks(6).set_debug(True)
             res = {}
             for fuse in ('0', '1'):
-                os.environ['MOE_X3_FUSE'] = fuse
-                y = m(xd)[-1].cpu().numpy()
+                y = m.set_option('x3_fuse', fuse)(xd)[-1].cpu().numpy()
                 res[fuse] = (y, {k: m.debug_tap(k) for k in ('input2', 'arsb1', 'arsb6')})
             m.set_debug(False).set_exact_blocks(-1)
             for k in ('input2', 'arsb1', 'arsb6'):
@@ -834,7 +822,5 @@ def test_split_operand_conv_single_launch(dev):
                 assert np.abs(res['1'][1][k] - res['0'][1][k]).max() <= 2e-6 * scale, (key, shape, k)
             assert np.abs(res['1'][0] - want).max() <= TOL
     finally:
-        if old is None:
-            os.environ.pop('MOE_X3_FUSE', None)
-        else:
-            os.environ['MOE_X3_FUSE'] = old
+        if m is not None:
+            m.set_option('x3_fuse', 1).set_debug(False).set_exact_blocks(-1)
