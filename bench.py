@@ -3,8 +3,9 @@
 256-px tiles with 5-px overlap: BASELINE.json configs[1]) on N MI355X GPUs of one node.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N ...                       (started plainly: re-executes itself under torch.distributed.run, one rank per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W          (the driver's form)
 
 A step = one pass of the hot path (doCrop: tile gather -> Net4x on the MFMA kernels -> stitch) over one batch
 of N frames that are already resident in HBM.  N = 1: one frame.  N > 1: the N frames' tiles are sharded
@@ -21,19 +22,32 @@ through the legacy-format file path.  Inputs: the headline is a seeded natural-i
 SURVEY 8(d) input (seed-0 uniform uint8 noise / 255) is timed and parity-checked as a second input (`inputs`).
 
 Extra objects on the JSON line:
-  roofline        the dominant kernel (3x3 64->256 implicit-GEMM conv at 2x resolution, 59.8 % of the FLOPs):
-                  algorithmic FLOPs / launch time from hipEvents recorded on the launch stream inside the timed steps
-  roofline_trunk  the same for the one-launch ARSBs with fp16 operands (two 64->64 implicit GEMMs, the shape the north star names)
-  sustained       a >= --sustain second leg after the timed steps (the part is power-capped: short bursts run faster)
-  cpu_baseline    the oracle (a port of the reference's PyTorch-CPU fp32 path, proven equal to it on the goldens) timed on
-                  this host with one socket's physical cores on a full tile row (8 tiles) + the ragged corner of the same
-                  frame, and on BASELINE config 1 (256x256, a2) in full; rank 0 only.  The same tiles are the parity gate:
-                  the worst max-abs error of the engine's tiles vs the oracle must be <= 1e-3 or the run exits non-zero.
+  roofline          the kernel group with the largest share of the frame among the ones bracketed by hipEvents on the launch stream
+                    (the two 3x3 64->256 implicit-GEMM convs at 2x resolution -- R and U branch are timed SEPARATELY, they run different
+                    epilogues -- and the one-launch ARSBs).  `achieved` / `frac` use ALGORITHMIC FLOPs (the frame's pixels,
+                    no tile overlap); `achieved_executed` / `frac_executed` count the overlapping tile pixels the kernels really compute.
+                    `peak` = compute units x 4 SIMDs x 1024 FLOP/clk x max engine clock, all read from the device (moe_device_info).
+                    `traffic` = HBM bytes per launch from the committed PMC passes of THIS command's launch shapes (profiles/pmc_bench.json).
+  roofline_kernels  every bracketed group, dominant first
+  clock             shader clock / package power sampled with rocm-smi during the sustained leg (the part is power-capped), and
+                    `frac_at_clock` = roofline.frac rescaled to the peak at the sampled clock
+  sustained         a >= --sustain second leg after the timed steps
+  dropin_loop       the reference's own per-tile loop (python/imageProcess.py:157-172: slice view -> model(x) -> torch blends ->
+                    slice assign) around the drop-in module, i.e. what a maintainer gets by swapping the class in runSR.mode_switch only
+  cpu_baseline      the oracle (a port of the reference's PyTorch-CPU fp32 path, proven equal to it on the goldens) timed on
+                    this host with one socket's physical cores on a full tile row (8 tiles) + the ragged corner of the same
+                    frame, and on BASELINE config 1 (256x256, a2) in full; rank 0 only.
+Parity gate (same oracle tiles): the worst max-abs error of the engine's fp32 tile results vs the oracle over BOTH inputs must be
+<= 1e-3, and the delivered fp16 canvas must equal those tiles to fp16 rounding (<= 1e-3 + half an fp16 ulp of the value); otherwise every
+rank exits non-zero.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -44,8 +58,21 @@ for _p in (ROOT, os.path.join(ROOT, 'tests')):
 FRAME = (3, 1080, 1920)
 CROP, PAD, SCALE = 256, 5, 4
 MFLOP_PER_PX_PLANE = 3.9456          # Net4x conv FLOPs per LR pixel per plane
-PEAK_FP16_TFLOPS = 2500.0            # MI355X dense fp16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense)
 PARITY_TOL = 1e-3
+# bracketed layer groups: (profile substring, label, algorithmic FLOPs per LR pixel and plane)
+GROUPS = [
+    ('convt_R1.up1', 'R-branch 3x3 64->256 @2x res (+bias +PixelShuffle(2) +PReLU, fused 64->1 tail with split activations: conv3x3 EPI 7)', 4 * 2 * 256 * 64 * 9),
+    ('u.up1', 'U-branch 3x3 64->256 @2x res (+bias +PixelShuffle(2) +PReLU, fused 64->1 tail: conv3x3 EPI 3)', 4 * 2 * 256 * 64 * 9),
+    ('arsb', 'arsb_fused_kernel (one ARSB per launch: two 3x3 64->64 convs @1x res + PReLU + hi/lo residual stream; 5 of 6 ARSBs)', 5 * 2 * 2 * 64 * 64 * 9),
+]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
 def main():
@@ -59,7 +86,15 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU oracle legs (baseline + parity gate)')
     ap.add_argument('--cpu-tiles', type=int, default=9, help='tiles of the headline frame run through the CPU oracle (parity + baseline)')
     ap.add_argument('--no-noise-input', action='store_true', help='skip the second (uniform uint8 noise) input')
+    ap.add_argument('--no-dropin-loop', action='store_true', help='skip the per-tile drop-in loop leg')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # started plainly: become the launcher (one rank per GPU, rendezvous on the loopback address); the ranks re-enter main()
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+               '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
 
     import numpy as np
     import torch
@@ -73,10 +108,7 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('MOE_FORCE_DEVICE', os.environ.get('LOCAL_RANK', '0')))   # MOE_FORCE_DEVICE: test mode, ranks share a GPU
     backend = os.environ.get('MOE_DIST_BACKEND', 'nccl')                                     # 'gloo' only for that test mode
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node {}'.format(args.gpus))
-        args.gpus = world
+    args.gpus = world
     _lib.require_device()
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
@@ -101,6 +133,9 @@ def main():
     opt = runSR.getOpt({'op': 'SR', 'model': 'a', 'scale': SCALE, 'ensemble': 0})
     model = opt.modelCached.set_precision(args.precision)
     precision = model.resolved_precision()
+    dinfo = _lib.device_info(local)
+    # dense fp16 MFMA peak: every CU has 4 SIMDs, each retires 1024 FLOP per clock (v_mfma_f32_32x32x16_f16: 32768 FLOP in 32 cycles)
+    peak_tflops = dinfo['compute_units'] * 4 * 1024 * dinfo['clock_khz'] * 1e3 / 1e12
 
     # ---- input frames, resident in HBM ------------------------------------------------------------------
     nframes = world
@@ -114,6 +149,8 @@ def main():
     frames = make_frames('natural')
     plan = ip._plan_for(opt, frames[0].shape)
     assert plan.n_tiles == 40, plan.n_tiles
+    tile_px_total = sum((t[1] - t[0]) * (t[3] - t[2]) for t in plan.tiles)
+    overlap = tile_px_total / float(FRAME[1] * FRAME[2])             # executed / algorithmic pixels (1.064 for this grid)
 
     def step(fr):
         if world == 1:
@@ -127,25 +164,28 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    def timed(fr, steps):
+    def all_max(v):
+        if world > 1:
+            t = torch.tensor([v], dtype=torch.float64, device=dev if backend == 'nccl' else None)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            v = float(t.item())
+        return v
+
+    def timed(fr, steps, fn=None):
+        fn = fn or step
         fence()
         t0 = time.perf_counter()
         for _ in range(steps):
-            step(fr)
+            fn(fr)
         fence()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == 'nccl' else None)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
+        return all_max(time.perf_counter() - t0)
 
     in_mp = nframes * FRAME[1] * FRAME[2] / 1e6
     for _ in range(args.warmup):
         step(frames)
-    model.set_profile('up1,arsb')      # hipEvent pairs around the 64->256 @2x convs (both branches) and the one-launch ARSBs, on the launch stream
+    model.set_profile(','.join(g[0] for g in GROUPS))      # hipEvent pairs on the launch stream around the launches of each group
     dt = timed(frames, args.steps)
-    prof_up1, prof_c2 = model.get_profile(all_keys=True)
+    profs = model.get_profile(all_keys=True)
     model.set_profile(None)
     ms_per_step = dt / args.steps * 1e3
     value = in_mp / (ms_per_step / 1e3)
@@ -154,31 +194,65 @@ def main():
         'metric': 'megapixels/sec (input), 1080p 4x SR (Net4x a4), 256-px tiles with overlap',
         'value': round(value, 3), 'unit': 'MP/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'fp16', 'data': 'synthetic',
+        'dtype': 'fp16' if precision != 'fp16x3' else 'fp16x3 (split fp16 operands, three MFMA passes)', 'data': 'synthetic',
         'config': {'workload': 'BASELINE configs[1]: {} frame(s) 1920x1080 RGB -> 7680x4320, model a4 (Net4x, synthetic weights in zoo format), '
                                'crop 256 pad 5 align 8 -> 40 tiles/frame, fp16 I/O, fp16 MFMA operands + fp32 accumulate'.format(nframes),
                    'frames_per_step': nframes, 'tiles_per_frame': plan.n_tiles, 'output_mp_per_s': round(value * SCALE * SCALE, 2),
                    'tflops_algorithmic': round(nframes * 3 * FRAME[1] * FRAME[2] * MFLOP_PER_PX_PLANE * 1e6 / (ms_per_step / 1e3) / 1e12, 2),
+                   'tile_overlap_factor': round(overlap, 4),
                    'parallelism': 'tile-parallel x{} (round-robin tiles, all-to-all of tile results, stitch on rank f%N)'.format(world) if world > 1 else 'single GPU',
                    'precision': precision, 'input': 'natural-image-like synthetic frame (tests/golden_defs.natural_image)'},
+        'device': {'compute_units': dinfo['compute_units'], 'max_clock_ghz': round(dinfo['clock_khz'] / 1e6, 3),
+                   'peak_fp16_mfma_tflops': round(peak_tflops, 1), 'peak_formula': 'CUs x 4 SIMD x 1024 FLOP/clk x max clock (hipDeviceProp)'},
     }
 
-    def roof(prof, kernel):
-        ach = prof['flops'] / (prof['total_ms'] / 1e3) / 1e12
-        return {'bound': 'mfma', 'kernel': kernel, 'achieved': round(ach, 1), 'peak': PEAK_FP16_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(ach / PEAK_FP16_TFLOPS, 4), 'launches': prof['launches'], 'avg_launch_ms': round(prof['total_ms'] / prof['launches'], 4),
-                'gflop_per_launch': round(prof['flops'] / prof['launches'] / 1e9, 2)}
-    if prof_up1['launches'] > 0:
-        res['roofline'] = roof(prof_up1, 'conv3x3_sp_kernel<3> (3x3 64->256 @2x res, +bias +PixelShuffle(2) +PReLU, fused 64->1 tail taps)')
-        res['roofline']['traffic'] = _pmc_traffic(res['roofline']['gflop_per_launch'])
-    if prof_c2['launches'] > 0:
-        res['roofline_trunk'] = roof(prof_c2, 'arsb_fused_kernel (one ARSB per launch: two 3x3 64->64 convs @1x res + PReLU + hi/lo residual stream)')
+    # ---- roofline objects: one per bracketed group, dominant (by time) first ----------------------------------------
+    pmc = _pmc_table()
+    kernels = []
+    frames_timed = args.steps        # every rank computes one frame's worth of tiles per step
+    for (key, label, flop_px), prof in zip(GROUPS, profs):
+        if prof['launches'] <= 0 or prof['total_ms'] <= 0:
+            continue
+        secs = prof['total_ms'] / 1e3
+        alg = 3.0 * FRAME[1] * FRAME[2] * flop_px * frames_timed                      # algorithmic FLOPs of the group in the timed steps
+        exe = prof['flops']                                                             # what the launches computed (tile pixels)
+        k = {'bound': 'mfma', 'kernel': label, 'layer_key': key,
+             'achieved': round(alg / secs / 1e12, 1), 'peak': round(peak_tflops, 1), 'unit': 'TFLOP/s', 'frac': round(alg / secs / 1e12 / peak_tflops, 4),
+             'achieved_executed': round(exe / secs / 1e12, 1), 'frac_executed': round(exe / secs / 1e12 / peak_tflops, 4),
+             'launches': prof['launches'], 'avg_launch_ms': round(prof['total_ms'] / prof['launches'], 4),
+             'ms_per_frame': round(prof['total_ms'] / frames_timed, 3), 'share_of_step': round(prof['total_ms'] / frames_timed / ms_per_step, 4),
+             'gflop_per_launch_algorithmic': round(alg / prof['launches'] / 1e9, 2)}
+        t = pmc.get(key)
+        if t:       # PMC passes of this same command: bytes per frame / launches per frame
+            k['traffic'] = int(t['hbm_bytes_per_frame'] / max(1, t['launches_per_frame']))
+            k['traffic_note'] = t.get('note', '')
+            if t.get('mfma_busy') is not None:
+                k['mfma_busy_pmc'] = t['mfma_busy']
+        else:
+            k['traffic'] = None
+        kernels.append(k)
+    kernels.sort(key=lambda k: -k['ms_per_frame'])
+    if kernels:
+        res['roofline'] = dict(kernels[0])
+        res['roofline_kernels'] = kernels
+        trunk = [k for k in kernels if k['layer_key'] == 'arsb']
+        if trunk:
+            res['roofline_trunk'] = trunk[0]
 
-    # ---- sustained leg (power-capped part: a 0.5 s burst flatters the clock) -------------------------------
+    # ---- sustained leg (power-capped part: a 0.5 s burst flatters the clock), with the clock / power sampled beside it ------------
     if args.sustain > 0:
         n_s = max(args.steps, int(args.sustain / (ms_per_step / 1e3)) + 1)
+        sampler = _ClockSampler(local) if rank == 0 else None
+        if sampler:
+            sampler.start()
         dts = timed(frames, n_s)
+        clock = sampler.stop() if sampler else None
         res['sustained'] = {'seconds': round(dts, 2), 'steps': n_s, 'ms_per_step': round(dts / n_s * 1e3, 3), 'value': round(in_mp / (dts / n_s), 3), 'unit': 'MP/s'}
+        if clock:
+            res['clock'] = clock
+            if kernels and clock.get('sclk_ghz_mean'):
+                res['clock']['frac_at_clock'] = round(kernels[0]['frac'] * (dinfo['clock_khz'] / 1e6) / clock['sclk_ghz_mean'], 4)
+                res['clock']['note'] = 'frame-average shader clock under the package power cap; frac_at_clock = roofline.frac against the MFMA peak at that clock'
 
     # ---- second input: uniform uint8 noise ------------------------------------------------------
     inputs = {'natural': {'value': res['value'], 'ms_per_step': res['ms_per_step']}}
@@ -190,10 +264,31 @@ def main():
         inputs['noise_u8'] = {'value': round(in_mp / (dtn / args.steps), 3), 'ms_per_step': round(dtn / args.steps * 1e3, 3)}
     res['inputs'] = inputs
 
+    # ---- the reference's own tile loop around the drop-in module (rank 0, one GPU) ---------------------------------------
+    if world == 1 and not args.no_dropin_loop:
+        ramp = torch.from_numpy(plan.ramp.copy()).to(dev).half()
+        xin = frames[0]
+
+        def loop(_):
+            return _reference_style_loop(opt, xin, plan, ramp, torch)
+        y_loop = loop(None)
+        torch.cuda.synchronize()
+        y_dev = ip.doCrop(opt, xin)
+        n_l = max(3, args.steps // 2)
+        dtl = timed(None, n_l, loop)
+        ms_l = dtl / n_l * 1e3
+        res['dropin_loop'] = {'value': round(FRAME[1] * FRAME[2] / 1e6 / (ms_l / 1e3), 3), 'unit': 'MP/s', 'ms_per_step': round(ms_l, 3), 'steps': n_l,
+                              'ratio_to_value': round(ms_per_step / ms_l, 3),
+                              'max_abs_vs_device_docrop': float('{:.3e}'.format(float((y_loop.float() - y_dev.float()).abs().max()))),
+                              'what': "the reference's per-tile loop (python/imageProcess.py:157-172) with torch blends, calling models.Net4x.__call__ = moe_net_forward on "
+                                      '3 planes of <= 256x256 per call (40 calls per frame, fp16 canvas AND fp16 blends as in the reference GPU path); '
+                                      'moe_run_plan (the headline) batches 8 tiles per launch set and stitches from fp32 tiles'}
+
     # ---- CPU baseline + parity gate (rank 0) -----------------------------------------------------------------
     parity_ok = True
     if rank == 0 and not args.no_cpu_baseline:
         from oracle import nets as onets        # test infrastructure: the checker / baseline, never the product path
+        from oracle import planner as oplanner, stitch as ostitch
         import ctypes
         ncores, nthreads = _one_socket_cores()
         torch.set_num_threads(nthreads)
@@ -202,7 +297,9 @@ def main():
         if world > 1:
             ks = ks[1:2] + ks[8:9]            # multi-GPU runs: a bounded check (the other ranks wait)
         off = plan.tile_offsets(3)
-        tile_px_total = sum((t[1] - t[0]) * (t[3] - t[2]) for t in plan.tiles)
+        opl = oplanner.prepare(FRAME, 1 << 40, 1e-3, PAD, SCALE, 8, CROP)
+        rows = ostitch.axis_cover(opl.anchors_h, SCALE, opl.pad_sc, plan.outH)
+        cols = ostitch.axis_cover(opl.anchors_w, SCALE, opl.pad_sc, plan.outW)
 
         def check(fr, tiles):
             pool = torch.empty(plan.pool_elems(3), dtype=torch.float32, device=dev)
@@ -212,7 +309,7 @@ def main():
                                                   ctypes.c_void_p(pool.data_ptr()), 0, 1, 1, torch.cuda.current_stream().cuda_stream))
             torch.cuda.synchronize()
             x16 = fr.float().cpu().numpy()          # the same fp16-quantised input the engine saw
-            px, cpu_s, errs = 0, 0.0, []
+            px, cpu_s, errs, cerrs, cbounds = 0, 0.0, [], [], []
             for k in tiles:
                 top, bottom, left, right = plan.tiles[k][:4]
                 xt = np.ascontiguousarray(x16[:, None, top:bottom, left:right])
@@ -222,20 +319,40 @@ def main():
                 px += (bottom - top) * (right - left)
                 got = pool[off[k]:off[k] + want.size].reshape(want.shape).cpu().numpy()
                 errs.append(float(np.abs(got - want).max()))
-            return px, cpu_s, errs
-        px, cpu_s, errs = check(frames[0], ks)
+                # the DELIVERED fp16 canvas where this tile is final and un-blended: rows / columns from the tile's solid start up to the
+                # next tile's first written row / column (python/imageProcess.py:120-131,167-170)
+                i, j = divmod(k, opl.step_w)
+                y0, y1 = rows[i][1], (rows[i + 1][0] if i + 1 < len(rows) else plan.outH)
+                x0, x1 = cols[j][1], (cols[j + 1][0] if j + 1 < len(cols) else plan.outW)
+                oy, ox = rows[i][2], cols[j][2]
+                if y1 > y0 and x1 > x0:
+                    w_reg = want[:, y0 - oy:y1 - oy, x0 - ox:x1 - ox]
+                    c_reg = y[:, y0:y1, x0:x1].float().cpu().numpy()
+                    d = np.abs(c_reg - w_reg)
+                    cerrs.append(float(d.max()))
+                    # fp16 rounding of the delivered value: half an ulp of |v| (2^-11 relative, rounded up to the binade)
+                    cbounds.append(float((d - (PARITY_TOL + np.exp2(np.ceil(np.log2(np.maximum(np.abs(w_reg), 1e-3))) - 11))).max()))
+            return px, cpu_s, errs, cerrs, cbounds
+        px, cpu_s, errs, cerrs, cb = check(frames[0], ks)
         frame_s = cpu_s / px * tile_px_total              # all 40 tiles at the sampled per-pixel rate
-        parity = {'natural': {'tiles': ks, 'worst_max_abs': float('{:.3e}'.format(max(errs))), 'per_tile': [float('{:.2e}'.format(e)) for e in errs]}}
-        parity_ok = max(errs) <= PARITY_TOL
+
+        def pobj(tiles, errs, cerrs, cb):
+            return {'tiles': tiles, 'worst_max_abs': float('{:.3e}'.format(max(errs))), 'per_tile': [float('{:.2e}'.format(e)) for e in errs],
+                    'canvas_fp16_worst_max_abs': float('{:.3e}'.format(max(cerrs))) if cerrs else None,
+                    'canvas_within_tol_plus_half_ulp': bool(max(cb) <= 0) if cb else None,
+                    'ok': bool(max(errs) <= PARITY_TOL and (not cb or max(cb) <= 0))}
+        parity = {'natural': pobj(ks, errs, cerrs, cb)}
+        parity_ok = parity['natural']['ok']
         if noise_frames is not None:
             kn = ks if world == 1 else ks[:1]
-            _, cpu_n, errs_n = check(noise_frames[0], kn)
-            parity['noise_u8'] = {'tiles': kn, 'worst_max_abs': float('{:.3e}'.format(max(errs_n))), 'per_tile': [float('{:.2e}'.format(e)) for e in errs_n]}
-            parity['noise_u8']['ok'] = max(errs_n) <= PARITY_TOL
+            _, cpu_n, errs_n, cerrs_n, cb_n = check(noise_frames[0], kn)
+            parity['noise_u8'] = pobj(kn, errs_n, cerrs_n, cb_n)
+            parity_ok = parity_ok and parity['noise_u8']['ok']
         res['cpu_baseline'] = {'value': round(FRAME[1] * FRAME[2] / 1e6 / frame_s, 5), 'unit': 'MP/s', 'cores': ncores, 'threads': nthreads,
                                'kind': 'port', 'sample': '{} of 40 tiles (tile row 1 + the ragged corner: {} tile pixels x 3 planes) of the headline frame through the fp32 '
                                'oracle (torch/oneDNN conv backend), {:.1f} s; extrapolated to the frame by tile pixels'.format(len(ks), px, cpu_s),
-                               'cpu_model': _cpu_model(), 'host_logical_cpus': os.cpu_count()}
+                               'cpu_model': _cpu_model(), 'host_logical_cpus': os.cpu_count(),
+                               'note': 'the GPU idles during this leg: device-busy averages over the whole process include it'}
         if world == 1:      # BASELINE config 1 in full: 256x256 RGB, a2 (real weights), one tile, on the CPU oracle
             sd_a2 = gd.state_dict_for('a2', load_state_dict_file)
             x1 = gd.noise_u8(0, (3, 256, 256)).astype(np.float32)[:, None] / np.float32(255)
@@ -246,17 +363,87 @@ def main():
             res['cpu_baseline']['config1'] = {'workload': 'BASELINE configs[0]: 256x256 RGB -> 512x512, a2, one tile, fp32 oracle', 'seconds': round(c1, 3),
                                               'value': round(256 * 256 / 1e6 / c1, 5), 'unit': 'MP/s'}
         res['config']['parity'] = parity
-        res['config']['parity_max_abs_vs_oracle'] = parity['natural']['worst_max_abs']
+        res['config']['parity_max_abs_vs_oracle'] = max(p['worst_max_abs'] for p in parity.values())
         res['config']['parity_tolerance'] = PARITY_TOL
         res['config']['parity_ok'] = bool(parity_ok)
     if rank == 0:
         print(json.dumps(res))
         sys.stdout.flush()
-    if world > 1:
+    if world > 1:       # every rank learns the verdict of rank 0's gate before anybody exits
+        flag = torch.tensor([1 if parity_ok else 0], dtype=torch.int32, device=dev if backend == 'nccl' else None)
+        dist.broadcast(flag, src=0)
+        parity_ok = bool(int(flag.item()))
         dist.barrier()
         dist.destroy_process_group()
     if not parity_ok:
-        raise SystemExit('parity gate failed: the engine differs from the oracle by more than {} on the headline input'.format(PARITY_TOL))
+        raise SystemExit('parity gate failed: the engine differs from the oracle by more than {} (tiles) or the fp16 canvas by more than that plus half an ulp'.format(PARITY_TOL))
+
+
+def _reference_style_loop(opt, x, plan, ramp, torch):
+    """The loop a MoePhoto maintainer keeps when only the class in runSR.mode_switch is swapped (python/imageProcess.py:157-172): for every
+    tile, hand the net a slice VIEW of the planes-as-batch image, cross-fade the fresh result into what the canvas window already
+    holds (rows first, then columns, each over `padSc` entries in front of the tile's first new entry), and assign it aligned to the
+    window's bottom-right corner.  Written against the plan's tile tuples; dtype of canvas and blends = dtype of x (fp16 on the GPU path)."""
+    C = x.shape[0]
+    sc, psc = plan.sc, plan.padSc
+    xb = plan.padImage(x).unsqueeze(1)
+    canvas = x.new_empty((C, plan.outH, plan.outW))
+
+    def fade(fresh, held, first_new, dim, weights):
+        n = fresh.shape[dim]
+        if first_new < 0:
+            first_new += n
+        if first_new < 1:
+            return fresh, held
+        a = first_new - psc
+        band = torch.lerp(held.narrow(dim, a, psc), fresh.narrow(dim, a, psc), weights)
+        return torch.cat([band, fresh.narrow(dim, first_new, n - first_new)], dim), held.narrow(dim, a, n - a)
+    wr, wc = ramp.view(-1, 1), ramp.view(1, -1)
+    for (top, bottom, left, right, tt, lt, bsc, rsc) in plan.tiles:
+        r = opt(xb[..., top:bottom, left:right]).squeeze(1)[..., :plan.outH - top * sc, :plan.outW - left * sc]
+        held = canvas[..., top * sc:bsc, left * sc:rsc]
+        r, held = fade(r, held, tt, -2, wr)
+        r, _ = fade(r, held, lt, -1, wc)
+        h, w = r.shape[-2:]
+        canvas[..., bsc - h:bsc, rsc - w:rsc] = r
+    return canvas
+
+
+class _ClockSampler(object):
+    """rocm-smi's shader clock and package power, sampled twice a second in a side thread while the sustained leg runs."""
+
+    def __init__(self, device):
+        self.device, self.samples, self._stop, self._t = device, [], threading.Event(), None
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                out = subprocess.run(['rocm-smi', '-d', str(self.device), '--showclocks', '--showpower', '--json'], capture_output=True, text=True, timeout=5).stdout
+                d = json.loads(out)
+                card = next(iter(d.values()))
+                sclk = next((v for k, v in card.items() if 'sclk' in k.lower() and 'mhz' in str(v).lower()), None)
+                pw = next((v for k, v in card.items() if 'power' in k.lower() and 'graphics' in k.lower()), None)
+                mhz = float(str(sclk).strip('()').lower().replace('mhz', '')) if sclk else None
+                if mhz and mhz > 300:       # (idle samples at the start / end of the leg are dropped)
+                    self.samples.append((mhz, float(pw) if pw else None))
+            except Exception:
+                pass
+            self._stop.wait(0.5)
+
+    def start(self):
+        self._t = threading.Thread(target=self._run, daemon=True)
+        self._t.start()
+
+    def stop(self):
+        self._stop.set()
+        if self._t:
+            self._t.join(timeout=10)
+        if not self.samples:
+            return None
+        mhz = [s[0] for s in self.samples]
+        pw = [s[1] for s in self.samples if s[1] is not None]
+        return {'sclk_ghz_mean': round(sum(mhz) / len(mhz) / 1e3, 3), 'sclk_ghz_min': round(min(mhz) / 1e3, 3), 'sclk_ghz_max': round(max(mhz) / 1e3, 3),
+                'package_power_w_mean': round(sum(pw) / len(pw), 1) if pw else None, 'samples': len(mhz), 'source': 'rocm-smi --showclocks --showpower during the sustained leg'}
 
 
 def _cpu_model():
@@ -293,16 +480,13 @@ def _one_socket_cores():
     return n, n
 
 
-def _pmc_traffic(gflop_per_launch):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), if present.  The counters were
-    collected on launches of 12 planes of 256^2 (tools/prof_workload.py); the benchmark's launches carry more planes (8 tiles per
-    launch set, split by the 32-bit offset range), so the figure is scaled by the launches' algorithmic FLOPs (traffic is linear in planes)."""
-    p = os.path.join(ROOT, 'profiles', 'pmc_dominant.json')
+def _pmc_table():
+    """{layer key: {'hbm_bytes_per_frame', 'launches_per_frame', ...}} from the committed rocprofv3 PMC passes of THIS command
+    (tools/pmc_bench.sh -> tools/pmc_collect.py -> profiles/pmc_bench.json), or {} when absent."""
     try:
-        d = json.load(open(p))
-        return int(d['hbm_bytes_per_launch'] * gflop_per_launch / d['gflop_per_launch'])
+        return json.load(open(os.path.join(ROOT, 'profiles', 'pmc_bench.json'))).get('groups', {})
     except Exception:
-        return None
+        return {}
 
 
 if __name__ == '__main__':

@@ -4,7 +4,7 @@
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # (tests/ -> repo root)
 for p in (ROOT, os.path.join(ROOT, 'tests')):
     sys.path.insert(0, p)
 import torch  # noqa: E402

@@ -1,0 +1,340 @@
+"""Full-size BASELINE configurations and the wide parity net, on the GPU (`pytest -m gpu`).
+
+* config 2, every tile: the engine's own split-operand mode ('fp16x3', pinned to the oracle at 2e-5 by test_gpu_parity.py) is the
+  transfer standard; ALL 40 tiles x 4 seeds x {natural, uint8 noise} of the 1080p frame in the default arithmetic must stay within
+  1e-3 - 2e-5 of it, likewise full frames of a2 / a3 / dn_lite5 (milliseconds per frame instead of 3 s of CPU oracle per tile);
+* config 3 (python/runDN.py:10-16 + python/runSR.py:10-16 at 4K: l25 -> a2, 144 + 144 tiles) and config 5 (8K -> 32K, a4, 512-px
+  tiles, 144 tiles, fp16 canvas of 3.19 GB) at FULL size through size-independent properties: tile grid, tiles of each step against
+  the oracle, the stitched canvas against the oracle's fold of the engine's own tiles on windows that cut every kind of seam
+  (python/imageProcess.py:120-131,157-172), batching invariance; their timings and the stitch kernel's rate go to gpurun_out/;
+* multi-GPU path with real engine calls: 2 and 3 ranks sharing this GPU (gloo for the exchange, MOE_FORCE_DEVICE), and bench.py --gpus 2
+  started plainly in that mode.
+"""
+import ctypes
+import json
+import os
+import socket
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+import torch
+
+import golden_defs as gd
+from moephoto_amd.weights import load_state_dict_file, save_state_dict_file
+from oracle import nets as onets, planner as oplanner, stitch as ostitch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 1e-3
+XFER = 2e-5          # what 'fp16x3' itself is allowed against the oracle (test_gpu_parity.py)
+
+
+@pytest.fixture(scope='module')
+def dev():
+    from moephoto_amd import _lib
+    _lib.require_device()
+    return torch.device('cuda:0')
+
+
+def _report(name, obj):
+    d = os.path.join(ROOT, 'gpurun_out')
+    try:
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, 'fullsize_report.json')
+        cur = json.load(open(path)) if os.path.exists(path) else {}
+        cur[name] = obj
+        json.dump(cur, open(path, 'w'), indent=1)
+    except Exception:
+        pass
+
+
+def _opt_sr(model, scale, crop, fp16_io=False):
+    from moephoto_amd import imageProcess as ip, runSR
+    from moephoto_amd.config import config
+    config.modelRoot, config.crop_sr, config.fp16, config.deviceId = gd.ZOO, crop, fp16_io, 0
+    key = model + str(scale)
+    ip.modelCache.pop('SR' + key, None)
+    if gd.MODELS[key][1] is None:
+        path = os.path.join('/tmp', 'moe_synth_{}.pth'.format(key))
+        save_state_dict_file(gd.synth_state_dict(key, load_state_dict_file), path)
+        runSR.mode_switch[key] = (path, runSR.mode_switch[key][1])
+    return runSR.getOpt({'op': 'SR', 'model': model, 'scale': scale, 'ensemble': 0})
+
+
+def _opt_dn(model, crop):
+    from moephoto_amd import imageProcess as ip, runDN
+    from moephoto_amd.config import config
+    config.modelRoot, config.crop_dn, config.crop_dns, config.deviceId = gd.ZOO, crop, crop, 0
+    ip.modelCache.pop('DN' + model, None)
+    if model == '25':
+        path = '/tmp/moe_synth_l25.pth'
+        save_state_dict_file(gd.synth_state_dict('l25', load_state_dict_file), path)
+        runDN.mode_switch['25'] = (path,) + tuple(runDN.mode_switch['25'][1:])
+    return runDN.getOpt({'op': 'DN', 'model': model})
+
+
+def _pool_of(opt, plan, xd, per_batch=0, stitch_to=None):
+    """Raw fp32 tile results of the device-resident doCrop (moe_run_plan_ex with a caller pool)."""
+    from moephoto_amd import _lib
+    C = xd.shape[0]
+    pool = torch.empty(plan.pool_elems(C), dtype=torch.float32, device=xd.device)
+    sC, sH, sW = xd.stride()
+    dt = _lib.F16 if xd.dtype == torch.float16 else _lib.F32
+    out_p, out_dt = (stitch_to.data_ptr(), _lib.F16 if stitch_to.dtype == torch.float16 else _lib.F32) if stitch_to is not None else (None, _lib.F32)
+    _lib.check(_lib.lib().moe_run_plan_ex(opt.modelCached._h, plan._h, xd.data_ptr(), dt, sC, sH, sW, out_p, out_dt, per_batch,
+                                          ctypes.c_void_p(pool.data_ptr()), 0, 1, 1 if stitch_to is not None else 0, torch.cuda.current_stream().cuda_stream))
+    return pool
+
+
+def _frames(kind, seed, shape):
+    return gd.natural_image(seed, shape) if kind == 'natural' else gd.noise_u8(seed, shape).astype(np.float32) / np.float32(255)
+
+
+def test_parity_sweep_all_tiles_vs_exact_mode(dev):
+    """Every tile of full frames, several seeds, both input classes: default arithmetic against the engine's exact mode."""
+    from moephoto_amd import imageProcess as ip
+    report = {}
+    cases = [('a', 4, 256, (3, 1080, 1920), (0, 1, 2, 3)), ('a', 2, 256, (3, 1080, 1920), (0, 1)), ('a', 3, 256, (3, 540, 960), (0, 1))]
+    for model, scale, crop, shape, seeds in cases:
+        opt = _opt_sr(model, scale, crop)
+        m = opt.modelCached
+        worst = {}
+        for kind in ('natural', 'noise_u8'):
+            for seed in seeds:
+                xd = torch.from_numpy(_frames(kind, 100 + seed if kind == 'natural' else seed, shape)).to(dev).half()
+                plan = ip._plan_for(opt, xd.shape)
+                m.set_precision('auto')
+                got = _pool_of(opt, plan, xd)
+                m.set_precision('fp16x3')
+                want = _pool_of(opt, plan, xd)
+                m.set_precision('auto')
+                off = plan.tile_offsets(3) + [plan.pool_elems(3)]
+                d = (got - want).abs()
+                per_tile = [float(d[off[k]:off[k + 1]].max()) for k in range(plan.n_tiles)]
+                worst[(kind, seed)] = max(per_tile)
+                assert max(per_tile) <= TOL - XFER, (model, scale, kind, seed, int(np.argmax(per_tile)), max(per_tile))
+        report['{}{}'.format(model, scale)] = {'{}:{}'.format(k[0], k[1]): float('{:.3e}'.format(v)) for k, v in worst.items()}
+    # NetDN (dn_lite5), 1080p, pad 7
+    from moephoto_amd.config import config
+    config.fp16 = False
+    opt = _opt_dn('lite5', 256)
+    m = opt.modelCached
+    worst = {}
+    for kind in ('natural', 'noise_u8'):
+        xd = torch.from_numpy(_frames(kind, 7, (3, 1080, 1920))).to(dev).half()
+        plan = ip._plan_for(opt, xd.shape)
+        m.set_precision('auto')
+        got = _pool_of(opt, plan, xd)
+        m.set_precision('fp16x3')
+        want = _pool_of(opt, plan, xd)
+        m.set_precision('auto')
+        worst[kind] = float((got - want).abs().max())
+        assert worst[kind] <= TOL - XFER, (kind, worst[kind])
+    report['dn_lite5'] = {k: float('{:.3e}'.format(v)) for k, v in worst.items()}
+    _report('parity_sweep_max_abs_default_vs_fp16x3', report)
+
+
+def _fold_window(tile_at, rows, cols, step_w, ramp, pad_sc, y0, y1, x0, x1, C):
+    """The sequential blend of doCrop (python/imageProcess.py:120-131,167-170) restricted to the HR window [y0,y1) x [x0,x1): tiles in
+    raster order, each cross-fading its blend bands into what the window holds and overwriting its solid part."""
+    out = np.full((C, y1 - y0, x1 - x0), np.nan, np.float32)
+    for i, (fy, sy, oy, ey) in enumerate(rows):
+        for j, (fx, sx, ox, ex_) in enumerate(cols):
+            a0, a1, b0, b1 = max(fy, y0), min(ey, y1), max(fx, x0), min(ex_, x1)
+            if a1 <= a0 or b1 <= b0:
+                continue
+            r = tile_at(i * step_w + j, a0 - oy, a1 - oy, b0 - ox, b1 - ox)
+            cur = out[:, a0 - y0:a1 - y0, b0 - x0:b1 - x0]
+            ys, xs = np.arange(a0, a1), np.arange(b0, b1)
+            wy = ramp[np.clip(ys - fy, 0, max(pad_sc - 1, 0))].astype(np.float32)[None, :, None]
+            wx = ramp[np.clip(xs - fx, 0, max(pad_sc - 1, 0))].astype(np.float32)[None, None, :]
+            with np.errstate(invalid='ignore'):
+                v1 = np.where((ys < sy)[None, :, None], cur + wy * (r - cur), r)
+                v = np.where((xs < sx)[None, None, :], cur + wx * (v1 - cur), v1)
+            out[:, a0 - y0:a1 - y0, b0 - x0:b1 - x0] = v.astype(np.float32)
+    return out
+
+
+def _check_stitch_windows(pool, canvas, plan, opl, sc, C, tol):
+    """Canvas == oracle fold of the engine's own tile results on windows around interior seams, image edges and the re-anchored last
+    row / column of tiles."""
+    off = plan.tile_offsets(C)
+    rows = ostitch.axis_cover(opl.anchors_h, sc, opl.pad_sc, plan.outH)
+    cols = ostitch.axis_cover(opl.anchors_w, sc, opl.pad_sc, plan.outW)
+    ramp = oplanner.blend_ramp(opl.pad_sc)
+
+    def tile_at(k, r0, r1, c0, c1):
+        t = plan.tiles[k]
+        th, tw = (t[1] - t[0]) * sc, (t[3] - t[2]) * sc
+        v = pool[off[k]:off[k] + C * th * tw].view(C, th, tw)[:, r0:r1, c0:c1]
+        return v.cpu().numpy()
+    H, W = plan.outH, plan.outW
+    ny, nx = len(rows), len(cols)
+    wins = [(rows[1][0] - 40, rows[1][1] + 40, cols[1][0] - 40, cols[1][1] + 40),                      # an interior corner of four tiles
+            (0, 96, cols[nx // 2][0] - 48, cols[nx // 2][1] + 48),                                      # top image edge across a vertical seam
+            (rows[ny - 1][0] - 64, H, cols[nx - 1][0] - 64, W),                                          # the re-anchored last row x last column
+            (rows[ny // 2][0] - 24, rows[ny // 2][1] + 24, 0, 200),                                      # left image edge across a horizontal seam
+            (H - 130, H, cols[2][0] - 30, cols[2][1] + 30)]
+    worst = 0.0
+    for (y0, y1, x0, x1) in wins:
+        y0, x0, y1, x1 = max(0, y0), max(0, x0), min(H, y1), min(W, x1)
+        want = _fold_window(tile_at, rows, cols, opl.step_w, ramp, opl.pad_sc, y0, y1, x0, x1, C)
+        got = canvas[:, y0:y1, x0:x1].float().cpu().numpy()
+        assert not np.isnan(want).any()
+        worst = max(worst, float(np.abs(got - want).max()))
+    assert worst <= tol, worst
+    return worst
+
+
+def _time_ms(fn, reps=3):
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def test_config3_full_size_dn_l25_then_sr_a2(dev):
+    """BASELINE config 3 as written: 3840x2160 RGB, [{'op':'DN','model':'25'}, {'op':'SR','model':'a','scale':2}], 256-px tiles:
+    144 tiles (pad 7) then 144 tiles (pad 5) -> 7680x4320."""
+    from moephoto_amd import _lib, imageProcess as ip, runSR
+    from moephoto_amd.config import config
+    config.fp16 = True
+    shape = (3, 2160, 3840)
+    x = gd.natural_image(31, shape)
+    xd = torch.from_numpy(x).to(dev).half()
+    odn, osr = _opt_dn('25', 256), _opt_sr('a', 2, 256, fp16_io=True)
+    rep = {}
+    # ---- step 1: SEDN l25 ---------------------------------------------------------------------------------------------
+    plan = ip._plan_for(odn, xd.shape)
+    assert plan.n_tiles == 144 and (plan.stepH, plan.stepW) == (9, 16)
+    d16 = torch.empty(shape, dtype=torch.float16, device=dev)
+    pool = _pool_of(odn, plan, xd, stitch_to=d16)
+    pool1 = _pool_of(odn, plan, xd, per_batch=1)
+    assert torch.equal(pool, pool1)                                     # batching invariance (SE pooling is per tile, whatever shares a launch)
+    del pool1
+    opl = oplanner.prepare(shape, 1 << 40, 1e-3, 7, 1, 8, 256)
+    assert [tuple(t) for t in opl.tiles] == [tuple(t) for t in plan.tiles]
+    sd = gd.state_dict_for('l25', load_state_dict_file)
+    x16 = xd.float().cpu().numpy()
+    off = plan.tile_offsets(3)
+    for k in (17, 143):                                                 # an interior 256x256 tile and the ragged bottom-right corner
+        top, bottom, left, right = plan.tiles[k][:4]
+        want = onets.forward('sedn', sd, np.ascontiguousarray(x16[:, None, top:bottom, left:right])).numpy()[:, 0]
+        got = pool[off[k]:off[k] + want.size].view(want.shape).cpu().numpy()
+        assert np.abs(got - want).max() <= TOL, (k, float(np.abs(got - want).max()))
+    rep['dn_stitch_window_max_abs'] = _check_stitch_windows(pool, d16, plan, opl, 1, 3, 2.5e-4 + 1e-6)     # fp16 canvas: half an ulp of values < 1
+    assert torch.equal(d16, ip.doCrop(odn, xd))
+    rep['dn_l25_ms'] = round(_time_ms(lambda: ip.doCrop(odn, xd)), 2)
+    del pool
+    # ---- step 2: Net2x a2 on the engine's denoised frame --------------------------------------------------------------
+    plan2 = ip._plan_for(osr, d16.shape)
+    assert plan2.n_tiles == 144
+    y16 = torch.empty((3, 4320, 7680), dtype=torch.float16, device=dev)
+    pool = _pool_of(osr, plan2, d16, stitch_to=y16)
+    assert torch.equal(pool, _pool_of(osr, plan2, d16, per_batch=1))
+    opl2 = oplanner.prepare(shape, 1 << 40, 1e-3, 5, 2, 8, 256)
+    sd2 = gd.state_dict_for('a2', load_state_dict_file)
+    dn16 = d16.float().cpu().numpy()
+    off2 = plan2.tile_offsets(3)
+    for k in (40, 143):
+        top, bottom, left, right = plan2.tiles[k][:4]
+        want = onets.forward('net2x', sd2, np.ascontiguousarray(dn16[:, None, top:bottom, left:right])).numpy()[:, 0]
+        got = pool[off2[k]:off2[k] + want.size].view(want.shape).cpu().numpy()
+        assert np.abs(got - want).max() <= TOL, (k, float(np.abs(got - want).max()))
+    rep['sr_stitch_window_max_abs'] = _check_stitch_windows(pool, y16, plan2, opl2, 2, 3, 5e-4 + 1e-6)
+    assert torch.equal(y16, runSR.sr(osr)(d16))
+    rep['sr_a2_ms'] = round(_time_ms(lambda: ip.doCrop(osr, d16)), 2)
+    rep['chain_ms'] = round(rep['dn_l25_ms'] + rep['sr_a2_ms'], 2)
+    rep['input_mp_per_s'] = round(3840 * 2160 / 1e6 / (rep['chain_ms'] / 1e3), 2)
+    _report('config3_4k_l25_then_a2', rep)
+
+
+def test_config5_full_size_8k_to_32k(dev):
+    """BASELINE config 5 on one GPU: 7680x4320 RGB -> 30720x17280, a4, crop_sr = 512 -> 144 tiles (9 x 16), fp16 canvas of 3.19 GB
+    (the HBM-bound stitch path)."""
+    from moephoto_amd import _lib, imageProcess as ip
+    shape = (3, 4320, 7680)
+    xd = torch.from_numpy(gd.natural_image(51, shape)).to(dev).half()
+    opt = _opt_sr('a', 4, 512, fp16_io=True)
+    plan = ip._plan_for(opt, xd.shape)
+    assert plan.n_tiles == 144 and (plan.stepH, plan.stepW) == (9, 16)
+    assert (plan.outH, plan.outW) == (17280, 30720)
+    canvas = torch.empty((3, plan.outH, plan.outW), dtype=torch.float16, device=dev)
+    pool = _pool_of(opt, plan, xd, stitch_to=canvas)
+    pool1 = _pool_of(opt, plan, xd, per_batch=1)
+    assert torch.equal(pool, pool1)
+    del pool1
+    opl = oplanner.prepare(shape, 1 << 40, 1e-3, 5, 4, 8, 512)
+    assert [tuple(t) for t in opl.tiles] == [tuple(t) for t in plan.tiles]
+    sd = gd.state_dict_for('a4', load_state_dict_file)
+    x16 = xd.float().cpu().numpy()
+    off = plan.tile_offsets(3)
+    for k in (18, 143):                                                 # an interior 512x512 tile, the ragged corner
+        top, bottom, left, right = plan.tiles[k][:4]
+        want = onets.forward('net4x', sd, np.ascontiguousarray(x16[:, None, top:bottom, left:right])).numpy()[:, 0]
+        got = pool[off[k]:off[k] + want.size].view(want.shape).cpu().numpy()
+        assert np.abs(got - want).max() <= TOL, (k, float(np.abs(got - want).max()))
+    rep = {'stitch_window_max_abs': _check_stitch_windows(pool, canvas, plan, opl, 4, 3, 5e-4 + 1e-6)}
+    rep['frame_ms'] = round(_time_ms(lambda: ip.doCrop(opt, xd), reps=2), 2)
+    rep['input_mp_per_s'] = round(7680 * 4320 / 1e6 / (rep['frame_ms'] / 1e3), 2)
+    L = _lib.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    ms = _time_ms(lambda: _lib.check(L.moe_stitch(plan._h, 0, pool.data_ptr(), None, 3, canvas.data_ptr(), _lib.F16, stream)), reps=5)
+    alg = 3.0 * plan.outH * plan.outW * (4 + 2)                          # every HR pixel read once (fp32 tile) and written once (fp16)
+    rep['stitch_ms'] = round(ms, 3)
+    rep['stitch_algorithmic_gb_per_s'] = round(alg / (ms / 1e3) / 1e9, 1)
+    rep['stitch_pool_bytes_read_gb_per_s'] = round((plan.pool_elems(3) * 4 + 3.0 * plan.outH * plan.outW * 2) / (ms / 1e3) / 1e9, 1)
+    _report('config5_8k_to_32k_a4_512', rep)
+    assert rep['stitch_algorithmic_gb_per_s'] >= 1500, rep
+
+
+# ---- multi-GPU path with real engine calls, ranks sharing this GPU -------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _shared_gpu_env():
+    env = dict(os.environ, MOE_FORCE_DEVICE='0', MOE_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    return env
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_dist_ranks_sharing_one_gpu(world, dev):
+    """dist.run_frames with `world` processes on this GPU: owner-sharded moe_run_plan_tiles into the exchange buffer, the all-to-all
+    (gloo, staged through the host), moe_stitch_dev from the buffer -- every stitched frame bit-equal to the single-process doCrop."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', 'dist_gpu_worker.py')]
+    p = subprocess.run(cmd, cwd=ROOT, env=_shared_gpu_env(), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    for r in range(world):
+        assert 'RANK {} OK'.format(r) in p.stdout, p.stdout[-2000:]
+
+
+def test_bench_gpus2_started_plainly(dev):
+    """`python bench.py --gpus 2` with NO torchrun around it (the way the driver starts its N = 1 run): it must re-launch itself as two
+    ranks, run the sharded step, and rank 0 must print one JSON line with n_gpus 2 whose parity gate ran."""
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--sustain', '0', '--cpu-tiles', '9']
+    t0 = time.time()
+    p = subprocess.run(cmd, cwd=ROOT, env=_shared_gpu_env(), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{') and '"metric"' in l]
+    assert len(lines) == 1, p.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['config']['frames_per_step'] == 2 and res['scaling'] == 'weak'
+    assert res['config']['parity_ok'] is True and res['config']['parity']['natural']['worst_max_abs'] <= TOL
+    assert res['value'] > 0 and res['steps'] == 2
+    _report('bench_gpus2_shared_gpu', {'value': res['value'], 'ms_per_step': res['ms_per_step'], 'wall_s': round(time.time() - t0, 1)})
