@@ -61,8 +61,8 @@ MFLOP_PER_PX_PLANE = 3.9456          # Net4x conv FLOPs per LR pixel per plane (
 PARITY_TOL = 1e-3
 # bracketed layer groups: (profile substring, label, algorithmic FLOPs per LR pixel and plane)
 GROUPS = [
-    ('convt_R1.up1', 'R-branch 3x3 64->256 @2x res (+bias +PixelShuffle(2) +PReLU, fused 64->1 tail with split activations: conv3x3 EPI 7)', 4 * 2 * 256 * 64 * 9),
-    ('u.up1', 'U-branch 3x3 64->256 @2x res (+bias +PixelShuffle(2) +PReLU, fused 64->1 tail: conv3x3 EPI 3)', 4 * 2 * 256 * 64 * 9),
+    ('convt_R1.up1', 'R-branch 3x3 64->256 @2x res (+bias +PixelShuffle(2) +PReLU, fused 64->1 tail as phase-class sums, split activations: conv3x3_rw EPI 7)', 4 * 2 * 256 * 64 * 9),
+    ('u.up1', 'U-branch 3x3 64->256 @2x res (+bias +PixelShuffle(2) +PReLU, fused 64->1 tail as phase-class sums: conv3x3_rw EPI 3)', 4 * 2 * 256 * 64 * 9),
     ('arsb', 'arsb_fused_kernel (one ARSB per launch: two 3x3 64->64 convs @1x res + PReLU + hi/lo residual stream; 5 of 6 ARSBs)', 5 * 2 * 2 * 64 * 64 * 9),
 ]
 

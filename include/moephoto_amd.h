@@ -118,7 +118,7 @@ int moe_net_set_profile(moe_net* net, const char* layer_substrings);
 int moe_net_get_profile_at(moe_net* net, int index, double* total_ms, int64_t* launches, double* flops);
 int moe_net_get_profile(moe_net* net, double* total_ms, int64_t* launches, double* flops);
 /* MOE_PREC_MIXED only: how many leading ARSBs run with split operands (0..6; -1 = the architecture's default:
- * Net2x 6, Net3x 2, Net4x 1, NetDN 1).  Takes effect at the next forward. */
+ * Net2x 4, Net3x 2, Net4x 1, NetDN 1).  Takes effect at the next forward. */
 int moe_net_set_exact_blocks(moe_net* net, int blocks);
 /* Kernel-form switches of one net, for A/B measurements and the parity tests that compare forms of one layer in-process
  * ("sp_impl" = "auto" | "rw" | "sp", "arsb_fuse" / "x3_fuse" / "conv1x1" / "fuse_tail" / "sedn_fuse" / "pool_fuse" = "0" | "1",

@@ -55,12 +55,38 @@ struct ConvArgs {
     // fused tail (conv3x3_sp EPI 3): A fragments of the 64->1 tail conv and the planar fp32 per-tap sums [9][B][H*r][W*r]
     const half_t* tail_w;
     float* tplanes;
+    int tail_form;        // fused tail output: 0 nine tap planes per phase (conv3x3_sp EPI 3/7, tapsum2 / tapsum<R>), 1 phase-class sums + aprons
+                          // (conv3x3_rw EPI 3/7, r == 2, layout tailsum_layout(B, H, W) behind `tplanes`, gathered by tapsum4)
     int tail_split;       // fused tail: also split the activation operand (EPI 7; tail_w then holds eight fragments, the second four = fp16 weights in rows 16..24)
     int dbg;              // timing ablations (MOE_DBG env; results are wrong when set): 1 no patch DMA, 2 no MFMA, 4 no stores, 8 no epilogue
     // conv3x3_rw, PReLU epilogue, one chunk, r = 1 only: per-plane channel sums of the STORED (fp16) output, pool[b][slab][64] with
     // slab = 2 * workgroup + row half, zeroed by the caller, pool_slabs >= 2 * G (SEDN's fused block tail needs them, sedn_fuse)
     float* pool; int pool_slabs;
 };
+
+// Fused tail, "phase-class sums" form (tests/tailsum_model.py states the arithmetic).  One branch's buffer, fp32 ELEMENT offsets:
+//   S  [4 phases][4 classes][B][H][W]      sums of the per-tap products that land on output pixels of one parity class, formed inside a patch
+//   RA [4][2][B][py][W]                    row aprons: what patch row pyi exports to the vertically adjacent patch's edge row (classes (1, cj))
+//   CA [4][2][B][H][px]                    column aprons (classes (ci, 1)),   CO [4][B][py][px]  the corner term of class (1, 1)
+// H, W: the conv's INPUT size (HR = 2H x 2W), py / px: patches of kTileH x kTileW
+struct TailSumLayout { unsigned S, RA, CA, CO, total; int py, px; };
+__host__ __device__ inline TailSumLayout tailsum_layout(int B, int H, int W)
+{
+    TailSumLayout l;
+    l.py = (H + kTileH - 1) / kTileH; l.px = (W + kTileW - 1) / kTileW;
+    auto up = [](unsigned long long n) { return (unsigned)((n + 63) / 64 * 64); };
+    l.S = 0;
+    l.RA = l.S + up(16ull * B * H * W);
+    l.CA = l.RA + up(8ull * B * l.py * W);
+    l.CO = l.CA + up(8ull * B * H * l.px);
+    l.total = l.CO + up(4ull * B * l.py * l.px);
+    return l;
+}
+inline bool tailsum_fits(int B, int H, int W)      // 32-bit byte offsets into the whole buffer
+{
+    const unsigned long long el = 16ull * B * H * W + 8ull * B * ((H + kTileH - 1) / kTileH) * W + 8ull * B * H * ((W + kTileW - 1) / kTileW) + 4ull * B * ((H + kTileH - 1) / kTileH) * ((W + kTileW - 1) / kTileW) + 4 * 64;
+    return el * 4 < (1ull << 32) - (1ull << 17);
+}
 
 // 1x1 convs of lite (conv1x1.hip): 64 (48 real) input channels, one chunk (r = 1) or four (r = 2, pixel shuffle folded into the store),
 // fp16 or split operands, optionally the 48->1 tail conv folded in (one fp32 plane [B][2H][2W] of complete dot products)
@@ -161,6 +187,7 @@ struct TapSumArgs {
     void* y; int y_dtype; const long long* y_off;
     int B, H, W;   // HR size
     int r;         // pixel-shuffle factor of the producing conv (2 or 3)
+    int form;      // 0: nine tap planes per phase, 1: phase-class sums + aprons (r == 2; t0 / t1 are tailsum_layout buffers)
     int vec_ok;    // r == 2 and every output row start is 16-byte aligned: the 8-outputs-per-thread kernel may be used
 };
 void launch_tapsum(const TapSumArgs& a, hipStream_t s);

@@ -84,7 +84,7 @@ struct NetOptions {
     int conv_impl = 2;        // conv_impl   sp (2, default: the fast 3x3 kernels) | v1 (0: the generic kernel everywhere; debugging, not with 'mixed')
     int sp_impl = 1;          // sp_impl     auto (1: conv3x3_rw where it wins) | rw (2: conv3x3_rw for every epilogue it compiles) | sp (0: conv3x3_sp only)
     int tail_split = 1;       // tail_split  0 | r (1, default: the R branch's fused tail also splits its activation operand) | ru (2)
-    int tail_form = 0;        // tail_form   sums (1: phase-class sums + aprons from conv3x3_rw, tapsum4) | planes (0: nine tap planes per phase, tapsum2)
+    int tail_form = 1;        // tail_form   sums (1, default: phase-class sums + aprons from conv3x3_rw, tapsum4) | planes (0: nine tap planes per phase, tapsum2)
     bool conv1x1 = true;      // conv1x1     lite's 1x1 layers on conv1x1.hip (0: generic kernel)
     bool x3_fuse = true;      // x3_fuse     split-operand 3x3 64->64 layers as ONE launch (conv64_x3.hip; 0: three launches)
     bool arsb_fuse = true;    // arsb_fuse   single-pass ARSBs as one launch (arsb_fused.hip; 0: two launches)
@@ -92,7 +92,7 @@ struct NetOptions {
     bool sedn_fuse = true;    // sedn_fuse   SEDN's fused block tail
     bool pool_fuse = true;    // pool_fuse   SE / FRM channel sums out of the producing conv's epilogue
     int exact_blocks_env = -1;   // MOE_EXACT_BLOCKS (moe_net_set_exact_blocks overrides)
-    int tiles_per_batch = 0;  // tiles_per_batch   tiles of 256^2 pixels per launch set when the caller passes 0 (0: 8)
+    int tiles_per_batch = 0;  // tiles_per_batch   tiles of 256^2 pixels per launch set when the caller passes 0 (0: 16)
     int max_groups = 0;       // max_groups  persistent workgroups per launch (0: one per CU), applied at finalize
     int dbg = 0;              // dbg         timing-ablation bits of the conv kernels (results are wrong when set)
     std::string trace_key = "convt_R1.up1";
@@ -563,6 +563,7 @@ struct Fwd {
     half_t* side16 = nullptr;    // fp16 sum of the two low-order products of a 3x3 conv (split precision), output layout
     bool dry() const { return ar.base == nullptr; }
     int tail1_parts = 2;         // partial planes per branch the fused 1x1 tail wrote (conv_mfma_kernel: 2, conv1x1.hip: 1)
+    int tail_form = 0;           // fused tail of this forward: 0 nine tap planes (conv3x3_sp), 1 phase-class sums (conv3x3_rw + tapsum4)
     float* pool_out = nullptr;   // set around a conv() call: let the conv pool its output per plane (conv64_x3's pooled epilogue), [B][pool_slabs][64]
     int pool_slabs = 0;
     bool pool_done = false;      // the conv did
@@ -662,7 +663,7 @@ struct Fwd {
         a.slope = L.slope; a.scale = L.scale;
         const int dbg = n.opt.dbg;
         a.dbg = dbg;
-        a.tail_w = tail_w; a.tplanes = tplanes;
+        a.tail_w = tail_w; a.tplanes = tplanes; a.tail_form = tplanes ? tail_form : 0;
         a.tail_split = (tplanes && mixed && tail_split_for(key)) ? 1 : 0;
         a.tail1_w = tail1_w; a.tail1_out = tail1_out;
         if (pool_out && !x3 && L.r == 1 && L.nchunks == 1 && !res) { a.pool = pool_out; a.pool_slabs = pool_slabs; }      // conv3x3_rw's pooled epilogue (SEDN rblock.2)
@@ -672,11 +673,15 @@ struct Fwd {
         if (tplanes && !(fast && !x3)) return false;
         bool fused_ok = true;
         // PReLU-only epilogues (first upsampler stage of Net4x, SEDN's rblock convs) run on the register-resident-weights kernel
-        // (conv3x3_rw.hip: 6 % faster there); its fused-tail variant is 4 % slower than conv3x3_sp's and only used with MOE_SP_IMPL=rw;
-        // MOE_SP_IMPL=sp: everything on conv3x3_sp (A/B)
+        // (conv3x3_rw.hip: 6 % faster there), and so does the fused tail in its phase-class-sums form (tail_form = sums); option
+        // sp_impl = sp keeps the PReLU epilogues on conv3x3_sp (A/B)
         const int rw_mode = n.opt.sp_impl;
         auto launch = [&](const ConvArgs& ca) {
-            if (fast && rw_mode && (rw_mode == 2 || !ca.tplanes) && launch_conv3x3_rw(ca, s)) { pool_done = ca.pool != nullptr; return; }
+            if (ca.tplanes && ca.tail_form == 1) {       // phase-class sums: conv3x3_rw is the only producer of that buffer layout
+                if (!(fast && launch_conv3x3_rw(ca, s))) fused_ok = false;
+                return;
+            }
+            if (fast && rw_mode && !ca.tplanes && launch_conv3x3_rw(ca, s)) { pool_done = ca.pool != nullptr; return; }
             if (fast && launch_conv3x3_sp(ca, s)) return;
             if (ca.tplanes) { fused_ok = false; return; }
             launch_conv_mfma(ca, L.taps, L.nseg, s);
@@ -800,7 +805,8 @@ int exact_blocks_of(const moe_net& n)
     const int env = n.opt.exact_blocks_env;
     if (env >= 0) return env > 6 ? 6 : env;
     switch (n.arch) {
-        case MOE_ARCH_NET2X: return 6;
+        case MOE_ARCH_NET2X: return 4;      // measured on the GPU, worst tile of three 1080p uint8-noise frames vs the exact mode: 1.6e-3 / 1.3e-3 / 8.8e-4 / 7.0e-4 / 5.3e-4
+                                            // with 1 / 2 / 3 / 4 / 6 blocks at 14.4 / 16.0 / 17.6 / 19.0 / 22.2 ms per frame (profiles/r03): 4 keeps 30 % of margin
         case MOE_ARCH_NET3X: return 2;
         case MOE_ARCH_NET4X: return 1;
         case MOE_ARCH_NETDN: return 1;
@@ -948,13 +954,24 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         float* tp[2] = {nullptr, nullptr};
         const bool fuse = can_fuse_tail(n, f, B, h, w);      // last upsampler conv + 64->1 tail conv in one kernel
         int H = h, W = w;
+        {   // form of the fused tail's output: phase-class sums when the last stage is a x2 shuffle the register-weight kernel takes
+            int hl = h, wl = w;
+            for (int st = 0; st + 1 < n.stages; ++st) { hl *= n.r; wl *= n.r; }
+            bool ok = fuse && n.opt.tail_form == 1 && n.r == 2 && wl % 4 == 0 && tailsum_fits(B, hl, wl) &&
+                      2ll * B * hl * wl * 64 + 2ll * (wl + 1) * 64 < (1ll << 32) - 65536;
+            for (const char* br : {"u", "convt_R1"}) {
+                const auto it = n.conv_index.find(std::string(br) + ".up" + std::to_string(n.stages - 1));
+                ok = ok && it != n.conv_index.end() && n.convs[it->second].slope < 1.f;
+            }
+            f.tail_form = ok ? 1 : 0;
+        }
         for (int br = 0; br < 2; ++br) {
             Act cur = br == 0 ? Bb : A;
             H = h; W = w;
             for (int st = 0; st < n.stages; ++st) {
                 const std::string key = std::string(br == 0 ? "convt_R1" : "u") + ".up" + std::to_string(st);
                 if (fuse && st == n.stages - 1) {
-                    tp[br] = (float*)f.ar.take((size_t)9 * B * H * n.r * W * n.r * 4 + 4096);
+                    tp[br] = (float*)f.ar.take(f.tail_form == 1 ? (size_t)tailsum_layout(B, H, W).total * 4 + 4096 : (size_t)9 * B * H * n.r * W * n.r * 4 + 4096);
                     const half_t* frag = f.dry() ? nullptr : f.small<half_t>(br == 0 ? "tail_r.frag" : "tail_u.frag");
                     if (!f.conv(key, cur, Act{}, nullptr, H, W, nullptr, nullptr, frag, f.dry() ? (float*)16 : tp[br]))
                         return fail(MOE_EINVAL, "fused tail kernel rejected layer %s", key.c_str());
@@ -973,6 +990,7 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
             if (!f.dry()) {
                 TapSumArgs t{};
                 t.t0 = tp[0]; t.t1 = tp[1]; t.y = y; t.y_dtype = y_dtype; t.y_off = y_off_dev; t.B = B; t.H = H; t.W = W; t.r = n.r;
+                t.form = f.tail_form;
                 t.vec_ok = n.r == 2 && f.y_vec && W % 8 == 0;
                 launch_tapsum(t, s);
             }
@@ -1659,7 +1677,7 @@ int moe_run_plan_ex(moe_net* n, const moe_plan* pl, const void* img, int img_dty
         pool = p.pool;
     }
     if (max_tiles <= 0) {
-        max_tiles = n->opt.tiles_per_batch > 0 ? n->opt.tiles_per_batch : 8;      // (tiles of 256^2 pixels per launch set; 8 measured 1.8 % faster than 4 on the 1080p x4 frame: fewer pipeline fills per pixel)
+        max_tiles = n->opt.tiles_per_batch > 0 ? n->opt.tiles_per_batch : 16;     // (tiles of 256^2 pixels per launch set: 28.97 / 28.59 / 28.42 / 28.28 / 28.33 ms per 1080p x4 frame with 4 / 8 / 12 / 16 / 24, profiles/r03: fewer pipeline fills per pixel)
     }
     for (size_t gi = 0; gi < p.groups.size(); ++gi) {
         const auto& g = p.groups[gi];
@@ -1742,7 +1760,7 @@ int moe_run_plan_tiles(moe_net* n, const moe_plan* pl, const void* imgs, int img
         d->n_frames = n_frames; d->tile_dst.assign(tile_dst, tile_dst + nt * n_frames);
     }
     if (max_tiles <= 0) {
-        max_tiles = n->opt.tiles_per_batch > 0 ? n->opt.tiles_per_batch : 8;      // (tiles of 256^2 pixels per launch set; 8 measured 1.8 % faster than 4 on the 1080p x4 frame: fewer pipeline fills per pixel)
+        max_tiles = n->opt.tiles_per_batch > 0 ? n->opt.tiles_per_batch : 16;     // (tiles of 256^2 pixels per launch set: 28.97 / 28.59 / 28.42 / 28.28 / 28.33 ms per 1080p x4 frame with 4 / 8 / 12 / 16 / 24, profiles/r03: fewer pipeline fills per pixel)
     }
     for (size_t gi = 0; gi < p.groups.size(); ++gi) {
         const auto& g = p.groups[gi];

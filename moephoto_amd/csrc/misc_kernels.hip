@@ -342,6 +342,79 @@ __global__ __launch_bounds__(256) void tapsum2_kernel(TapSumArgs a)
     }
 }
 
+// Gather of the "phase-class sums" form (conv3x3_rw.hip EPI 3 / 7; the arithmetic is stated in tests/tailsum_model.py): an output pixel
+// (2y' + i', 2x' + j') is the sum over the four phases (i, j) and both branches of S_(i,j)[i' ^ i][j' ^ j][y'][x'] -- 32 bytes read per output
+// pixel instead of 72 -- plus, on patch edges, the aprons of the neighbouring patch in the fixed order S + RA + CA + CO.  One thread makes
+// the 8 consecutive outputs over 4 conv-input columns: per phase and branch two 16-byte loads (the class of the even and of the odd outputs).
+template <bool VEC>
+__global__ __launch_bounds__(256) void tapsum4_kernel(TapSumArgs a)
+{
+    const int h = a.H >> 1, w = a.W >> 1, nq = w >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)a.B * a.H * nq) return;
+    const int xq = (int)(idx % nq);
+    const int Y = (int)((idx / nq) % a.H), b = (int)(idx / ((long long)nq * a.H));
+    const int ip = Y & 1, yl = Y >> 1, x0 = xq * 4;
+    const TailSumLayout L = tailsum_layout(a.B, h, w);
+    const unsigned plane = (unsigned)(a.B * h * w);
+    const unsigned row = (unsigned)((b * h + yl) * w + x0);
+    const int pyi = yl / kTileH, rho = yl - pyi * kTileH, pxi = x0 / kTileW, chi = x0 - pxi * kTileW;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int br = 0; br < 2; ++br) {
+        const float* t = br ? a.t1 : a.t0;
+        if (!t) continue;
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+            const int i = ph >> 1, j = ph & 1, ci = ip ^ i;
+            const int sv = i == 0 ? 1 : -1, sh = j == 0 ? 1 : -1;
+            const float* S = t + L.S + (unsigned)(ph * 4 + 2 * ci) * plane + row;
+            float4 e = *(const float4*)(S + (unsigned)j * plane);            // class (ci, j' ^ j) of the even outputs (j' = 0)
+            float4 o = *(const float4*)(S + (unsigned)(1 ^ j) * plane);      // ... of the odd outputs
+            const int pyn = pyi + sv, pxn = pxi + sh;
+            const bool rowfix = ci == 1 && rho == (sv == 1 ? kTileH - 1 : 0) && pyn >= 0 && pyn < L.py;
+            const bool colfix = chi == (sh == 1 ? kTileW - 4 : 0) && pxn >= 0 && pxn < L.px;      // the quad that holds the patch's edge column
+            if (rowfix) {
+                const float* RA = t + L.RA + (unsigned)(ph * 2) * (unsigned)(a.B * L.py * w) + (unsigned)((b * L.py + pyn) * w + x0);
+                const float4 r0 = *(const float4*)(RA + (unsigned)j * (unsigned)(a.B * L.py * w));
+                const float4 r1 = *(const float4*)(RA + (unsigned)(1 ^ j) * (unsigned)(a.B * L.py * w));
+                e.x += r0.x; e.y += r0.y; e.z += r0.z; e.w += r0.w;
+                o.x += r1.x; o.y += r1.y; o.z += r1.z; o.w += r1.w;
+            }
+            if (colfix) {      // the class with cj = 1 is the odd outputs' for j = 0, the even outputs' for j = 1; its edge element is the quad's last (sh = +1) / first
+                float fix = t[L.CA + (unsigned)(ph * 2 + ci) * (unsigned)(a.B * h * L.px) + (unsigned)((b * h + yl) * L.px + pxn)];
+                float4& q = j == 0 ? o : e;
+                float& el = sh == 1 ? q.w : q.x;
+                el += fix;
+                if (rowfix) el += t[L.CO + (unsigned)ph * (unsigned)(a.B * L.py * L.px) + (unsigned)((b * L.py + pyn) * L.px + pxn)];
+            }
+            acc[0] += e.x; acc[1] += o.x; acc[2] += e.y; acc[3] += o.y;
+            acc[4] += e.z; acc[5] += o.z; acc[6] += e.w; acc[7] += o.w;
+        }
+    }
+    const long long yo = (a.y_off ? a.y_off[b] : (long long)b * a.H * a.W) + (long long)Y * a.W + 2 * x0;
+    if (a.y_dtype == MOE_F16) {
+        if (VEC) {
+            half8_t v;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = (half_t)acc[k];
+            *(half8_t*)((half_t*)a.y + yo) = v;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ((half_t*)a.y)[yo + k] = (half_t)acc[k];
+        }
+    } else {
+        float* yp = (float*)a.y + yo;
+        if (VEC) {
+            *(float4*)yp = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            *(float4*)(yp + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) yp[k] = acc[k];
+        }
+    }
+}
+
 // Fused 1x1 tail (lite): y = sum of the four partial planes (two branches x two 32-channel halves), fixed order.
 __global__ __launch_bounds__(256) void tail1sum_kernel(Tail1SumArgs a)
 {
@@ -909,6 +982,12 @@ void launch_tail(const TailArgs& a, hipStream_t s)
 
 void launch_tapsum(const TapSumArgs& a, hipStream_t s)
 {
+    if (a.form == 1) {          // phase-class sums (r == 2, W % 8 == 0 by construction: the producing conv requires input widths that are multiples of 4)
+        const long long n = (long long)a.B * a.H * (a.W / 8);
+        if (a.vec_ok) tapsum4_kernel<true><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(a);
+        else tapsum4_kernel<false><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(a);
+        return;
+    }
     const dim3 grid((a.W + 255) / 256, a.H, a.B);
     if (a.r == 3) tapsum_kernel<3><<<grid, dim3(256), 0, s>>>(a);
     else if (a.vec_ok) {

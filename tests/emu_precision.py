@@ -187,7 +187,7 @@ def lite_budget(keys=('lite2', 'lite4', 'lite8')):
             print(line, flush=True)
 
 
-DEFAULT_EXACT = {'net2x': 6, 'net3x': 2, 'net4x': 1, 'netdn': 1}      # == exact_blocks_of() in engine.cpp
+DEFAULT_EXACT = {'net2x': 4, 'net3x': 2, 'net4x': 1, 'netdn': 1}      # == exact_blocks_of() in engine.cpp
 
 
 def _load(key):

@@ -5,10 +5,10 @@ cd "$(dirname "$0")/.."
 cp moephoto_amd/libmoephoto_amd.so /tmp/lib_product.so
 run() {
   cp "$2" moephoto_amd/libmoephoto_amd.so
-  timeout 300 python bench.py --steps ${AB_STEPS:-10} --warmup 3 --no-cpu-baseline --sustain 0 --no-noise-input 2>/dev/null | python -c "
+  timeout 300 python bench.py --steps ${AB_STEPS:-10} --warmup 3 --no-cpu-baseline --sustain 0 --no-noise-input --no-dropin-loop 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('$1', 'ms_per_step', d['ms_per_step'], 'up1 avg ms', d['roofline']['avg_launch_ms'], 'frac', d['roofline']['frac'], 'arsb avg ms', d.get('roofline_trunk',{}).get('avg_launch_ms'))"
+print('$1', 'ms_per_step', d['ms_per_step'], [(k['layer_key'], k['ms_per_frame']) for k in d.get('roofline_kernels', [])])"
 }
 for rep in 1 2; do
   args=("$@")
