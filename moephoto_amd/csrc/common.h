@@ -143,6 +143,18 @@ struct ConvX3Args {
 bool launch_conv64_x3(ConvX3Args a, int max_groups, hipStream_t s);   // false: not applicable (caller uses the three-launch form)
 hipError_t conv64_x3_init();
 
+// Workgroup count of a launch whose epilogue pools per plane into per-workgroup slabs (conv3x3_rw EPI 4, conv64_x3 EPI 3): a multiple or a divisor
+// of the patches per plane P, so that the patch -> workgroup map (item % G with item = plane * P + k) -- and with it every slab's content and
+// summation order -- does not depend on how many planes share the launch.  (The SE / FRM gates feed fp16-rounded weights and multipliers: with
+// batch-dependent sums the last bit of a gate moved and SEDN's output with it by up to 5e-4; now a tile's result is independent of its launch set.)
+inline int pooled_groups(long long P, long long items, int max_groups)
+{
+    long long G = 1;
+    if (P <= max_groups) G = P * (max_groups / P);
+    else for (long long d = max_groups; d >= 1; --d) if (P % d == 0) { G = d; break; }
+    return (int)(G < items ? G : items);
+}
+
 struct DirectConvArgs {
     const half_t* in; half_t* out; const half_t* res;
     const float* w;       // plain fp32 OIHW weights [cout][cin][k][k] (original channel counts)

@@ -312,7 +312,7 @@ bool launch_conv64_x3(ConvX3Args a, int max_groups, hipStream_t s)
     a.px = (a.W + TW - 1) / TW;
     a.py = (a.H + TH - 1) / TH;
     const long long items = (long long)a.B * a.px * a.py;
-    const int G = (int)std::min<long long>(items, max_groups);
+    const int G = a.pool ? pooled_groups((long long)a.px * a.py, items, max_groups) : (int)std::min<long long>(items, max_groups);
     const dim3 grid(G), blk(256);
     if (a.pool && (a.res_hi || a.slope != 1.f || a.pool_slabs < G)) return false;
     if (a.pool) conv64_x3_kernel<3><<<grid, blk, LDS_BYTES, s>>>(a);

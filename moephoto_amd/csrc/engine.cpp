@@ -666,7 +666,10 @@ struct Fwd {
         a.tail_w = tail_w; a.tplanes = tplanes; a.tail_form = tplanes ? tail_form : 0;
         a.tail_split = (tplanes && mixed && tail_split_for(key)) ? 1 : 0;
         a.tail1_w = tail1_w; a.tail1_out = tail1_out;
-        if (pool_out && !x3 && L.r == 1 && L.nchunks == 1 && !res) { a.pool = pool_out; a.pool_slabs = pool_slabs; }      // conv3x3_rw's pooled epilogue (SEDN rblock.2)
+        if (pool_out && !x3 && L.r == 1 && L.nchunks == 1 && !res) {      // conv3x3_rw's pooled epilogue (SEDN rblock.2)
+            a.pool = pool_out; a.pool_slabs = pool_slabs;
+            a.G = pooled_groups((long long)a.px * a.py, items, n.max_groups);      // slab contents independent of the launch's plane count (common.h)
+        }
         // 3x3 / 64-input-channel layers with shared weights run on the software-pipelined kernel (conv3x3_sp.hip); everything else
         // (1x1 convs, SEDN's per-plane `trans`, epilogues that kernel does not compile, MOE_CONV_IMPL=v1) on the generic one
         const bool fast = L.taps == 9 && L.nseg == 1 && !L.per_plane && n.opt.conv_impl == 2;

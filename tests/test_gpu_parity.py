@@ -800,6 +800,35 @@ def test_kernel_forms_agree(dev):
                 assert np.abs(y1 - want).max() <= 2e-5, (key, float(np.abs(y1 - want).max()))
 
 
+def test_fused_tail_sums_vs_planes(dev):
+    """The two forms of the fused 64->1 tail compute the same nine products per HR pixel and differ only in the association of their fp32 sum
+    (tests/tailsum_model.py): phase-class sums + aprons (conv3x3_rw EPI 3 / 7 + tapsum4) against nine tap planes (conv3x3_sp EPI 3 / 7 + tapsum2) on
+    shapes that put patch seams, ragged last patches (H % 8, W % 32 != 0: the masked kernel variant), single-patch images and several planes
+    into play, with and without the activation split of the R branch.  The main convs of the two forms (conv3x3_rw / conv3x3_sp) accumulate in different
+    orders, which flips an fp16 rounding of an activation now and then (one ulp of it times a tail weight): the forms agree to ~1e-4, a misplaced apron
+    would show as 1e-2."""
+    cases = [('a2', (3, 8, 32)), ('a2', (2, 20, 44)), ('a2', (1, 72, 136)), ('a2', (5, 16, 64)), ('a2', (3, 12, 100)), ('a2', (1, 8, 8)),
+             ('a4', (3, 8, 16)), ('a4', (2, 20, 44)), ('a4', (1, 40, 72)), ('a4', (3, 24, 36))]
+    for key, shape in cases:
+        arch, sd = gd.MODELS[key][0], gd.state_dict_for(key, load_state_dict_file)
+        for kind in ('natural', 'noise'):
+            x = (gd.natural_image(41, shape) if kind == 'natural' else gd.noise_image(41, shape))[:, None]
+            xd = torch.from_numpy(x).to(dev)
+            want = onets.forward(arch, sd, x).numpy()
+            for prec, split in (('mixed', 'r'), ('mixed', '0'), ('fp16', 'r')):
+                m = module_for(key, prec)
+                try:
+                    m.set_option('tail_split', split)
+                    ys = m.set_option('tail_form', 'sums')(xd)[-1].cpu().numpy()
+                    yp = m.set_option('tail_form', 'planes')(xd)[-1].cpu().numpy()
+                finally:
+                    m.set_option('tail_form', 'sums').set_option('tail_split', 'r')
+                scale = max(1.0, float(np.abs(want).max()))
+                assert np.abs(ys - yp).max() <= (2.5e-4 if kind == 'natural' else 6e-4) * scale, (key, shape, kind, prec, split, float(np.abs(ys - yp).max()))
+                if prec == 'mixed' and split == 'r':
+                    assert np.abs(ys - want).max() <= TOL, (key, shape, kind, float(np.abs(ys - want).max()))
+
+
 def test_split_operand_conv_single_launch(dev):
     """conv64_x3.hip (the three split-operand products of a 3x3 64->64 layer in one launch, both weight parts in registers) against the
     three-launch form (option x3_fuse = 0) and the oracle: every epilogue (plain = conv_input2, PReLU = conv_1, residual = conv_2), ragged
