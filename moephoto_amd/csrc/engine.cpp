@@ -87,7 +87,8 @@ struct NetOptions {
     int tail_form = 1;        // tail_form   sums (1, default: phase-class sums + aprons from conv3x3_rw, tapsum4) | planes (0: nine tap planes per phase, tapsum2)
     bool conv1x1 = true;      // conv1x1     lite's 1x1 layers on conv1x1.hip (0: generic kernel)
     bool x3_fuse = true;      // x3_fuse     split-operand 3x3 64->64 layers as ONE launch (conv64_x3.hip; 0: three launches)
-    bool arsb_fuse = true;    // arsb_fuse   single-pass ARSBs as one launch (arsb_fused.hip; 0: two launches)
+    bool arsb_fuse = true;    // arsb_fuse   single-pass ARSBs as one launch (0: two launches)
+    int arsb_impl = 1;        // arsb_impl   v1 (1: arsb_fused.hip, 16x16x32 MFMAs, wave = 16 channels) | v2 (2: arsb32.hip, 32x32x16 MFMAs, waves in lock-step)
     bool fuse_tail = true;    // fuse_tail   last upsampler conv + 64->1 / 48->1 tail conv in one kernel
     bool sedn_fuse = true;    // sedn_fuse   SEDN's fused block tail
     bool pool_fuse = true;    // pool_fuse   SE / FRM channel sums out of the producing conv's epilogue
@@ -116,6 +117,7 @@ struct NetOptions {
         if (key == "sp_impl") { const int t = tri(v, "sp", "auto", "rw", -1); if (t < 0) return false; sp_impl = t; return true; }
         if (key == "tail_split") { const int t = tri(v, "0", "r", "ru", -1); if (t < 0) return false; tail_split = t; return true; }
         if (key == "tail_form") { const int t = tri(v, "planes", "sums", nullptr, -1); if (t < 0) return false; tail_form = t; return true; }
+        if (key == "arsb_impl") { const int t = tri(v, nullptr, "v1", "v2", -1); if (t < 1) return false; arsb_impl = t; return true; }
         if (key == "conv1x1") return flag(conv1x1);
         if (key == "x3_fuse") return flag(x3_fuse);
         if (key == "arsb_fuse") return flag(arsb_fuse);
@@ -131,7 +133,7 @@ struct NetOptions {
     void from_env()
     {
         static const char* const names[][2] = {{"MOE_CONV_IMPL", "conv_impl"}, {"MOE_SP_IMPL", "sp_impl"}, {"MOE_TAIL_SPLIT", "tail_split"}, {"MOE_TAIL_FORM", "tail_form"},
-                                               {"MOE_CONV1X1", "conv1x1"}, {"MOE_X3_FUSE", "x3_fuse"}, {"MOE_ARSB_FUSE", "arsb_fuse"}, {"MOE_FUSE_TAIL", "fuse_tail"},
+                                               {"MOE_CONV1X1", "conv1x1"}, {"MOE_ARSB_IMPL", "arsb_impl"}, {"MOE_X3_FUSE", "x3_fuse"}, {"MOE_ARSB_FUSE", "arsb_fuse"}, {"MOE_FUSE_TAIL", "fuse_tail"},
                                                {"MOE_SEDN_FUSE", "sedn_fuse"}, {"MOE_POOL_FUSE", "pool_fuse"}, {"MOE_DBG", "dbg"}, {"MOE_TRACE_KEY", "trace_key"},
                                                {"MOE_TILES_PER_BATCH", "tiles_per_batch"}, {"MOE_MAX_GROUPS", "max_groups"}};
         for (const auto& nv : names)
@@ -929,7 +931,12 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
                     const size_t tb = 8 * 16 * 4 * 40 * 8;
                     if (trace && i == 3 && hipMalloc((void**)&q.trace, tb) == hipSuccess) (void)hipMemsetAsync(q.trace, 0, tb, s);
                     const int rec = f.prof_begin("arsb" + std::to_string(i), 2.0 * 2.0 * (double)B * h * w * L1.cout * L1.cin * 9);
-                    done = launch_arsb_fused(q, n.max_groups, s);
+                    if (n.opt.arsb_impl == 2) {
+                        ArsbArgs q2 = q;
+                        q2.w1 = f.blob<half_t>(L1.w_hi); q2.w2 = f.blob<half_t>(L2.w_hi);      // (pack_conv order; conv_2's carry the ScaleLayer factor as well)
+                        done = launch_arsb32(q2, n.max_groups, s);
+                    }
+                    if (!done) done = launch_arsb_fused(q, n.max_groups, s);
                     f.prof_end(rec);
                     if (q.trace) {
                         std::vector<unsigned long long> host(tb / 8);

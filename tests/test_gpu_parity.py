@@ -660,8 +660,10 @@ def test_rccl_path_world1(dev):
         dist.destroy_process_group()
 
 
-def test_fused_arsb_matches_two_launch_form(dev):
-    """The fused ARSB kernel (conv_1 -> PReLU -> conv_2 -> + x in one launch, weights in registers) against the two-launch form of
+@pytest.mark.parametrize('impl', ['v1', 'v2'])
+def test_fused_arsb_matches_two_launch_form(impl, dev):
+    """impl v1 = arsb_fused.hip (16x16x32 MFMAs, wave = 16 channels), v2 = arsb32.hip (32x32x16 MFMAs, waves in lock-step).
+    The fused ARSB kernel (conv_1 -> PReLU -> conv_2 -> + x in one launch, weights in registers) against the two-launch form of
     the same arithmetic (option arsb_fuse = 0) and the oracle: ragged shapes (patches are 8 x 30 outputs), 48- and 64-channel nets,
     with and without the hi+lo stream."""
     cases = [('a2', (3, 8, 16)), ('a2', (3, 24, 40)), ('a2', (2, 40, 264)), ('a2', (3, 9, 35)), ('a2', (5, 88, 64)), ('dn_lite5', (3, 16, 64)), ('dn_lite5', (3, 33, 31))]
@@ -677,6 +679,7 @@ def test_fused_arsb_matches_two_launch_form(dev):
                 for prec, nb in (('fp16', -1), ('mixed', 0), ('mixed', -1)):
                     m = module_for(key, prec).set_exact_blocks(nb)
                     touched.append(m)
+                    m.set_option('arsb_impl', impl)
                     y0 = m.set_option('arsb_fuse', 0)(xd)[-1].cpu().numpy()
                     y1 = m.set_option('arsb_fuse', 1)(xd)[-1].cpu().numpy()
                     m.set_exact_blocks(-1)
@@ -695,7 +698,7 @@ def test_fused_arsb_matches_two_launch_form(dev):
                         assert np.abs(y1 - want).max() <= TOL, (key, shape, kind, float(np.abs(y1 - want).max()))
     finally:
         for m in touched:
-            m.set_option('arsb_fuse', 1).set_exact_blocks(-1)
+            m.set_option('arsb_fuse', 1).set_option('arsb_impl', 'v1').set_exact_blocks(-1)
 
 
 RESIZE = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(G, 'resize', '*.npz')) if 'scale_factors' not in p)
