@@ -71,38 +71,64 @@ constexpr OpList mrow_ops(int i)
     r.push(OP_P, i, 4, 2); r.push(OP_P, i, 6, 2); r.push(OP_MW, i, 1);
     return r;
 }
-// epilogue of output row i (of the wave's four), per 16-byte slot o: residual add in fp32, [hi/lo split by channel pairs,] store(s)
-constexpr OpList yrow_ops(int i, bool lo)
+// epilogue of slot o (eight channels of the lane's pixel) of output row i (of the wave's four): residual add in fp32 by halves, [hi/lo split by channel
+// pairs,] store(s).  The next row's x_hi word takes the register this row's has just released (ONE set of residual registers).
+constexpr OpList yslot_ops(int i, int o, bool lo)
 {
     OpList r;
-    for (int o = 0; o < 2; ++o) {
-        r.push(OP_RES, i, o);
-        if (i < 3) r.push(OP_XHI, i + 1, o);       // the next row's x_hi word takes the register this one has just released (ONE set of residual registers)
-        if (lo) { r.push(OP_SPL, i, o, 0); r.push(OP_SPL, i, o, 2); }
-        r.push(OP_ST, i, o);
-    }
+    r.push(OP_RES, i, o, 0); r.push(OP_RES, i, o, 2);
+    if (i < 3) r.push(OP_XHI, i + 1, o);
+    if (lo) { r.push(OP_SPL, i, o, 0); r.push(OP_SPL, i, o, 2); }
+    r.push(OP_ST, i, o);
     return r;
 }
-constexpr OpList conv1_ops(int s)              // row step s of conv_1 (x row 5h + s): 12, 24, 36, 36, 36, 24, 12 MFMAs
+constexpr OpList yrow_ops(int i, bool lo) { OpList r = yslot_ops(i, 0, lo); r.append(yslot_ops(i, 1, lo)); return r; }      // (slot after slot: they share sh / sl)
+// A row step has 12 chunks of 1, 2 or 3 MFMAs; an MFMA hides about five other instructions and an op is dealt to ONE chunk, so ops are kept to ~12
+// instructions (a DMA piece = address half + validity/issue half) and the steps with 12 MFMAs get as little as the dependences allow:
+//   * output rows 2 (slot 1) and 3 are finished by conv_2's last two row steps (24 + 12 MFMAs): their epilogues ride in row steps 0..2 of the NEXT patch's
+//     conv_1 (acc[2] / acc[3] are first written there in steps 2 / 3; the last patch of a workgroup runs them after the loop);
+//   * the x_lo words of a patch are fetched in conv_1's steps 4 and 5, thousands of cycles before conv_2's step 3 needs the first (loads and stores share
+//     vmcnt IN ORDER: issued behind a store they would wait for its acknowledgement; issued a step or two ahead of their use the wait showed in the
+//     trace as 1.3 - 2.2k cycles per patch);
+//   * DMA pieces 0..7 (patch rows 0 .. 7.5 of the next patch) go out behind barrier A in conv_1's steps 1..3 and land by barrier B; pieces 8..12 ride in
+//     conv_2's idle steps 0..2 and are published by the NEXT barrier A (conv_1 reads rows >= 7 from its step 1 on).
+constexpr OpList dma_ops(int i0, int i1)
 {
     OpList r;
-    if (s == 1) for (int i = 0; i < 4; ++i) r.push(OP_DMA, i);         // (behind barrier A)
-    if (s == 2) for (int i = 4; i < 9; ++i) r.push(OP_DMA, i);
-    if (s == 3) { OpList x; for (int i = 9; i < 13; ++i) x.push(OP_DMA, i); r = interleave(x, mrow_ops(0)); }
-    if (s >= 4) r = mrow_ops(s - 3);
+    for (int i = i0; i < i1; ++i) { r.push(OP_DMA, i, 0); r.push(OP_DMA, i, 1); }
+    return r;
+}
+constexpr OpList tail_ops(bool lo)             // what the next patch's conv_1 would have carried
+{
+    OpList r = yslot_ops(2, 1, lo);
+    r.append(yslot_ops(3, 0, lo)); r.append(yslot_ops(3, 1, lo));
+    return r;
+}
+constexpr OpList conv1_ops(int s, bool lo)     // row step s of conv_1 (x row 5h + s): 12, 24, 36, 36, 36, 24, 12 MFMAs
+{
+    OpList r, x;
+    if (s == 0) r = yslot_ops(2, 1, lo);
+    if (s == 1) r = interleave(dma_ops(0, 1), yslot_ops(3, 0, lo));      // (behind barrier A)
+    if (s == 2) r = interleave(dma_ops(1, 5), yslot_ops(3, 1, lo));
+    if (s == 3) r = interleave(dma_ops(5, 8), mrow_ops(0));
+    if (s == 4) { if (lo) { x.push(OP_XLO, 0, 0); x.push(OP_XLO, 0, 1); x.push(OP_XLO, 1, 0); x.push(OP_XLO, 1, 1); } r = interleave(x, mrow_ops(1)); }
+    if (s == 5) { if (lo) { x.push(OP_XLO, 2, 0); x.push(OP_XLO, 2, 1); x.push(OP_XLO, 3, 0); x.push(OP_XLO, 3, 1); } r = interleave(x, mrow_ops(2)); }
+    if (s == 6) r = mrow_ops(3);
     return r;
 }
 constexpr OpList conv2_ops(int s, bool lo)     // row step s of conv_2 (m row 4h + s): 12, 24, 36, 36, 24, 12 MFMAs
 {
-    OpList r, x;
-    // every x_lo word is fetched before the first store of the patch goes out (step 3): loads and stores share vmcnt
-    if (lo && s == 0) { r.push(OP_XLO, 0, 0); r.push(OP_XLO, 0, 1); }
-    if (lo && s == 1) { r.push(OP_XLO, 1, 0); r.push(OP_XLO, 1, 1); r.push(OP_XLO, 2, 0); }
-    if (lo && s == 2) { r.push(OP_XLO, 2, 1); r.push(OP_XLO, 3, 0); r.push(OP_XLO, 3, 1); }
-    if (s == 2) { r.push(OP_XHI, 0, 0); r.push(OP_XHI, 0, 1); }
-    if (s >= 3) r = yrow_ops(s - 3, lo);
+    OpList r;
+    if (s == 0) r = dma_ops(8, 9);
+    if (s == 1) r = dma_ops(9, 11);
+    if (s == 2) { r = dma_ops(11, 13); r.push(OP_XHI, 0, 0); r.push(OP_XHI, 0, 1); }
+    if (s == 3) r = yrow_ops(0, lo);
+    if (s == 4) r = yrow_ops(1, lo);
+    if (s == 5) r = yslot_ops(2, 0, lo);
     return r;
 }
+// stores in flight behind the last DMA piece of conv_2 when the next barrier A is reached (rows 0, 1, slot 0 of row 2; slot 1 of row 2 in conv_1's step 0)
+constexpr int stores_behind_dma(bool lo) { return lo ? 12 : 6; }
 
 struct Item { int b, pyi, pxi; };
 
@@ -182,13 +208,19 @@ __global__ __launch_bounds__(256) void arsb32_kernel(ArsbArgs a)
     // ride in the MFMA stream.  A per-lane table (13 registers, rebuilt when the patch cuts the image border differently: conv3x3_rw.hip) did not fit:
     // with both convs' weights resident the rebuild block spilled to scratch and cost 8,000 cycles on 44 % of the patches.
     const int qlane = w4 * 8 + (lane >> 3);
+    unsigned d_off = 0, d_r = 0, d_cc = 0;                    // DMA piece in the making: byte offset inside the patch, patch row / column of the lane's pixel
+    auto piece_addr = [&](int i) {
+        unsigned q = (unsigned)(i * 32 + qlane);
+        asm volatile("" : "+v"(q));                           // (recomputed per piece: hoisted out of the patch loop, the row / column of 13 pieces spill)
+        d_r = __umul24(q, 241u) >> 13;                        // q / 34 for q < 442   (24-bit multiplies: full rate, and cheap enough that the compiler
+        d_cc = (unsigned)(__mul24((int)d_r, -XW) + (int)q);     //  selects instead of branching around the offset -- a branch splits the pinned schedule)
+        const unsigned sl = (unsigned)(lane & 7) ^ ((d_cc >> 1) & 7u);      // logical 16-B slot behind this physical slot
+        d_off = ((__umul24(d_r, (unsigned)a.W) + d_cc) << 7) | (sl << 4);
+    };
     auto piece_off = [&](int i, int ya, int xa, bool live) {      // ya, xa: image row / column of the patch origin (wave-uniform)
-        const int q = i * 32 + qlane;
-        const int r = (q * 241) >> 13;                        // q / 34 for q < 442
-        const int cc = q - r * XW;
-        const int sl = (lane & 7) ^ ((cc >> 1) & 7);          // logical 16-B slot behind this physical slot
-        const bool ok = ((unsigned)(ya + r) < (unsigned)a.H) & ((unsigned)(xa + cc) < (unsigned)a.W) & (q < NPIX) & live;
-        return ok ? (unsigned)(r * a.W + cc) * 128u + (unsigned)sl * 16u : kOOR;
+        bool ok = ((unsigned)ya + d_r < (unsigned)a.H) & ((unsigned)xa + d_cc < (unsigned)a.W) & live;
+        if (i * 32 + 31 >= NPIX) ok &= (i * 32 + qlane < NPIX);
+        return ok ? d_off : kOOR;
     };
     auto origin = [&](const Item& it) {
         return (unsigned)((it.b * a.H + it.pyi * TH - 2) * a.W + it.pxi * TW - 2 + 2 * a.W + 2) * 128u;
@@ -223,6 +255,19 @@ __global__ __launch_bounds__(256) void arsb32_kernel(ArsbArgs a)
 
     float16_t acc[4];
     half8_t fr[13];           // fragment f of row step t (0..6 conv_1, 7..12 conv_2) lives in fr[(f - t) mod 13]
+    u4_t xlo[4][2], xhv[2];   // residual words in flight: x_lo of the four rows, x_hi of ONE row (slot o)
+    unsigned sh[4], sl[4];
+    // stream tensors: byte offset of (output row 4h, column x0) of the patch, the lane's column part; row 3 of the PREVIOUS patch (stored one patch late)
+    unsigned so0 = 0, vo = kOOR, so2p = kOOR, so3p = kOOR, vop = kOOR, xprev = lds0;
+    int yrow0 = 0;
+    {
+        const u4_t z4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int o = 0; o < 2; ++o) { xhv[o] = z4; xlo[3][o] = z4; }      // (the first patch runs the late epilogues of "the patch before" with their stores rejected)
+        xlo[2][1] = z4;
+        acc[2] = zero16; acc[3] = zero16;
+    }
+    auto row_so = [&](int i) { return (yrow0 + i < a.H) ? so0 + (unsigned)(i * a.W * 128) : kOOR; };
 
     // ===== prologue: the first patch ====================================================================================================================
     Item it_cur = decode(g);
@@ -231,7 +276,7 @@ __global__ __launch_bounds__(256) void arsb32_kernel(ArsbArgs a)
 #pragma unroll
         for (int i = 0; i < NDMA_W; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(smem + (i * 4 + w4) * 1024), 16,
-                                                     piece_off(i, it_cur.pyi * TH - 2, it_cur.pxi * TW - 2, true), org, 0, 0);
+                                                     (piece_addr(i), piece_off(i, it_cur.pyi * TH - 2, it_cur.pxi * TW - 2, true)), org, 0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -244,22 +289,23 @@ __global__ __launch_bounds__(256) void arsb32_kernel(ArsbArgs a)
         const bool has_next = p + 1 < K;
         const Item itn = advance(it);                         // (beyond the last patch: nothing is fetched, see patch_key)
         const unsigned xcur = lds0 + (unsigned)((p & 1) * XBYTES), xnxt = lds0 + (unsigned)(((p + 1) & 1) * XBYTES);
-        const unsigned orgn = origin(itn);
-        const int yan = itn.pyi * TH - 2, xan = itn.pxi * TW - 2;
+        // (pinned in SGPRs once: left to the compiler, the carries of advance() and the origin are re-derived in front of every DMA piece)
+        const unsigned orgn = (unsigned)__builtin_amdgcn_readfirstlane((int)origin(itn));
+        const int yan = __builtin_amdgcn_readfirstlane(itn.pyi * TH - 2), xan = __builtin_amdgcn_readfirstlane(itn.pxi * TW - 2);
+        const unsigned dnxt = (unsigned)__builtin_amdgcn_readfirstlane(((p + 1) & 1) * XBYTES + w4 * 1024);
         const int y0 = it.pyi * TH, x0 = it.pxi * TW;
         A32_STAMP(0)
-        // stream tensors: byte offset of (output row 4h + i, column x0) and the lane's column validity
-        const unsigned so0 = (unsigned)(((it.b * a.H + y0 + 4 * h) * a.W + x0) * 128);
-        const unsigned vo = ((j < TW) & (x0 + j < a.W)) ? lane_ob : kOOR;
+        so0 = (unsigned)(((it.b * a.H + y0 + 4 * h) * a.W + x0) * 128);
+        vo = ((j < TW) & (x0 + j < a.W)) ? lane_ob : kOOR;
+        yrow0 = y0 + 4 * h;
         unsigned hp[8];                                       // activated m row being written (packed halves: slot 0 | slot 1)
-        u4_t xlo[4][2], xhv[2];                               // residual words in flight: x_lo of the four rows, x_hi of ONE row (slot o)
-        unsigned sh[4], sl[4];
 
         // ---- micro-ops ---------------------------------------------------------------------------------------------------------------------------
-        auto op_dma = [&](auto I_) __attribute__((always_inline)) {
-            constexpr int i = decltype(I_)::value;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)((char*)smem + ((p + 1) & 1) * XBYTES + (i * 4 + w4) * 1024), 16,
-                                                     piece_off(i, yan, xan, has_next), orgn, 0, 0);
+        auto op_dma = [&](auto I_, auto HALF_) __attribute__((always_inline)) {
+            constexpr int i = decltype(I_)::value, half = decltype(HALF_)::value;
+            if constexpr (half == 0) piece_addr(i);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)((char*)smem + dnxt + i * 4096), 16,
+                                                          piece_off(i, yan, xan, has_next), orgn, 0, 0);
         };
         auto op_p = [&](auto I_, auto K0_, auto N_) __attribute__((always_inline)) {      // PReLU on packed halves (slope <= 1) of channel pairs k0 .. k0+n-1 of m row i
             constexpr int i = decltype(I_)::value, k0 = decltype(K0_)::value, n = decltype(N_)::value;
@@ -276,19 +322,19 @@ __global__ __launch_bounds__(256) void arsb32_kernel(ArsbArgs a)
             const unsigned ad = mw[o];         // (a local: inline-asm operands inside a generic lambda do not capture)
             asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(ad), "v"(d), "n"(i * ROWB) : "memory");
         };
-        auto row_so = [&](int i) { return (y0 + 4 * h + i < a.H) ? so0 + (unsigned)(i * a.W * 128) : kOOR; };
         auto op_xlo = [&](auto I_, auto O_) __attribute__((always_inline)) {
             constexpr int i = decltype(I_)::value, o = decltype(O_)::value;
             xlo[i][o] = __builtin_amdgcn_raw_buffer_load_b128(rlo, vo + (unsigned)(o * 32), row_so(i), 0);
         };
         auto op_xhi = [&](auto I_, auto O_) __attribute__((always_inline)) {
             constexpr int i = decltype(I_)::value, o = decltype(O_)::value;
-            xhv[o] = *(const __attribute__((address_space(3))) u4_t*)(xcur + xh[o] + (unsigned)(i * ROWB));
+            // (row 3, slot 1 follows slot 1 of row 2, which rides in the NEXT patch's conv_1 -- or in the tail of this one: xprev is the buffer of the patch it belongs to)
+            xhv[o] = *(const __attribute__((address_space(3))) u4_t*)((i == 3 && o == 1 ? xprev : xcur) + xh[o] + (unsigned)(i * ROWB));
         };
-        auto op_res = [&](auto I_, auto O_) __attribute__((always_inline)) {      // acc += x_hi [+ x_lo 2^-11] (in place) for the eight channels of slot o
-            constexpr int i = decltype(I_)::value, o = decltype(O_)::value;
+        auto op_res = [&](auto I_, auto O_, auto K0_) __attribute__((always_inline)) {      // acc += x_hi [+ x_lo 2^-11] (in place) for channel pairs k0, k0+1 of slot o
+            constexpr int i = decltype(I_)::value, o = decltype(O_)::value, k0 = decltype(K0_)::value;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = k0; k < k0 + 2; ++k) {
                 float v0 = acc[i][8 * o + 2 * k], v1 = acc[i][8 * o + 2 * k + 1];
                 v0 = mix_lo(xhv[o][k], 1.0f, v0); v1 = mix_hi(xhv[o][k], 1.0f, v1);
                 if (LO) { v0 = mix_lo(xlo[i][o][k], 0.00048828125f, v0); v1 = mix_hi(xlo[i][o][k], 0.00048828125f, v1); }
@@ -296,7 +342,7 @@ __global__ __launch_bounds__(256) void arsb32_kernel(ArsbArgs a)
             }
             if (!LO) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = k0; k < k0 + 2; ++k) {
                     const half2_t pr = {(half_t)acc[i][8 * o + 2 * k], (half_t)acc[i][8 * o + 2 * k + 1]};
                     sh[k] = __builtin_bit_cast(unsigned, pr);
                 }
@@ -309,29 +355,31 @@ __global__ __launch_bounds__(256) void arsb32_kernel(ArsbArgs a)
         };
         auto op_st = [&](auto I_, auto O_) __attribute__((always_inline)) {
             constexpr int i = decltype(I_)::value, o = decltype(O_)::value;
-            const unsigned so = row_so(i);
+            constexpr bool late = i == 3 || (i == 2 && o == 1);      // (runs one patch late: offsets of the patch it belongs to)
+            const unsigned so = i == 3 ? so3p : late ? so2p : row_so(i);
+            const unsigned vv = (late ? vop : vo) + (unsigned)(o * 32);
             const u4_t dh = {sh[0], sh[1], sh[2], sh[3]};
-            __builtin_amdgcn_raw_buffer_store_b128(dh, ryh, vo + (unsigned)(o * 32), so, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(dh, ryh, vv, so, 0);
             if (LO) {
                 const u4_t dl = {sl[0], sl[1], sl[2], sl[3]};
-                __builtin_amdgcn_raw_buffer_store_b128(dl, ryl, vo + (unsigned)(o * 32), so, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(dl, ryl, vv, so, 0);
             }
         };
         // the ops [f n / 12, (f + 1) n / 12) of a list: PH 0 conv_1 row step S, 1 conv_2 row step S, 2 / 3 the tails (m row 4, output row 3; F = 0, all ops)
         auto run_ops = [&](auto PH_, auto S_, auto F_) __attribute__((always_inline)) {
             constexpr int PH = decltype(PH_)::value, S = decltype(S_)::value, F = decltype(F_)::value;
-            constexpr OpList L = PH == 0 ? conv1_ops(S) : PH == 1 ? conv2_ops(S, LO) : PH == 2 ? mrow_ops(4) : yrow_ops(3, LO);
+            constexpr OpList L = PH == 0 ? conv1_ops(S, LO) : PH == 1 ? conv2_ops(S, LO) : PH == 2 ? mrow_ops(4) : tail_ops(LO);
             constexpr int lo = PH < 2 ? F * L.n / 12 : 0, hi = PH < 2 ? (F + 1) * L.n / 12 : L.n;
             auto run = [&](auto I_) __attribute__((always_inline)) {
                 constexpr int I = decltype(I_)::value;
                 if constexpr (I >= lo && I < hi) {
                     constexpr Op o = L.op[I];
-                    if constexpr (o.kind == OP_DMA) op_dma(std::integral_constant<int, o.a>{});
+                    if constexpr (o.kind == OP_DMA) op_dma(std::integral_constant<int, o.a>{}, std::integral_constant<int, o.b>{});
                     if constexpr (o.kind == OP_P) op_p(std::integral_constant<int, o.a>{}, std::integral_constant<int, o.b>{}, std::integral_constant<int, o.c>{});
                     if constexpr (o.kind == OP_MW) op_mw(std::integral_constant<int, o.a>{}, std::integral_constant<int, o.b>{});
                     if constexpr (o.kind == OP_XLO) op_xlo(std::integral_constant<int, o.a>{}, std::integral_constant<int, o.b>{});
                     if constexpr (o.kind == OP_XHI) op_xhi(std::integral_constant<int, o.a>{}, std::integral_constant<int, o.b>{});
-                    if constexpr (o.kind == OP_RES) op_res(std::integral_constant<int, o.a>{}, std::integral_constant<int, o.b>{});
+                    if constexpr (o.kind == OP_RES) op_res(std::integral_constant<int, o.a>{}, std::integral_constant<int, o.b>{}, std::integral_constant<int, o.c>{});
                     if constexpr (o.kind == OP_SPL) op_spl(std::integral_constant<int, o.a>{}, std::integral_constant<int, o.b>{}, std::integral_constant<int, o.c>{});
                     if constexpr (o.kind == OP_ST) op_st(std::integral_constant<int, o.a>{}, std::integral_constant<int, o.b>{});
                 }
@@ -346,7 +394,10 @@ __global__ __launch_bounds__(256) void arsb32_kernel(ArsbArgs a)
         auto step1 = [&](auto S_) __attribute__((always_inline)) {
             constexpr int s = decltype(S_)::value;
             constexpr int nm = (s <= 4 ? 1 : 0) + ((s >= 1 && s <= 5) ? 1 : 0) + ((s >= 2) ? 1 : 0);      // rows this x row contributes to
-            if (s == 1) {       // barrier A: nobody reads m or the old x buffer any more
+            if (s == 1) {       // barrier A: nobody reads m or the old x buffer any more; DMA pieces 8..12 of this patch (issued in the previous conv_2) have landed
+                if (LO) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                static_assert(stores_behind_dma(true) == 12 && stores_behind_dma(false) == 6, "counted wait of barrier A");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
             }
@@ -392,7 +443,9 @@ __global__ __launch_bounds__(256) void arsb32_kernel(ArsbArgs a)
             }
         }
         A32_STAMP(8)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // DMA pieces 0..7 of patch p+1 and the late stores of patch p-1 are complete; the eight x_lo loads issued behind them may still fly
+        if (LO) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         A32_STAMP(9)
         __builtin_amdgcn_s_barrier();                         // barrier B: m is complete, x[p+1] has landed for every wave
         asm volatile("" ::: "memory");
@@ -414,8 +467,9 @@ __global__ __launch_bounds__(256) void arsb32_kernel(ArsbArgs a)
 #pragma unroll
                 for (int f = 0; f < 12; ++f) fa[f] += d21;
             }
-            if (LO && s == 3) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the x_lo words (issued in steps 0..2) have landed BEFORE the first store goes out --
-                                                                        // loads and stores share the counter, a later counted wait would also wait for store acknowledgements
+            if (LO && s == 3) __builtin_amdgcn_s_waitcnt(0x0F75);      // vmcnt(5): the x_lo words (issued in conv_1's steps 4, 5; only DMA pieces 8..12 are younger) have landed
+                                                                        // BEFORE the first store goes out -- loads and stores share the counter, a later counted wait would also
+                                                                        // wait for store acknowledgements
             auto chunk = [&](auto F_) __attribute__((always_inline)) {
                 constexpr int f = decltype(F_)::value;
                 constexpr int dx = f >> 2, ks = f & 3;
@@ -445,9 +499,13 @@ __global__ __launch_bounds__(256) void arsb32_kernel(ArsbArgs a)
 #define A32_STEP(S) step2(std::integral_constant<int, S>{});
         A32_STEP(0) A32_STEP(1) A32_STEP(2) A32_STEP(3) A32_STEP(4) A32_STEP(5)
 #undef A32_STEP
-        run_ops(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});      // output row 3 of the wave
         A32_STAMP(17)
+        so2p = row_so(2);                                     // slot 1 of output row 2 and row 3 of the wave: their epilogues ride in the next patch's conv_1
+        so3p = row_so(3);
+        vop = vo;
+        xprev = xcur;
         it_cur = itn;
+        if (!has_next) run_ops(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
     }
 #endif
 }

@@ -88,7 +88,7 @@ struct NetOptions {
     bool conv1x1 = true;      // conv1x1     lite's 1x1 layers on conv1x1.hip (0: generic kernel)
     bool x3_fuse = true;      // x3_fuse     split-operand 3x3 64->64 layers as ONE launch (conv64_x3.hip; 0: three launches)
     bool arsb_fuse = true;    // arsb_fuse   single-pass ARSBs as one launch (0: two launches)
-    int arsb_impl = 1;        // arsb_impl   v1 (1: arsb_fused.hip, 16x16x32 MFMAs, wave = 16 channels) | v2 (2: arsb32.hip, 32x32x16 MFMAs, waves in lock-step)
+    int arsb_impl = 2;        // arsb_impl   v2 (2, default: arsb32.hip, 32x32x16 MFMAs, waves in lock-step) | v1 (1: arsb_fused.hip, 16x16x32 MFMAs, wave = 16 channels)
     bool fuse_tail = true;    // fuse_tail   last upsampler conv + 64->1 / 48->1 tail conv in one kernel
     bool sedn_fuse = true;    // sedn_fuse   SEDN's fused block tail
     bool pool_fuse = true;    // pool_fuse   SE / FRM channel sums out of the producing conv's epilogue

@@ -696,9 +696,15 @@ def test_fused_arsb_matches_two_launch_form(impl, dev):
                             assert np.abs(y - want).max() <= (1e-2 if prec == 'fp16' else 2e-3), (key, shape, prec, nb, float(np.abs(y - want).max()))
                     if prec == 'mixed' and nb == -1:
                         assert np.abs(y1 - want).max() <= TOL, (key, shape, kind, float(np.abs(y1 - want).max()))
+                    # few persistent workgroups: every workgroup walks several patches (v2 hands output row 3 of a patch over to the next
+                    # patch's first row steps); a conv is a pure function of its patch, so the result must not change by a bit
+                    if shape[1] * shape[2] >= 40 * 64:
+                        y2 = m.set_exact_blocks(nb).set_option('max_groups', 16)(xd)[-1].cpu().numpy()
+                        m.set_option('max_groups', 0).set_exact_blocks(-1)
+                        assert np.array_equal(y2, y1), (key, shape, prec, nb, float(np.abs(y2 - y1).max()))
     finally:
         for m in touched:
-            m.set_option('arsb_fuse', 1).set_option('arsb_impl', 'v1').set_exact_blocks(-1)
+            m.set_option('arsb_fuse', 1).set_option('arsb_impl', 'v2').set_option('max_groups', 0).set_exact_blocks(-1)
 
 
 RESIZE = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(G, 'resize', '*.npz')) if 'scale_factors' not in p)
