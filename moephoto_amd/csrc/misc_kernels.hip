@@ -864,48 +864,94 @@ __global__ __launch_bounds__(256) void stitch4_kernel(StitchArgs a)
     }
 }
 
-// Eight consecutive pixels per thread (out_w % 8 == 0, at most 64 tile columns).  The 350-us form above spends its time in a chain of
-// four dependent table loads per thread (col_first -> col_tab -> tile_off -> tile data) for 16 bytes of payload: here the row
-// side is block-uniform (scalar loads), the column table and the tile offsets of this block's tile row are staged in LDS once per
-// block, so a thread's chain is col_first -> tile data, with two 16-byte loads and one 16/32-byte store per thread.
-__global__ __launch_bounds__(256) void stitch8_kernel(StitchArgs a)
+// R rows x eight consecutive pixels per thread (out_w % 8 == 0, at most 64 tile columns).  History of this kernel on the 8K / 32K canvas:
+// one pixel per thread 465 us; four pixels (stitch4 above) 350 us -- a chain of four dependent table loads per thread (col_first -> col_tab
+// -> tile_off -> tile data) for 16 bytes of payload; eight pixels with the column table staged in LDS and a block-uniform row side
+// 388 us / 4.46 ms = 1.6 / 2.1 TB/s; this form 1.88 ms on the 32K canvas = 5.1 TB/s.  What the last step removed: (1) a block lived for one
+// chain of dependent loads and moved 12 KB with it -- now a block takes R rows, so one chain carries R x 2 independent 16-byte loads per
+// thread; (2) seam ROWS (two covering tile rows: 4 % of the rows) sent every thread through the per-pixel fold -- now a thread whose eight
+// columns lie in the solid part of ONE tile column folds the covering tile rows as vectors (the reference's order per pixel: cur = r, or
+// cur + ramp (r - cur) inside the tile's blend band, python/imageProcess.py:120-131, so the result stays bit-identical to the sequential
+// loop); (3) a thread on a COLUMN seam walked its 8 pixels one after the other, ~5 dependent loads each, and held its wave meanwhile --
+// every fourth wave of a 2048-px tile column; now such threads only enlist their group and the whole block folds the seam pixels one
+// pixel per thread.
+template <int R>
+__global__ __launch_bounds__(256) void stitch8r_kernel(StitchArgs a)
 {
     __shared__ int s_col[64 * 4];
-    __shared__ long long s_off[64];
-    const int Y = blockIdx.y, c = blockIdx.z;
-    const int i0 = a.row_first[Y], ni = a.row_cnt[Y];
+    __shared__ int s_seam[256];
+    __shared__ int s_nseam;
+    const int Y0 = blockIdx.y * R, c = blockIdx.z;
     const int nsw = a.step_w;
     for (int t = threadIdx.x; t < nsw * 4; t += 256) s_col[t] = a.col_tab[t];
-    for (int t = threadIdx.x; t < nsw; t += 256) s_off[t] = a.tile_off[i0 * nsw + t];
+    if (threadIdx.x == 0) s_nseam = 0;
     __syncthreads();
     const int X0 = (blockIdx.x * 256 + threadIdx.x) * 8;
-    if (X0 >= a.out_w) return;
-    float v[8];
-    const int j0 = a.col_first[X0], j7 = a.col_first[X0 + 7];
-    bool fast = ni == 1 && a.col_cnt[X0] == 1 && a.col_cnt[X0 + 7] == 1 && j0 == j7;
-    if (fast) {
-        const int sy = a.row_tab[i0 * 4 + 1], oy = a.row_tab[i0 * 4 + 2], eh = a.row_tab[i0 * 4 + 3];
+    if (X0 < a.out_w) {
+        const int j0 = a.col_first[X0], j7 = a.col_first[X0 + 7];
+        bool colfast = a.col_cnt[X0] == 1 && a.col_cnt[X0 + 7] == 1 && j0 == j7;
         const int sx = s_col[j0 * 4 + 1], ox = s_col[j0 * 4 + 2], ew = s_col[j0 * 4 + 3];
-        const long long o = s_off[j0] + ((long long)c * eh + (Y - oy)) * ew + (X0 - ox);
-        fast = Y >= sy && X0 >= sx && (o & 3) == 0;
-        if (fast) {
-            const float4 q0 = *(const float4*)(a.tiles + o), q1 = *(const float4*)(a.tiles + o + 4);
-            v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+        colfast = colfast && X0 >= sx;
+        if (!colfast) s_seam[atomicAdd(&s_nseam, 1)] = threadIdx.x;      // eight columns on a seam: handed to the whole block below
+        else {
+            float v[R][8];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int Y = min(Y0 + r, a.out_h - 1);            // (rows past the canvas repeat the last one and are not stored)
+                const int i0 = a.row_first[Y], ni = a.row_cnt[Y];  // block-uniform
+                float cur[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int i = i0; i < i0 + ni; ++i) {
+                    const int fy = a.row_tab[i * 4 + 0], sy = a.row_tab[i * 4 + 1], oy = a.row_tab[i * 4 + 2], eh = a.row_tab[i * 4 + 3];
+                    const long long o = a.tile_off[i * nsw + j0] + ((long long)c * eh + (Y - oy)) * ew + (X0 - ox);
+                    float q[8];
+                    if ((o & 3) == 0) {
+                        const float4 q0 = *(const float4*)(a.tiles + o), q1 = *(const float4*)(a.tiles + o + 4);
+                        q[0] = q0.x; q[1] = q0.y; q[2] = q0.z; q[3] = q0.w; q[4] = q1.x; q[5] = q1.y; q[6] = q1.z; q[7] = q1.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) q[e] = a.tiles[o + e];
+                    }
+                    if (Y < sy) {
+                        const float wgt = a.ramp[Y - fy];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) cur[e] = cur[e] + wgt * (q[e] - cur[e]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) cur[e] = q[e];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[r][e] = cur[e];
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (Y0 + r >= a.out_h) break;
+                const long long o = ((long long)c * a.out_h + Y0 + r) * a.out_w + X0;
+                if (a.out_dtype == MOE_F16) {
+                    half8_t h;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) h[e] = (half_t)v[r][e];
+                    *(half8_t*)((half_t*)a.out + o) = h;
+                } else {
+                    *(float4*)((float*)a.out + o) = make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);
+                    *(float4*)((float*)a.out + o + 4) = make_float4(v[r][4], v[r][5], v[r][6], v[r][7]);
+                }
+            }
         }
     }
-    if (!fast) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = stitch_pixel(a, X0 + e, Y, c);
-    }
-    const long long o = ((long long)c * a.out_h + Y) * a.out_w + X0;
-    if (a.out_dtype == MOE_F16) {
-        half8_t h;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) h[e] = (half_t)v[e];
-        *(half8_t*)((half_t*)a.out + o) = h;
-    } else {
-        *(float4*)((float*)a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
-        *(float4*)((float*)a.out + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    __syncthreads();
+    // column seams: one pixel per thread and pass, the exact per-pixel fold (a thread walking its own 8 x R seam pixels one after the other
+    // held its wave for 32 chains of dependent loads: every fourth wave of a 2048-px tile column)
+    const int total = s_nseam * 8 * R;
+    for (int t = threadIdx.x; t < total; t += 256) {
+        const int gidx = t / (8 * R), rem = t - gidx * 8 * R;
+        const int r = rem >> 3, e = rem & 7;
+        const int X = (blockIdx.x * 256 + s_seam[gidx]) * 8 + e, Y = Y0 + r;
+        if (Y >= a.out_h) continue;
+        const float cur = stitch_pixel(a, X, Y, c);
+        const long long o = ((long long)c * a.out_h + Y) * a.out_w + X;
+        if (a.out_dtype == MOE_F16) ((half_t*)a.out)[o] = (half_t)cur;
+        else ((float*)a.out)[o] = cur;
     }
 }
 
@@ -1028,7 +1074,7 @@ void launch_frm(const FrmArgs& a, hipStream_t s)
 
 void launch_stitch(const StitchArgs& a, hipStream_t s)
 {
-    if (a.out_w % 8 == 0 && a.step_w <= 64 && ((uintptr_t)a.out & 15) == 0) hipLaunchKernelGGL(stitch8_kernel, dim3((a.out_w / 8 + 255) / 256, a.out_h, a.C), dim3(256), 0, s, a);
+    if (a.out_w % 8 == 0 && a.step_w <= 64 && ((uintptr_t)a.out & 15) == 0) hipLaunchKernelGGL(stitch8r_kernel<4>, dim3((a.out_w / 8 + 255) / 256, (a.out_h + 3) / 4, a.C), dim3(256), 0, s, a);
     else if (a.out_w % 4 == 0 && ((uintptr_t)a.out & 15) == 0) hipLaunchKernelGGL(stitch4_kernel, dim3((a.out_w / 4 + 255) / 256, a.out_h, a.C), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(stitch_kernel, dim3((a.out_w + 255) / 256, a.out_h, a.C), dim3(256), 0, s, a);
 }
