@@ -146,8 +146,12 @@ __global__ __launch_bounds__(256) void conv64_x3_kernel(ConvX3Args a)
         const int y0 = it.pyi * TH, x0 = it.pxi * TW;
         if (POOL && it.b != pool_b) { pool_flush(pool_b); pool_b = it.b; }
 
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                     // a_hi[p] has landed; every wave is done with a_lo[p-1]
+        // a_hi[p] has landed: its eleven pieces went out in pass 2 of the previous patch, in front of the stores of that pass's output rows 2..7
+        // (twelve 16-byte stores).  vmcnt counts loads and stores IN ORDER, so a plain vmcnt(0) here also waits for the acknowledgement of stores
+        // issued a few hundred cycles ago -- every patch.  (First patch: the prologue's pieces, nothing behind them.)
+        if (p == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                     // every wave is done with a_lo[p-1]
         asm volatile("" ::: "memory");
 
         half8_t fr[2][12];
@@ -163,7 +167,23 @@ __global__ __launch_bounds__(256) void conv64_x3_kernel(ConvX3Args a)
         if (i_ < (NREAD)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                             \
         __builtin_amdgcn_sched_group_barrier(0x002, (NVALU), 0);                                         \
     }
-        uint4 resw[4], sidew[4];      // EPI 2: residual hi / lo of the output rows in flight (a ring of four)
+        // EPI 2: the residual (hi + lo 2^-11) is added to ah[o] INSIDE PASS 1, three rows after the row's words were requested and one row after
+        // its last w_hi a_hi product: pass 1 has no stores in flight, so the counted waits for these loads wait for loads only.  (Round 2 fetched
+        // the words in pass 2 between the stores of finished rows: each wait then also waited for the stores -- and the next patch's DMA --
+        // issued in front of the load; EPI 2 ran 28 % slower than EPI 0 / 1.)
+        typedef unsigned u4v_t __attribute__((ext_vector_type(4)));
+        u4v_t resw[4], sidew[4];      // residual hi / lo of the rows in flight (a ring of four)
+        auto add_res = [&](float4_t (&h4)[2], const u4v_t& lo_w, const u4v_t& hi_w) {
+            const auto l0 = __builtin_amdgcn_permlane16_swap(lo_w.x, lo_w.z, false, false), l1 = __builtin_amdgcn_permlane16_swap(lo_w.y, lo_w.w, false, false);
+            const auto r0 = __builtin_amdgcn_permlane16_swap(hi_w.x, hi_w.z, false, false), r1 = __builtin_amdgcn_permlane16_swap(hi_w.y, hi_w.w, false, false);
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                float t0 = h4[cb][0], t1 = h4[cb][1], t2 = h4[cb][2], t3 = h4[cb][3];
+                t0 = mix_lo(l0[cb], kc.lowscale, t0); t1 = mix_hi(l0[cb], kc.lowscale, t1); t2 = mix_lo(l1[cb], kc.lowscale, t2); t3 = mix_hi(l1[cb], kc.lowscale, t3);
+                t0 = mix_lo(r0[cb], kc.one, t0); t1 = mix_hi(r0[cb], kc.one, t1); t2 = mix_lo(r1[cb], kc.one, t2); t3 = mix_hi(r1[cb], kc.one, t3);
+                h4[cb] = float4_t{t0, t1, t2, t3};
+            }
+        };
         const unsigned rowb = ((unsigned)(it.b * a.H + y0) * (unsigned)a.W + (unsigned)x0) * 128u;
         const bool okx = x0 + ocol < a.W;
         auto row_off = [&](int o) {
@@ -180,7 +200,16 @@ __global__ __launch_bounds__(256) void conv64_x3_kernel(ConvX3Args a)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int xr = 0; xr < 10; ++xr) {
-            __builtin_amdgcn_s_waitcnt(0xC07F);      // this row's fragments (read during the previous row) have landed: no counted waits between the MFMAs
+            // this row's fragments (read during the previous row) have landed: no counted waits between the MFMAs.  EPI 2, rows 3..9: also the residual
+            // words of output row xr-3, requested three row steps ago -- a COUNTED wait (younger: the DMA pieces and words of the two rows between),
+            // placed here behind the previous row's sched_barrier: a wait in mid-row does not keep the scheduler from hoisting the words' first use
+            // above it, and for a use it finds unprotected the compiler inserts vmcnt(0) while LDS-DMA pieces are in flight
+            if (EPI != 2 || xr < 3) __builtin_amdgcn_s_waitcnt(0xC07F);
+            else if (xr <= 5) __builtin_amdgcn_s_waitcnt(0x0078);     // vmcnt(8) lgkmcnt(0)
+            else if (xr == 6) __builtin_amdgcn_s_waitcnt(0x0077);     // 7
+            else if (xr == 7) __builtin_amdgcn_s_waitcnt(0x0075);     // 5
+            else if (xr == 8) __builtin_amdgcn_s_waitcnt(0x0074);     // 4
+            else __builtin_amdgcn_s_waitcnt(0x0072);                  // 2
             if (xr < 9) { MOE_READ_ROW((xr + 1) & 1, xr + 1) }
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx)
@@ -199,13 +228,16 @@ __global__ __launch_bounds__(256) void conv64_x3_kernel(ConvX3Args a)
                             }
                         }
                     }
+            if (EPI == 2 && xr >= 3) {        // rows 0..6 (ah[o] is complete since row step o + 2)
+                add_res(ah[xr - 3], sidew[(xr - 3) & 3], resw[(xr - 3) & 3]);
+            }
             // a_lo of THIS patch (its buffer was freed by the barrier above): 11 pieces over the first six rows
             if (xr < 5) { issue_piece(a.in_lo, it, 2 * xr, lbuf, true); issue_piece(a.in_lo, it, 2 * xr + 1, lbuf, true); }
             if (xr == 5) issue_piece(a.in_lo, it, 10, lbuf, true);
-            if (EPI == 2 && xr >= 7) {        // residual of output rows 0..2 (needed early in pass 2) at the end of pass 1
-                const unsigned off = row_off(xr - 7);
-                resw[xr - 7] = *(const uint4*)((const char*)a.res_hi + off);
-                sidew[xr - 7] = *(const uint4*)((const char*)a.res_lo + off);
+            if (EPI == 2 && xr < 8) {         // words of output row xr: their ring slot was released by the add above
+                const unsigned off = row_off(xr);
+                resw[xr & 3] = *(const u4v_t*)((const char*)a.res_hi + off);
+                sidew[xr & 3] = *(const u4v_t*)((const char*)a.res_lo + off);
             }
             MOE_PIN_ROW(((xr < 2 || xr > 7) ? (xr == 0 || xr == 9 ? 24 : 48) : 72), (xr < 9 ? 12 : 0), 1)
             __builtin_amdgcn_sched_barrier(0);
@@ -240,10 +272,11 @@ __global__ __launch_bounds__(256) void conv64_x3_kernel(ConvX3Args a)
                         for (int e = 0; e < 4; ++e) psum[e] = __builtin_fmaf(v[cb][e], m, psum[e]);
                     }
                 }
-                finish_row<EPI == 2, EPI == 2, true>(v, sidew[o & 3], resw[o & 3], kc, (char*)a.out_hi, (char*)a.out_lo, row_off(o));
+                finish_row<false, false, true>(v, uint4{}, uint4{}, kc, (char*)a.out_hi, (char*)a.out_lo, row_off(o));
             };
             MOE_SET_BASE(lbuf)
             MOE_READ_ROW(0, 0)
+            if (EPI == 2) add_res(ah[7], sidew[3], resw[3]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int xr = 0; xr < 10; ++xr) {
@@ -266,11 +299,6 @@ __global__ __launch_bounds__(256) void conv64_x3_kernel(ConvX3Args a)
                 if (xr < 5) { issue_piece(a.in_hi, itn, 2 * xr, hn, has_next); issue_piece(a.in_hi, itn, 2 * xr + 1, hn, has_next); }
                 if (xr == 5) issue_piece(a.in_hi, itn, 10, hn, has_next);
                 if (xr >= 3) out_row(ah[xr - 3], al[xr - 3], xr - 3);     // complete since the end of the previous row
-                if (EPI == 2 && xr >= 3 && xr < 8) {    // ring slot of row xr-3 is free again: residual of output row xr (drained at xr+3)
-                    const unsigned off = row_off(xr);
-                    resw[xr & 3] = *(const uint4*)((const char*)a.res_hi + off);
-                    sidew[xr & 3] = *(const uint4*)((const char*)a.res_lo + off);
-                }
                 MOE_PIN_ROW(((xr < 2 || xr > 7) ? (xr == 0 || xr == 9 ? 12 : 24) : 36), (xr < 9 ? 12 : 0), 3)
                 __builtin_amdgcn_sched_barrier(0);
             }
