@@ -63,7 +63,7 @@ PARITY_TOL = 1e-3
 GROUPS = [
     ('convt_R1.up1', 'R-branch 3x3 64->256 @2x res (+bias +PixelShuffle(2) +PReLU, fused 64->1 tail as phase-class sums, split activations: conv3x3_rw EPI 7)', 4 * 2 * 256 * 64 * 9),
     ('u.up1', 'U-branch 3x3 64->256 @2x res (+bias +PixelShuffle(2) +PReLU, fused 64->1 tail as phase-class sums: conv3x3_rw EPI 3)', 4 * 2 * 256 * 64 * 9),
-    ('arsb', 'arsb32_kernel (one ARSB per launch: two 3x3 64->64 convs @1x res + PReLU + hi/lo residual stream, 32x32x16 MFMAs; 5 of 6 ARSBs)', 5 * 2 * 2 * 64 * 64 * 9),
+    ('arsb', 'arsb32c_kernel (one ARSB per launch: two 3x3 64->64 convs @1x res + PReLU + hi/lo residual stream, 32x32x16 MFMAs, conv_1 rows kept in LDS down a patch column; 5 of 6 ARSBs)', 5 * 2 * 2 * 64 * 64 * 9),
 ]
 
 

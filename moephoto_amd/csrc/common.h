@@ -128,6 +128,9 @@ hipError_t arsb_fused_init();
 // second form (arsb32.hip): v_mfma_f32_32x32x16_f16, four waves in lock-step, both convs' weights resident; w1 / w2 in the conv3x3_sp fragment order (ConvLayer::w_hi)
 bool launch_arsb32(ArsbArgs a, int max_groups, hipStream_t s);
 hipError_t arsb32_init();
+// third form (arsb32c.hip): arsb32 with vertical continuation -- ten output rows per patch, the two last m rows of a patch stay in LDS for the patch below
+bool launch_arsb32c(ArsbArgs a, int max_groups, hipStream_t s);
+hipError_t arsb32c_init();
 
 // One 3x3 64->64 conv with split operands, three products in one launch (conv64_x3.hip); weights in the fused-ARSB order
 struct ConvX3Args {

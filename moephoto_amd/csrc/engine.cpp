@@ -88,7 +88,8 @@ struct NetOptions {
     bool conv1x1 = true;      // conv1x1     lite's 1x1 layers on conv1x1.hip (0: generic kernel)
     bool x3_fuse = true;      // x3_fuse     split-operand 3x3 64->64 layers as ONE launch (conv64_x3.hip; 0: three launches)
     bool arsb_fuse = true;    // arsb_fuse   single-pass ARSBs as one launch (0: two launches)
-    int arsb_impl = 2;        // arsb_impl   v2 (2, default: arsb32.hip, 32x32x16 MFMAs, waves in lock-step) | v1 (1: arsb_fused.hip, 16x16x32 MFMAs, wave = 16 channels)
+    int arsb_impl = 3;        // arsb_impl   v3 (3, default: arsb32c.hip, 32x32x16 MFMAs, waves in lock-step, vertical continuation: ten rows per patch, no recomputed
+                              //             m rows) | v2 (2: arsb32.hip, the same without continuation, eight rows per patch) | v1 (1: arsb_fused.hip, 16x16x32 MFMAs)
     bool fuse_tail = true;    // fuse_tail   last upsampler conv + 64->1 / 48->1 tail conv in one kernel
     bool sedn_fuse = true;    // sedn_fuse   SEDN's fused block tail
     bool pool_fuse = true;    // pool_fuse   SE / FRM channel sums out of the producing conv's epilogue
@@ -117,7 +118,7 @@ struct NetOptions {
         if (key == "sp_impl") { const int t = tri(v, "sp", "auto", "rw", -1); if (t < 0) return false; sp_impl = t; return true; }
         if (key == "tail_split") { const int t = tri(v, "0", "r", "ru", -1); if (t < 0) return false; tail_split = t; return true; }
         if (key == "tail_form") { const int t = tri(v, "planes", "sums", nullptr, -1); if (t < 0) return false; tail_form = t; return true; }
-        if (key == "arsb_impl") { const int t = tri(v, nullptr, "v1", "v2", -1); if (t < 1) return false; arsb_impl = t; return true; }
+        if (key == "arsb_impl") { const int t = (v && !strcmp(v, "v3")) ? 3 : tri(v, nullptr, "v1", "v2", -1); if (t < 1) return false; arsb_impl = t; return true; }
         if (key == "conv1x1") return flag(conv1x1);
         if (key == "x3_fuse") return flag(x3_fuse);
         if (key == "arsb_fuse") return flag(arsb_fuse);
@@ -931,10 +932,11 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
                     const size_t tb = 8 * 16 * 4 * 40 * 8;
                     if (trace && i == 3 && hipMalloc((void**)&q.trace, tb) == hipSuccess) (void)hipMemsetAsync(q.trace, 0, tb, s);
                     const int rec = f.prof_begin("arsb" + std::to_string(i), 2.0 * 2.0 * (double)B * h * w * L1.cout * L1.cin * 9);
-                    if (n.opt.arsb_impl == 2) {
+                    if (n.opt.arsb_impl >= 2) {
                         ArsbArgs q2 = q;
                         q2.w1 = f.blob<half_t>(L1.w_hi); q2.w2 = f.blob<half_t>(L2.w_hi);      // (pack_conv order; conv_2's carry the ScaleLayer factor as well)
-                        done = launch_arsb32(q2, n.max_groups, s);
+                        done = n.opt.arsb_impl == 3 ? launch_arsb32c(q2, n.max_groups, s) : false;
+                        if (!done) done = launch_arsb32(q2, n.max_groups, s);
                     }
                     if (!done) done = launch_arsb_fused(q, n.max_groups, s);
                     f.prof_end(rec);

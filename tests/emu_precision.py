@@ -28,6 +28,12 @@ def r16(x):
     return x.half().float()
 
 
+def q8(x, shift):
+    """x rounded to OCP fp8 e4m3 after scaling by 2^shift (saturating at +-448), as a scaled-MFMA operand would carry it."""
+    v = torch.clamp(x * float(2 ** shift), -448.0, 448.0)
+    return v.to(torch.float8_e4m3fn).float() * float(2.0 ** -shift)
+
+
 def prelu(x, a):
     return torch.where(x >= 0, x, x * a)
 
@@ -49,13 +55,20 @@ def layer_names(arch):
     return out
 
 
-def forward(arch, sd, x, w16=(), a16=(), stream16=False):
+def forward(arch, sd, x, w16=(), a16=(), stream16=False, corr8=(), shifts=(8, 4)):
     """w16 / a16: names of the convs whose weights / input activations are rounded to fp16 ('all' = every conv);
-    stream16: the trunk stream is stored as fp16 after conv_input2 and after every ARSB."""
+    stream16: the trunk stream is stored as fp16 after conv_input2 and after every ARSB.
+    corr8: convs computed as  conv(w16, a16) + conv(fp8(w - w16), fp8(a16)) + conv(fp8(w16), fp8(a - a16))  -- the split-operand form with its two
+    correction products on fp8 operands (scaled by 2^shifts[0] for weights, 2^shifts[1] for activations): a study for the block-scaled fp8 MFMA, which
+    runs at twice the fp16 rate (`python tests/emu_precision.py corr8`)."""
     T = lambda k: torch.from_numpy(np.asarray(sd[k], dtype=np.float32))
     r = 3 if arch == 'net3x' else 2
 
     def conv(name, v, w, b=None):
+        if name in corr8:
+            wh, vh = r16(w), r16(v)
+            sw, sa = shifts
+            return F.conv2d(vh, wh, b, padding=1) + F.conv2d(q8(vh, sa), q8(w - wh, sw + 11), None, padding=1) + F.conv2d(q8(v - vh, sa + 11), q8(wh, sw), None, padding=1)
         if name in w16 or 'all' in w16:
             w = r16(w)
         if name in a16 or 'all' in a16:
@@ -200,6 +213,23 @@ def main(argv):
     cmd = argv[1] if len(argv) > 1 else 'budget'
     if cmd == 'lite':
         lite_budget(tuple(argv[2:]) or ('lite2', 'lite4', 'lite8'))
+        return
+    if cmd == 'corr8':      # the exact layers of 'mixed' with fp8 correction products: error against fp32, beside the present form
+        for key in (argv[2:] or ['a2', 'a4', 'dn_lite5']):
+            arch, sd = gd.MODELS[key][0], _load(key)
+            n = DEFAULT_EXACT[arch]
+            ex = ['input2'] + ['c%d_%d' % (j, i) for i in range(1, n + 1) for j in (1, 2)]
+            for kind, shape, seed in (('noise', (3, 96, 96), 5), ('noise-u8', (3, 256, 256), 0), ('natural', (3, 40, 264), 5)):
+                x = gd.natural_image(seed, shape) if kind == 'natural' else gd.noise_image(seed, shape) if kind == 'noise' else gd.noise_u8(seed, shape).astype(np.float32) / 255.0
+                x = x[:, None]
+                with torch.no_grad():
+                    want = forward(arch, sd, x)
+                    w16, a16, s16 = mode_sets(arch, 'mixed', n)
+                    line = '%-9s %-8s n=%d: split fp16x3 %.3e' % (key, kind, n, float((forward(arch, sd, x, w16, a16, s16) - want).abs().max()))
+                    for sh in ((8, 4), (6, 2), (10, 6)):
+                        line += ' | fp8 corrections 2^%d/2^%d %.3e' % (sh[0], sh[1], float((forward(arch, sd, x, w16, a16, s16, corr8=ex, shifts=sh) - want).abs().max()))
+                    line += ' | no corrections (n=0, input2 fp16) %.3e' % float((forward(arch, sd, x, set(layer_names(arch)) - {'r.tail', 'u.tail'}, set(layer_names(arch)) - ({'r.tail', 'u.tail'} if arch == 'netdn' else {'r.tail'}), False) - want).abs().max())
+                print(line, flush=True)
         return
     if cmd == 'layers':
         key = argv[2] if len(argv) > 2 else 'a2'

@@ -660,13 +660,14 @@ def test_rccl_path_world1(dev):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('impl', ['v1', 'v2'])
+@pytest.mark.parametrize('impl', ['v1', 'v2', 'v3'])
 def test_fused_arsb_matches_two_launch_form(impl, dev):
-    """impl v1 = arsb_fused.hip (16x16x32 MFMAs, wave = 16 channels), v2 = arsb32.hip (32x32x16 MFMAs, waves in lock-step).
+    """impl v1 = arsb_fused.hip (16x16x32 MFMAs, wave = 16 channels), v2 = arsb32.hip (32x32x16 MFMAs, waves in lock-step), v3 = arsb32c.hip (v2 with
+    vertical continuation: ten rows per patch, a workgroup walks a column of patches and keeps the last two m rows for the patch below).
     The fused ARSB kernel (conv_1 -> PReLU -> conv_2 -> + x in one launch, weights in registers) against the two-launch form of
     the same arithmetic (option arsb_fuse = 0) and the oracle: ragged shapes (patches are 8 x 30 outputs), 48- and 64-channel nets,
     with and without the hi+lo stream."""
-    cases = [('a2', (3, 8, 16)), ('a2', (3, 24, 40)), ('a2', (2, 40, 264)), ('a2', (3, 9, 35)), ('a2', (5, 88, 64)), ('dn_lite5', (3, 16, 64)), ('dn_lite5', (3, 33, 31))]
+    cases = [('a2', (3, 8, 16)), ('a2', (3, 24, 40)), ('a2', (2, 40, 264)), ('a2', (3, 9, 35)), ('a2', (5, 88, 64)), ('a2', (2, 131, 61)), ('dn_lite5', (3, 16, 64)), ('dn_lite5', (3, 33, 31))]
     touched = []
     try:
         for key, shape in cases:
@@ -704,7 +705,7 @@ def test_fused_arsb_matches_two_launch_form(impl, dev):
                         assert np.array_equal(y2, y1), (key, shape, prec, nb, float(np.abs(y2 - y1).max()))
     finally:
         for m in touched:
-            m.set_option('arsb_fuse', 1).set_option('arsb_impl', 'v2').set_option('max_groups', 0).set_exact_blocks(-1)
+            m.set_option('arsb_fuse', 1).set_option('arsb_impl', 'v3').set_option('max_groups', 0).set_exact_blocks(-1)
 
 
 RESIZE = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(G, 'resize', '*.npz')) if 'scale_factors' not in p)

@@ -61,7 +61,7 @@ for k in sorted(K, key=lambda k: -DUR[k].get('grbm', DUR[k].get('sq', 0))):
 GROUP_KERNELS = {      # bench.py layer key -> regex of the kernel(s) that run it in the default build
     'convt_R1.up1': r'conv3x3_(sp_kernel<7>|rw_kernel<7[,>])',
     'u.up1': r'conv3x3_(sp_kernel<3>|rw_kernel<3[,>])',
-    'arsb': r'arsb(32|_fused)_kernel',
+    'arsb': r'arsb(32c?|_fused)_kernel',
 }
 groups = {}
 for key, rx in GROUP_KERNELS.items():

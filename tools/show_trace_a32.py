@@ -12,7 +12,7 @@ lib, trace = os.path.join(ROOT, 'moephoto_amd', 'libmoephoto_amd.so'), os.path.j
 shutil.copy(lib, '/tmp/lib_orig.so')
 try:
     shutil.copy(trace, lib)
-    env = dict(os.environ, MOE_ARSB_TRACE='1', MOE_ARSB_IMPL='v2', PROF_ITER='1', PROF_B=os.environ.get('PROF_B', '12'))
+    env = dict(os.environ, MOE_ARSB_TRACE='1', MOE_ARSB_IMPL=os.environ.get('TRACE_IMPL', 'v2'), PROF_ITER='1', PROF_B=os.environ.get('PROF_B', '12'))
     subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'prof_workload.py')], env=env, check=True, stdout=subprocess.DEVNULL)
 finally:
     shutil.copy('/tmp/lib_orig.so', lib)
