@@ -97,12 +97,12 @@ constexpr OpList conv1_ops(int s, bool lo)     // row step s of conv_1 (x row 5h
 {
     OpList r, x;
     if (s == 0) r = yslot_ops(3, 1, lo);
-    if (s == 1) {                               // (behind barrier A)
-        x.push(OP_MCP, 0, 0); x.push(OP_DMA, 0, 0); x.push(OP_MCP, 0, 1); x.push(OP_MCP, 1, 0); x.push(OP_DMA, 0, 1); x.push(OP_MCP, 1, 1);
-        r = interleave(x, yslot_ops(4, 0, lo));
+    if (s == 1) {                               // (behind barrier A)  the late output row 4 with its stores; the DMA pieces follow in steps 2, 3: a store issued
+        x.push(OP_MCP, 0, 0); x.push(OP_MCP, 0, 1); x.push(OP_MCP, 1, 0); x.push(OP_MCP, 1, 1);      // behind loads in flight waits for them at issue (see above)
+        r = interleave(x, yrow_ops(4, lo));
     }
-    if (s == 2) r = interleave(dma_ops(1, 5), yslot_ops(4, 1, lo));
-    if (s == 3) r = interleave(dma_ops(5, 8), mrow_ops(0));
+    if (s == 2) r = dma_ops(0, 6);
+    if (s == 3) r = interleave(dma_ops(6, 11), mrow_ops(0));
     if (s == 4) { if (lo) { x.push(OP_XLO, 0, 0); x.push(OP_XLO, 0, 1); x.push(OP_XLO, 1, 0); x.push(OP_XLO, 1, 1); } r = interleave(x, mrow_ops(1)); }
     if (s == 5) { if (lo) { x.push(OP_XLO, 2, 0); x.push(OP_XLO, 2, 1); x.push(OP_XLO, 3, 0); x.push(OP_XLO, 3, 1); } r = interleave(x, mrow_ops(2)); }
     if (s == 6) { if (lo) { x.push(OP_XLO, 4, 0); x.push(OP_XLO, 4, 1); } r = interleave(x, mrow_ops(3)); }
@@ -111,9 +111,9 @@ constexpr OpList conv1_ops(int s, bool lo)     // row step s of conv_1 (x row 5h
 constexpr OpList conv2_ops(int s, bool lo)     // row step s of conv_2 (m row 5h + s): 12, 24, 36, 36, 36, 24, 12 MFMAs
 {
     OpList r;
-    if (s == 0) r = dma_ops(8, 9);
-    if (s == 1) r = dma_ops(9, 11);
-    if (s == 2) { r = dma_ops(11, 13); r.push(OP_XHI, 0, 0); r.push(OP_XHI, 0, 1); }
+    if (s == 0) r = dma_ops(11, 12);           // (pieces 11, 12 = patch rows 10.4 .. 12: two row steps ahead of the first store)
+    if (s == 1) r = dma_ops(12, 13);
+    if (s == 2) { r.push(OP_XHI, 0, 0); r.push(OP_XHI, 0, 1); }
     if (s == 3) r = yrow_ops(0, lo);
     if (s == 4) r = yrow_ops(1, lo);
     if (s == 5) r = yrow_ops(2, lo);
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) void arsb32c_kernel(ArsbArgs a)
         auto step1 = [&](auto S_) __attribute__((always_inline)) {
             constexpr int s = decltype(S_)::value;
             constexpr int nm = (s <= 4 ? 1 : 0) + ((s >= 1 && s <= 5) ? 1 : 0) + ((s >= 2) ? 1 : 0);      // rows this x row contributes to
-            if (s == 1) {       // barrier A: nobody reads m or the old x buffer any more; DMA pieces 8..12 of this patch (issued in the previous conv_2) have landed: behind
+            if (s == 1) {       // barrier A: nobody reads m or the old x buffer any more; the last DMA pieces of this patch (issued in the previous conv_2) have landed: behind
                                 // them went the stores of output rows 0 .. 3 (16 with the lo stream, else 8)
                 if (LO) __builtin_amdgcn_s_waitcnt(0x4F70);      // vmcnt(16)
                 else __builtin_amdgcn_s_waitcnt(0x0F78);         // vmcnt(8)
@@ -513,11 +513,11 @@ __global__ __launch_bounds__(256) void arsb32c_kernel(ArsbArgs a)
             }
         }
         A32_STAMP(8)
-        // DMA pieces 0..7 of patch p+1 and the late stores of patch p-1 are complete; the ten x_lo loads issued behind them may still fly
+        // the DMA pieces of patch p+1 issued in conv_1 and the late stores of patch p-1 are complete; the ten x_lo loads issued behind them may still fly
         if (LO) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         A32_STAMP(9)
-        __builtin_amdgcn_s_barrier();                         // barrier B: m is complete, pieces 0..7 of x[p+1] have landed for every wave
+        __builtin_amdgcn_s_barrier();                         // barrier B: m is complete, the pieces of x[p+1] issued in conv_1 have landed for every wave
         asm volatile("" ::: "memory");
         A32_STAMP(10)
 
@@ -537,9 +537,9 @@ __global__ __launch_bounds__(256) void arsb32c_kernel(ArsbArgs a)
 #pragma unroll
                 for (int f = 0; f < 12; ++f) fa[f] += d21;
             }
-            if (LO && s == 3) __builtin_amdgcn_s_waitcnt(0x0F75);      // vmcnt(5): the x_lo words of rows 0..3 (issued in conv_1's steps 4, 5; only DMA pieces 8..12 are
-                                                                        // younger) have landed BEFORE the first store goes out -- loads and stores share the counter, a
-                                                                        // later counted wait would also wait for store acknowledgements
+            if (LO && s == 3) __builtin_amdgcn_s_waitcnt(0x0F72);      // vmcnt(2): the x_lo words (issued in conv_1's steps 4..6; only DMA pieces 11, 12 are younger) have
+                                                                        // landed BEFORE the first store goes out -- loads and stores share the counter, a later counted
+                                                                        // wait would also wait for store acknowledgements
             auto chunk = [&](auto F_) __attribute__((always_inline)) {
                 constexpr int f = decltype(F_)::value;
                 constexpr int dx = f >> 2, ks = f & 3;
