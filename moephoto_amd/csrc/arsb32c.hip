@@ -133,7 +133,9 @@ constexpr int TRACE_LDS = 0;
 #define A32_STAMP(SLOT)
 #endif
 
-template <bool LO>
+// KS: 16-channel k-slices of the convs' INPUT that carry data -- 4, or 3 for the 48-channel nets (NetDN: channels 48..63 of every activation and
+// the weights on them are zero; the fourth slice's fragments, MFMAs and reads are simply left out: -25 % MFMAs, bit-identical results)
+template <bool LO, int KS>
 __global__ __launch_bounds__(256) void arsb32c_kernel(ArsbArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -279,7 +281,8 @@ __global__ __launch_bounds__(256) void arsb32c_kernel(ArsbArgs a)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int f = 0; f < 12; ++f) fr[f] = *(lds_h8_t)(fa[f]);
+        for (int f = 0; f < 12; ++f)
+            if ((f & 3) < KS) fr[f] = *(lds_h8_t)(fa[f]);
     }
 
     for (int p = 0; p < K; ++p) {
@@ -311,12 +314,12 @@ __global__ __launch_bounds__(256) void arsb32c_kernel(ArsbArgs a)
                 for (int f0 = 0; f0 < 12; f0 += 4) {
                     half8_t b4[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < KS; ++u) {
                         b4[u] = *(lds_h8_t)(fa[f0 + u] + rowa);
                         b4[u] = valid ? b4[u] : zero8;
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < KS; ++u) {
                         const int f = f0 + u, dx = f >> 2, ks = f & 3;
                         t = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[(dy * 3 + dx) * 4 + ks], b4[u], (dy == 0 && f == 0) ? zero16 : t, 0, 0, 0);
                     }
@@ -386,9 +389,6 @@ __global__ __launch_bounds__(256) void arsb32c_kernel(ArsbArgs a)
         };
         auto op_xlo = [&](auto I_, auto O_) __attribute__((always_inline)) {
             constexpr int i = decltype(I_)::value, o = decltype(O_)::value;
-#ifdef A32_NO_XLO4
-            if (i == 4) return;
-#endif
             xlo[i][o] = __builtin_amdgcn_raw_buffer_load_b128(rlo, vo + (unsigned)(o * 32), row_so(i), 0);
         };
         auto op_xhi = [&](auto I_, auto O_) __attribute__((always_inline)) {
@@ -424,9 +424,6 @@ __global__ __launch_bounds__(256) void arsb32c_kernel(ArsbArgs a)
             const unsigned so = i == 4 ? so4p : late ? so3p : row_so(i);
             const unsigned vv = (late ? vop : vo) + (unsigned)(o * 32);
             const u4_t dh = {sh[0], sh[1], sh[2], sh[3]};
-#ifdef A32_NO_ST
-            if (i < 3) return;
-#endif
             __builtin_amdgcn_raw_buffer_store_b128(dh, ryh, vv, so, 0);
             if (LO) {
                 const u4_t dl = {sl[0], sl[1], sl[2], sl[3]};
@@ -437,7 +434,8 @@ __global__ __launch_bounds__(256) void arsb32c_kernel(ArsbArgs a)
         auto run_ops = [&](auto PH_, auto S_, auto F_) __attribute__((always_inline)) {
             constexpr int PH = decltype(PH_)::value, S = decltype(S_)::value, F = decltype(F_)::value;
             constexpr OpList L = PH == 0 ? conv1_ops(S, LO) : PH == 1 ? conv2_ops(S, LO) : PH == 2 ? mrow_ops(4) : tail_ops(LO);
-            constexpr int lo = PH < 2 ? F * L.n / 12 : 0, hi = PH < 2 ? (F + 1) * L.n / 12 : L.n;
+            constexpr int NCH = 3 * KS;      // chunks of a row step that carry MFMAs (F: index among them)
+            constexpr int lo = PH < 2 ? F * L.n / NCH : 0, hi = PH < 2 ? (F + 1) * L.n / NCH : L.n;
             auto run = [&](auto I_) __attribute__((always_inline)) {
                 constexpr int I = decltype(I_)::value;
                 if constexpr (I >= lo && I < hi) {
@@ -474,6 +472,7 @@ __global__ __launch_bounds__(256) void arsb32c_kernel(ArsbArgs a)
             auto chunk = [&](auto F_) __attribute__((always_inline)) {
                 constexpr int f = decltype(F_)::value;
                 constexpr int dx = f >> 2, ks = f & 3;
+                if constexpr (ks >= KS) return;
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
                     const int i = s - dy;
@@ -481,7 +480,7 @@ __global__ __launch_bounds__(256) void arsb32c_kernel(ArsbArgs a)
                         acc[(i + 1) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[(dy * 3 + dx) * 4 + ks], fr[(f + 14 - s) % 14], (dy == 0 && f == 0) ? zero16 : acc[(i + 1) & 3], 0, 0, 0);
                 }
                 if (s < 6) fr[(f + 13 - s) % 14] = *(lds_h8_t)(fa[f] + (unsigned)((s + 1) * ROWB));
-                run_ops(std::integral_constant<int, 0>{}, S_, F_);
+                run_ops(std::integral_constant<int, 0>{}, S_, std::integral_constant<int, dx * KS + ks>{});
 #pragma unroll
                 for (int i_ = 0; i_ < 3; ++i_) {
                     if (i_ < nm) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -528,7 +527,8 @@ __global__ __launch_bounds__(256) void arsb32c_kernel(ArsbArgs a)
             for (int f = 0; f < 12; ++f) fa[f] += d12;
         }
 #pragma unroll
-        for (int f = 0; f < 12; ++f) fr[(f + 14 - 7) % 14] = *(lds_h8_t)(fa[f]);
+        for (int f = 0; f < 12; ++f)
+            if ((f & 3) < KS) fr[(f + 14 - 7) % 14] = *(lds_h8_t)(fa[f]);
         auto step2 = [&](auto S_) __attribute__((always_inline)) {
             constexpr int s = decltype(S_)::value;
             constexpr int nm = (s <= 4 ? 1 : 0) + ((s >= 1 && s <= 5) ? 1 : 0) + ((s >= 2) ? 1 : 0);
@@ -543,6 +543,7 @@ __global__ __launch_bounds__(256) void arsb32c_kernel(ArsbArgs a)
             auto chunk = [&](auto F_) __attribute__((always_inline)) {
                 constexpr int f = decltype(F_)::value;
                 constexpr int dx = f >> 2, ks = f & 3;
+                if constexpr (ks >= KS) return;
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
                     const int i = s - dy;
@@ -551,7 +552,7 @@ __global__ __launch_bounds__(256) void arsb32c_kernel(ArsbArgs a)
                 }
                 if (s < 6) fr[(f + 13 - (7 + s)) % 14] = *(lds_h8_t)(fa[f] + (unsigned)((s + 1) * ROWB));
                 else fr[f] = *(lds_h8_t)(fa[f]);            // row 0 of patch p+1's conv_1 (landed and published by barrier B): (f - 14) mod 14 = f
-                run_ops(std::integral_constant<int, 1>{}, S_, F_);
+                run_ops(std::integral_constant<int, 1>{}, S_, std::integral_constant<int, dx * KS + ks>{});
 #pragma unroll
                 for (int i_ = 0; i_ < 3; ++i_) {
                     if (i_ < nm) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -591,9 +592,11 @@ __global__ __launch_bounds__(256) void arsb32c_kernel(ArsbArgs a)
 
 hipError_t arsb32c_init()
 {
-    hipError_t e = hipFuncSetAttribute((const void*)arsb32c_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + TRACE_LDS);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)arsb32c_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + TRACE_LDS);
+    hipError_t e;
+    if ((e = hipFuncSetAttribute((const void*)arsb32c_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + TRACE_LDS)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)arsb32c_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + TRACE_LDS)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)arsb32c_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + TRACE_LDS)) != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)arsb32c_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + TRACE_LDS);
 }
 
 // w1 / w2: packed A fragments in the conv3x3_sp / pack_conv order (ConvLayer::w_hi).  false: the layer does not fit this kernel
@@ -607,7 +610,9 @@ bool launch_arsb32c(ArsbArgs a, int max_groups, hipStream_t s)
     const long long items = (long long)a.B * a.px * a.py;
     if (items >= (1ll << 31) / 256) return false;
     const int G = (int)std::min<long long>(items, max_groups);
-    if (a.x_lo) arsb32c_kernel<true><<<dim3(G), dim3(256), LDS_BYTES + TRACE_LDS, s>>>(a);
-    else arsb32c_kernel<false><<<dim3(G), dim3(256), LDS_BYTES + TRACE_LDS, s>>>(a);
+    if (a.cin != 0 && a.cin != 48 && a.cin != 64) return false;
+    const bool k3 = a.cin == 48;               // the fourth 16-channel k-slice carries zeros only
+    if (a.x_lo) { if (k3) arsb32c_kernel<true, 3><<<dim3(G), dim3(256), LDS_BYTES + TRACE_LDS, s>>>(a); else arsb32c_kernel<true, 4><<<dim3(G), dim3(256), LDS_BYTES + TRACE_LDS, s>>>(a); }
+    else { if (k3) arsb32c_kernel<false, 3><<<dim3(G), dim3(256), LDS_BYTES + TRACE_LDS, s>>>(a); else arsb32c_kernel<false, 4><<<dim3(G), dim3(256), LDS_BYTES + TRACE_LDS, s>>>(a); }
     return true;
 }

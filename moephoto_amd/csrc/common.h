@@ -121,6 +121,7 @@ struct ArsbArgs {
     float slope;                              // PReLU slope of conv_1 (<= 1)
     int B, H, W;
     int px, py;                               // set by the launcher
+    int cin;                                  // channels that carry data (0 = 64): arsb32c leaves the fourth k-slice out for the 48-channel nets
     unsigned long long* trace;                // -DARSB_TRACE builds only: s_memtime stamps [workgroup < 8][patch < 16][wave 4][slot 40]
 };
 bool launch_arsb_fused(ArsbArgs a, int max_groups, hipStream_t s);   // false: not applicable (caller runs the two convs)
