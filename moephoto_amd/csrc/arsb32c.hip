@@ -121,6 +121,25 @@ constexpr OpList conv2_ops(int s, bool lo)     // row step s of conv_2 (m row 5h
     return r;
 }
 
+// The counted vmcnt waits of the kernel are derived from these tables (one buffer instruction per DMA piece and x_lo word, one or two per ST):
+constexpr int count_ops(const OpList& l, int kind, int b = -1) { int n = 0; for (int i = 0; i < l.n; ++i) n += l.op[i].kind == kind && (b < 0 || l.op[i].b == b); return n; }
+constexpr int vm_ops(const OpList& l, bool lo) { return count_ops(l, OP_DMA, 1) + count_ops(l, OP_XLO) + count_ops(l, OP_ST) * (lo ? 2 : 1); }
+// barrier A (conv_1, step 1): everything up to the last DMA piece issued in conv_2 is complete = all but the stores issued behind it (conv_2's later steps, conv_1's step 0)
+constexpr int wait_a(bool lo)
+{
+    int n = 0, s = 6;
+    for (; s >= 0 && count_ops(conv2_ops(s, lo), OP_DMA) == 0; --s) n += vm_ops(conv2_ops(s, lo), lo);
+    return n + vm_ops(conv1_ops(0, lo), lo);
+}
+// barrier B: the DMA pieces issued in conv_1 are complete = all but the x_lo words requested behind them
+constexpr int wait_b(bool lo) { int n = 0; for (int s = 4; s < 7; ++s) n += count_ops(conv1_ops(s, lo), OP_XLO); return n; }
+// before conv_2's first store (step 3): the x_lo words are complete = all but the DMA pieces issued in conv_2
+constexpr int wait_c(bool lo) { int n = 0; for (int s = 0; s < 3; ++s) n += count_ops(conv2_ops(s, lo), OP_DMA, 1); return n; }
+static_assert(wait_a(true) == 16 && wait_a(false) == 8 && wait_b(true) == 10 && wait_b(false) == 0 && wait_c(true) == 2, "the s_waitcnt immediates in the kernel");
+static_assert(count_ops(conv1_ops(2, true), OP_XLO) + count_ops(conv1_ops(3, true), OP_XLO) == 0 && count_ops(conv1_ops(4, true), OP_DMA) + count_ops(conv1_ops(5, true), OP_DMA) + count_ops(conv1_ops(6, true), OP_DMA) == 0,
+              "conv_1: DMA pieces first, x_lo words behind them");
+static_assert(vm_ops(conv2_ops(0, true), true) + vm_ops(conv2_ops(1, true), true) + vm_ops(conv2_ops(2, true), true) == wait_c(true), "conv_2, steps 0..2: DMA pieces only");
+
 struct Item { int b, pxi, pyi; };
 
 // cycle-level trace (tools/mk_variant.sh trace32 arsb32c.hip -DA32_TRACE; tools/show_trace_a32.py)
