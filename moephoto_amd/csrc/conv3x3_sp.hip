@@ -233,6 +233,17 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
 #define MOE_DRAIN2 0      // 1: measured +0.9 % on the launch (the early k-steps get too crowded); the wait it shortens is 300 of 6,260 cycles
 #endif
     constexpr bool DRAIN2 = TAIL && MOE_DRAIN2;
+    // EPI 6 (SEDN's fused block tail: activation + residual): stores FIRST, loads behind them.  The default schedule alternates one store of the previous
+    // tile and one residual load of this one in every k-step, with the DMA pieces in between: every store is issued behind loads in flight and stalls
+    // the wave at issue until they return (arsb32c.hip, profiles/r03/k_arsb32c_trace.txt).  PHASED: the eight slices of the previous tile are drained in
+    // k-steps 0, 1 (nothing is in flight behind the barrier's vmcnt(0)), the DMA pieces go out in k-steps 2..7, the residual words of this tile in
+    // k-steps 2..9 (their registers were released in steps 0, 1); the wait in front of the barrier counts: all but the loads issued behind the last DMA
+    // piece.  l25 per 1080p frame: 34.2 -> 33.2 ms (parking the drained slices in registers and storing them in one burst behind the barrier, with
+    // the old load timing, measured the same: tools/r03_l.sh).
+#ifndef MOE_SP_PHASED
+#define MOE_SP_PHASED 1
+#endif
+    constexpr bool PHASED = (EPI == 6) && MOE_SP_PHASED;
     unsigned slope2;               // {slope, slope} as packed halves
     {
         typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
@@ -529,7 +540,8 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
                 // fragments of the NEXT iteration's k-step 0 are read while this step's twelve MFMAs run: no LDS round trip
                 // between the last MFMA of a tile and the first of the next.
                 MOE_STAMP(1)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (PHASED) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");      // (the three residual words requested behind the last DMA piece may still fly)
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 MOE_STAMP(2)
                 __builtin_amdgcn_s_barrier();      // bare: __syncthreads() carries a fence that drains vmcnt/lgkmcnt again
                 asm volatile("" ::: "memory");
@@ -537,8 +549,13 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
                 MOE_LOAD_STEP(0, 0, nbuf)
             }
             if (!(MOE_ABL & 1)) {   // compile-time timing ablation (tools/ablate_sp.sh); 0 in the product build
-                if (s < 5) { issue_piece(ps, 2 * s, nbuf); issue_piece(ps, 2 * s + 1, nbuf); }
-                if (s == 5) issue_piece(ps, 10, nbuf);
+                if (PHASED) {
+                    if (s >= 2 && s < 7) { issue_piece(ps, 2 * (s - 2), nbuf); issue_piece(ps, 2 * (s - 2) + 1, nbuf); }
+                    if (s == 7) issue_piece(ps, 10, nbuf);
+                } else {
+                    if (s < 5) { issue_piece(ps, 2 * s, nbuf); issue_piece(ps, 2 * s + 1, nbuf); }
+                    if (s == 5) issue_piece(ps, 10, nbuf);
+                }
             }
 #pragma unroll
             for (int pr = 0; pr < 4; ++pr)
@@ -551,12 +568,19 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
                             cur[o][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cb][dy][nb], af[cb][pr], (s == 0 && dy == 0) ? biasv[nb] : cur[o][nb], 0, 0, 0);
                     }
                 }
+            if (PHASED) {
+                if (s < 2) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) drain_slice(prev, itp, top, 4 * s + q, drain, resw, sidew);
+                }
+                if (s >= 2 && s < 10) fetch_res(toc, s - 2);
+            } else
             if (DRAIN2) {      // fused tail: two slices per step in k-steps 0..3 -- the tap-plane stores (slices 3 and 7) then have eight k-steps
                                // to be acknowledged before the vmcnt(0) in front of the barrier (traces: that wait was 300 cycles per patch)
                 if (!(MOE_ABL & 2) && s < 4) { drain_slice(prev, itp, top, 2 * s, drain, resw, sidew); drain_slice(prev, itp, top, 2 * s + 1, drain, resw, sidew); }
             } else
             if (!(MOE_ABL & 2) && s >= DRAIN0 && s < DRAIN0 + 8) drain_slice(prev, itp, top, s - DRAIN0, drain, resw, sidew);
-            if (RES && s >= DRAIN0 + 1 && s <= DRAIN0 + 8) fetch_res(toc, s - DRAIN0 - 1);   // slice s-1's registers were consumed in the previous step
+            if (RES && !PHASED && s >= DRAIN0 + 1 && s <= DRAIN0 + 8) fetch_res(toc, s - DRAIN0 - 1);   // slice s-1's registers were consumed in the previous step
             if (X3 && s >= DRAIN0 + 1 && s <= DRAIN0 + 8) fetch_side(toc, s - DRAIN0 - 1);
 #ifdef MOE_STEP_STAMPS
             MOE_STAMP(4 + s)
@@ -586,6 +610,12 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(ConvArgs a)
                 if (i < SGB_DSR_SLOTS) __builtin_amdgcn_sched_group_barrier(0x100, 10 / SGB_DSR_SLOTS, 0);
                 if (i < SGB_DSR_SLOTS) __builtin_amdgcn_sched_group_barrier(0x002, SGB_VALU_A, 0);
                 else __builtin_amdgcn_sched_group_barrier(0x002, SGB_VALU_B, 0);
+                if (PHASED) {
+                    if ((i == SGB_DMA_AT || i == SGB_DMA_AT + 1) && s >= 2 && s <= 7) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    if (i == SGB_DMA_AT + 2 && s >= 2 && s < 10) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    if ((i == 2 || i == 5 || i == 8 || i == 11) && s < 2) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+                    continue;
+                }
                 if ((i == SGB_DMA_AT || i == SGB_DMA_AT + 1) && s <= 5) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 if (RES && i == SGB_DMA_AT + 2 && s >= DRAIN0 + 1 && s <= DRAIN0 + 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 if (X3 && i == SGB_DMA_AT + 3 && s >= DRAIN0 + 1 && s <= DRAIN0 + 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
