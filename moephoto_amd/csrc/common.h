@@ -146,9 +146,15 @@ struct ConvX3Args {
     // optional (plain epilogue only): per-plane channel sums of the output, the global average pool of lite's FRM / LB (MoeNet_lite2.py:16-20,
     // models.py:274) without a second pass over the tensor: pool[b][workgroup][64], zeroed by the caller, pool_slabs >= workgroups
     float* pool; int pool_slabs;
+    // conv64_q8.hip only: w_hi as A fragments of v_mfma_f32_32x32x16_f16 (ConvLayer::w_hi, pack_conv order), w_hi 2^8 and w_lo 2^8 as fp8 e4m3
+    // A fragments of v_mfma_scale_f32_32x32x64_f8f6f4: [tap 9][channel half 2][lane 64][32 bytes]
+    const half_t* wq_hi16; const unsigned char* wq_hi8; const unsigned char* wq_lo8;
 };
 bool launch_conv64_x3(ConvX3Args a, int max_groups, hipStream_t s);   // false: not applicable (caller uses the three-launch form)
 hipError_t conv64_x3_init();
+// the same conv with its two correction products on fp8 operands (conv64_q8.hip); false: not applicable (caller uses conv64_x3)
+bool launch_conv64_q8(ConvX3Args a, int max_groups, hipStream_t s);
+hipError_t conv64_q8_init();
 
 // Workgroup count of a launch whose epilogue pools per plane into per-workgroup slabs (conv3x3_rw EPI 4, conv64_x3 EPI 3): a multiple or a divisor
 // of the patches per plane P, so that the patch -> workgroup map (item % G with item = plane * P + k) -- and with it every slab's content and

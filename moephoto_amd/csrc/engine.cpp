@@ -56,6 +56,7 @@ struct ConvLayer {               // one MFMA convolution
     bool per_plane = false;      // SEDN trans: weights rebuilt per plane by the SE kernel
     size_t w_hi = 0, w_lo = 0, bias = 0, bias_img = 0, w_plain = 0, bias_plain = 0, w_pk32 = 0;   // offsets into the device blob
     size_t w_arsb_lo = 0;        // ... and their low parts ((w - fp16(w)) * 2^11) in the same order, for conv64_x3.hip
+    size_t wq_hi8 = 0, wq_lo8 = 0;   // ... w_hi 2^8 and w_lo 2^8 as fp8 e4m3 A fragments of v_mfma_scale_f32_32x32x64_f8f6f4 (conv64_q8.hip): [tap 9][half 2][lane 64][32 B]
     size_t w_arsb = 0;           // 3x3 64->64 trunk convs: A fragments of v_mfma_f32_16x16x32_f16 in the fused ARSB kernel's order (arsb_fused.hip)
     size_t w_x3 = 0;             // 1x1, one segment, split precision: [chunk][w_lo | w_hi | w_hi] for the single-launch path (acc_mode 4)
     bool has_x3 = false;
@@ -88,6 +89,7 @@ struct NetOptions {
     bool conv1x1 = true;      // conv1x1     lite's 1x1 layers on conv1x1.hip (0: generic kernel)
     bool x3_fuse = true;      // x3_fuse     split-operand 3x3 64->64 layers as ONE launch (conv64_x3.hip; 0: three launches)
     bool arsb_fuse = true;    // arsb_fuse   single-pass ARSBs as one launch (0: two launches)
+    int x3_impl = 1;          // x3_impl     x3 (1, default: conv64_x3.hip, three fp16 products) | q8 (2: conv64_q8.hip, the two correction products on fp8 operands)
     int k48 = 1;              // k48         1 (default): kernels that can skip the zero k-slice of the 48-channel nets do | 0: they run all four (A/B)
     int arsb_impl = 3;        // arsb_impl   v3 (3, default: arsb32c.hip, 32x32x16 MFMAs, waves in lock-step, vertical continuation: ten rows per patch, no recomputed
                               //             m rows) | v2 (2: arsb32.hip, the same without continuation, eight rows per patch) | v1 (1: arsb_fused.hip, 16x16x32 MFMAs)
@@ -119,6 +121,7 @@ struct NetOptions {
         if (key == "sp_impl") { const int t = tri(v, "sp", "auto", "rw", -1); if (t < 0) return false; sp_impl = t; return true; }
         if (key == "tail_split") { const int t = tri(v, "0", "r", "ru", -1); if (t < 0) return false; tail_split = t; return true; }
         if (key == "tail_form") { const int t = tri(v, "planes", "sums", nullptr, -1); if (t < 0) return false; tail_form = t; return true; }
+        if (key == "x3_impl") { const int t = tri(v, nullptr, "x3", "q8", -1); if (t < 1) return false; x3_impl = t; return true; }
         if (key == "k48") { const int t = onoff(v); if (t < 0) return false; k48 = t; return true; }
         if (key == "arsb_impl") { const int t = (v && !strcmp(v, "v3")) ? 3 : tri(v, nullptr, "v1", "v2", -1); if (t < 1) return false; arsb_impl = t; return true; }
         if (key == "conv1x1") return flag(conv1x1);
@@ -136,7 +139,7 @@ struct NetOptions {
     void from_env()
     {
         static const char* const names[][2] = {{"MOE_CONV_IMPL", "conv_impl"}, {"MOE_SP_IMPL", "sp_impl"}, {"MOE_TAIL_SPLIT", "tail_split"}, {"MOE_TAIL_FORM", "tail_form"},
-                                               {"MOE_CONV1X1", "conv1x1"}, {"MOE_ARSB_IMPL", "arsb_impl"}, {"MOE_K48", "k48"}, {"MOE_X3_FUSE", "x3_fuse"}, {"MOE_ARSB_FUSE", "arsb_fuse"}, {"MOE_FUSE_TAIL", "fuse_tail"},
+                                               {"MOE_CONV1X1", "conv1x1"}, {"MOE_ARSB_IMPL", "arsb_impl"}, {"MOE_K48", "k48"}, {"MOE_X3_IMPL", "x3_impl"}, {"MOE_X3_FUSE", "x3_fuse"}, {"MOE_ARSB_FUSE", "arsb_fuse"}, {"MOE_FUSE_TAIL", "fuse_tail"},
                                                {"MOE_SEDN_FUSE", "sedn_fuse"}, {"MOE_POOL_FUSE", "pool_fuse"}, {"MOE_DBG", "dbg"}, {"MOE_TRACE_KEY", "trace_key"},
                                                {"MOE_TILES_PER_BATCH", "tiles_per_batch"}, {"MOE_MAX_GROUPS", "max_groups"}};
         for (const auto& nv : names)
@@ -380,6 +383,50 @@ static void pack_arsb(const Param& W, ConvLayer& L, BlobBuilder& bb, float fold,
         }
 }
 
+// OCP fp8 e4m3 (4 exponent bits, bias 7, no infinities, one NaN code; largest finite value 448), round to nearest even, saturating
+static unsigned char to_e4m3(float v)
+{
+    const unsigned char sign = std::signbit(v) ? 0x80 : 0;
+    float x = std::fabs(v);
+    if (!(x == x)) return sign | 0x7F;
+    if (x >= 448.f) return sign | 0x7E;
+    if (x < 0.0009765625f) return sign;                       // below half of the smallest subnormal (2^-9): zero (ties to even: 2^-10 -> 0)
+    int e;
+    (void)std::frexp(x, &e);                                  // x = m 2^e, m in [0.5, 1)
+    int ex = e - 1;                                           // x = 1.f 2^ex
+    if (ex < -6) ex = -6;                                     // subnormal: spacing 2^-9
+    const float q = std::ldexp(1.f, ex - 3);                  // spacing of the grid at this exponent
+    float n = std::nearbyint(x / q);                          // (default rounding mode: to nearest even)
+    float y = n * q;
+    if (y >= 448.f) return sign | 0x7E;
+    if (y < 0.015625f) return sign | (unsigned char)(int)std::nearbyint(y * 512.f);      // subnormal: mantissa = y / 2^-9
+    int e2;
+    const float m2 = std::frexp(y, &e2);                      // y = m2 2^e2
+    const int ebits = e2 - 1 + 7;
+    const int mbits = (int)std::nearbyint((m2 * 2.f - 1.f) * 8.f);
+    return sign | (unsigned char)((ebits << 3) | mbits);
+}
+
+// fp8 weight parts of a 3x3 64->64 conv for conv64_q8.hip: lane l of fragment (tap, half c) holds output channel 32c + (l & 31), input channels
+// 32 (l >> 5) .. + 31 of that tap; both parts carry a factor 2^8 (the kernel's E8M0 scale takes it out again)
+static void pack_q8(const Param& W, ConvLayer& L, BlobBuilder& bb, float fold)
+{
+    const int cout = (int)W.shape[0], cin = (int)W.shape[1];
+    L.wq_hi8 = bb.take((size_t)9 * 2 * 64 * 32);
+    L.wq_lo8 = bb.take((size_t)9 * 2 * 64 * 32);
+    for (int tap = 0; tap < 9; ++tap)
+        for (int c = 0; c < 2; ++c)
+            for (int l = 0; l < 64; ++l)
+                for (int b = 0; b < 32; ++b) {
+                    const int oc = 32 * c + (l & 31), ci = 32 * (l >> 5) + b;
+                    const float v = (oc < cout && ci < cin) ? W.data[((size_t)oc * cin + ci) * 9 + tap] * fold : 0.f;
+                    const half_t hv = (half_t)v;
+                    const size_t idx = ((size_t)(tap * 2 + c) * 64 + l) * 32 + b;
+                    bb.at<unsigned char>(L.wq_hi8)[idx] = to_e4m3((float)hv * 256.f);
+                    bb.at<unsigned char>(L.wq_lo8)[idx] = to_e4m3((float)(half_t)((v - (float)hv) * 2048.f) * 256.f);
+                }
+}
+
 static float scalar_of(const moe_net& n, const std::string& name) { return n.get(name)->data[0]; }
 
 static int build_device_weights(moe_net& n, int precision)
@@ -399,7 +446,10 @@ static int build_device_weights(moe_net& n, int precision)
         // every bias-free 3x3 conv with <= 64 channels in and out (the trunks of Net*x / NetDN, lite's LB convs, SEDN's rblock.0/2) also gets
         // the register-resident weight order of arsb_fused.hip / conv64_x3.hip (+ its low part where split operands may be asked for)
         if (!plain && r == 1 && L.taps == 9 && L.nseg == 1 && L.nchunks == 1 && !b && !per_plane)
+        {
             pack_arsb(*n.get(wname), L, bb, scale, lo);
+            if (lo) pack_q8(*n.get(wname), L, bb, scale);
+        }
         n.conv_index[key] = (int)n.convs.size();
         n.convs.push_back(L);
     };
@@ -755,7 +805,14 @@ struct Fwd {
                 q.slope = L.slope; q.B = B; q.H = H; q.W = W;
                 if (pool_out && !res && L.slope == 1.f) { q.pool = pool_out; q.pool_slabs = pool_slabs; }
                 const int rec = prof_begin(key, 3 * 2.0 * (double)B * H * W * L.cout * L.cin * L.taps);
-                const bool ok = launch_conv64_x3(q, n.max_groups, s);
+                bool ok = false;
+                if (n.opt.x3_impl == 2 && mixed && L.wq_hi8 && !q.pool) {      // the two correction products on fp8 operands (conv64_q8.hip): 'mixed' only --
+                                                                                // 'fp16x3' promises 2e-5, fp8 corrections deliver ~15 bits
+                    ConvX3Args q8 = q;
+                    q8.wq_hi16 = blob<half_t>(L.w_hi); q8.wq_hi8 = blob<unsigned char>(L.wq_hi8); q8.wq_lo8 = blob<unsigned char>(L.wq_lo8);
+                    ok = launch_conv64_q8(q8, n.max_groups, s);
+                }
+                if (!ok) ok = launch_conv64_x3(q, n.max_groups, s);
                 prof_end(rec);
                 if (ok) { pool_done = q.pool != nullptr; return true; }
             }

@@ -712,6 +712,29 @@ def test_fused_arsb_matches_two_launch_form(impl, dev):
             m.set_option('arsb_fuse', 1).set_option('arsb_impl', 'v3').set_option('max_groups', 0).set_option('k48', 1).set_exact_blocks(-1)
 
 
+@pytest.mark.parametrize('key', ['a2', 'a4', 'dn_lite5'])
+def test_exact_layers_with_fp8_corrections(key, dev):
+    """Option x3_impl = q8 (conv64_q8.hip): the split-operand layers with their two correction products on fp8 operands -- the corrections carry 2^-11 of
+    the result, so the output must stay inside the product's tolerance against the oracle and move by a small fraction of it against the fp16 form
+    (tests/emu_precision.py corr8 predicts +-1e-4 on noise)."""
+    arch = gd.MODELS[key][0]
+    sd = gd.state_dict_for(key, load_state_dict_file)
+    m = module_for(key)
+    try:
+        for shape in ((3, 24, 40), (2, 40, 264), (3, 9, 35), (2, 88, 64)):
+            for kind in ('natural', 'noise'):
+                x = (gd.natural_image(23, shape) if kind == 'natural' else gd.noise_image(23, shape))[:, None]
+                want = onets.forward(arch, sd, x).numpy()
+                xd = torch.from_numpy(x).to(dev)
+                y3 = m.set_option('x3_impl', 'x3')(xd)[-1].cpu().numpy()
+                y8 = m.set_option('x3_impl', 'q8')(xd)[-1].cpu().numpy()
+                assert np.isfinite(y8).all(), (key, shape, kind)
+                assert np.abs(y8 - want).max() <= TOL, (key, shape, kind, float(np.abs(y8 - want).max()), float(np.abs(y3 - want).max()))
+                assert np.abs(y8 - y3).max() <= 8e-4, (key, shape, kind, float(np.abs(y8 - y3).max()))      # (pointwise, noise; the error against the oracle moves by ~1e-4)
+    finally:
+        m.set_option('x3_impl', 'x3')
+
+
 RESIZE = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(G, 'resize', '*.npz')) if 'scale_factors' not in p)
 
 

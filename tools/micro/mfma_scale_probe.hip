@@ -33,6 +33,29 @@ __global__ void mfma_k(const unsigned char* A, const unsigned char* B, const int
     for (int r = 0; r < 16; ++r) D[l * 16 + r] = c[r];
 }
 
+// the kernel's use: A parked in AGPRs, C non-zero (C[r] = 1000 + r), uniform scales 108 / 129 held in VGPRs behind an opaque asm
+__global__ void mfma_k2(const unsigned char* A, const unsigned char* B, float* D)
+{
+    const int l = threadIdx.x;
+    i8v a, b;
+    for (int r = 0; r < 8; ++r) {
+        unsigned va = 0, vb = 0;
+        for (int q = 0; q < 4; ++q) {
+            const int k = (l >> 5) * 32 + 4 * r + q;
+            va |= (unsigned)A[(l & 31) * 64 + k] << (8 * q);
+            vb |= (unsigned)B[k * 32 + (l & 31)] << (8 * q);
+        }
+        a[r] = (int)va; b[r] = (int)vb;
+    }
+    asm volatile("" : "+a"(a));
+    int s_a = 127 - 19, s_b = 127 + 2;
+    asm volatile("" : "+v"(s_a), "+v"(s_b));
+    f16v c;
+    for (int r = 0; r < 16; ++r) c[r] = 1000.f + r;
+    c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, s_a, 0, s_b);
+    for (int r = 0; r < 16; ++r) D[l * 16 + r] = c[r];
+}
+
 __global__ void cvt_k(const float* x, unsigned* y, float* back, int n)
 {
     const int i = threadIdx.x + blockIdx.x * blockDim.x;
@@ -95,6 +118,22 @@ int main()
             printf("mfma_scale_f32_32x32x64 fp8 x fp8, test %d (%s), scale-lane hypothesis %d: max |device - hypothesis| = %.3e of max |C| = %.3e   %s\n", test,
                    test == 0 ? "scales 1" : test == 1 ? "per-lane scales" : "byte 0 only", hyp, worst, scale, worst <= 1e-4 * scale ? "HOLDS" : "mismatch");
         }
+    }
+    {
+        hipLaunchKernelGGL(mfma_k2, dim3(1), dim3(64), 0, 0, dA, dB, dD);
+        float D[64 * 16];
+        hipMemcpy(D, dD, sizeof D, hipMemcpyDeviceToHost);
+        double worst = 0, scale = 0;
+        for (int l = 0; l < 64; ++l)
+            for (int r = 0; r < 16; ++r) {
+                const int j = l & 31, i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+                double ref = 0;
+                for (int k = 0; k < 64; ++k) ref += (double)e4m3_to_float(A[i * 64 + k]) * (double)e4m3_to_float(B[k * 32 + j]);
+                ref = ref * std::ldexp(1.0, -17) + 1000.0 + r;
+                worst = std::fmax(worst, std::fabs(ref - D[l * 16 + r]));
+                scale = std::fmax(scale, std::fabs(ref - 1000.0 - r));
+            }
+        printf("A in AGPRs, C = 1000 + r, scales 108 / 129: max |device - hypothesis| = %.3e, max |product term| = %.3e   %s\n", worst, scale, worst <= 2e-4 ? "HOLDS" : "MISMATCH");
     }
     // conversions
     const float xs[] = {0.f, 1.f, 1.0625f, 1.1875f, 0.3f, 447.f, 448.f, 449.f, 464.f, 480.f, 1000.f, 1e6f, 0.001953125f, 0.0009765625f, 0.0015f, 1e-4f, 17.f, 18.f, 19.f};
