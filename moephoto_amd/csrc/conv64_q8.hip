@@ -248,12 +248,18 @@ __global__ __launch_bounds__(256) void conv64_q8_kernel(ConvX3Args a)
             u4_t d = {0u, 0u, 0u, 0u};
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                unsigned p0 = 0, p1 = 0;
+                unsigned p0, p1;
                 const unsigned a0 = w0[2 * k], a1 = w0[2 * k + 1], b0 = w1[2 * k], b1 = w1[2 * k + 1];
-                asm volatile("v_cvt_scalef32_pk_fp8_f16 %0, %1, %2" : "+v"(p0) : "v"(a0), "v"(quarter));
-                asm volatile("v_cvt_scalef32_pk_fp8_f16 %0, %1, %2 op_sel:[0,0,1]" : "+v"(p0) : "v"(a1), "v"(quarter));
-                asm volatile("v_cvt_scalef32_pk_fp8_f16 %0, %1, %2" : "+v"(p1) : "v"(b0), "v"(quarter));
-                asm volatile("v_cvt_scalef32_pk_fp8_f16 %0, %1, %2 op_sel:[0,0,1]" : "+v"(p1) : "v"(b1), "v"(quarter));
+                // One block, the two words' conversions alternating, a wait state at its end: a conversion writes HALF a register, and gfx950 wants one
+                // wait state between such a write and the next VALU use of the register (the half-word is not forwarded).  The compiler's hazard
+                // recognizer places that state for its own instructions and cannot see into inline asm: issued back to back, the second conversion of a
+                // word at times kept a stale first half -- results that changed from run to run (tools/diag_q8_batch.py).
+                asm volatile("v_cvt_scalef32_pk_fp8_f16 %0, %2, %6\n\t"
+                             "v_cvt_scalef32_pk_fp8_f16 %1, %4, %6\n\t"
+                             "v_cvt_scalef32_pk_fp8_f16 %0, %3, %6 op_sel:[0,0,1]\n\t"
+                             "v_cvt_scalef32_pk_fp8_f16 %1, %5, %6 op_sel:[0,0,1]\n\t"
+                             "s_nop 0"
+                             : "=&v"(p0), "=&v"(p1) : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(quarter));
                 d[k] = p0; d[2 + k] = p1;
             }
 #ifdef Q8_CONST_IMAGE
