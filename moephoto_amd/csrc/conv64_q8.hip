@@ -267,6 +267,9 @@ __global__ __launch_bounds__(256) void conv64_q8_kernel(ConvX3Args a)
 #endif
             return d;
         };
+        // MODE.FP16_OVFL for the length of the conversion: with it the fp8 conversions saturate at +-448 (without: NaN beyond 464, i.e. for activations beyond
+        // 1856 -- tools/micro/cvt_ovfl_probe.hip); the epilogues' fp16 conversions keep their IEEE overflow, so it is switched off again behind the last one
+        asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1\n\ts_nop 3" ::: "memory");
         // units 0..3: pixel tid (0..255), all four 16-channel slots -- consecutive lanes are consecutive pixels with the same logical slot, the access pattern
         // both images are swizzled for; the pixel's row / column arithmetic is done once
         {
@@ -308,6 +311,7 @@ __global__ __launch_bounds__(256) void conv64_q8_kernel(ConvX3Args a)
                 asm volatile("ds_write_b128 %0, %1" ::"v"(adr), "v"(d) : "memory");
             }
         }
+        asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 0\n\ts_nop 3" ::: "memory");
     };
 
     float16_t acc[4];

@@ -89,7 +89,8 @@ struct NetOptions {
     bool conv1x1 = true;      // conv1x1     lite's 1x1 layers on conv1x1.hip (0: generic kernel)
     bool x3_fuse = true;      // x3_fuse     split-operand 3x3 64->64 layers as ONE launch (conv64_x3.hip; 0: three launches)
     bool arsb_fuse = true;    // arsb_fuse   single-pass ARSBs as one launch (0: two launches)
-    int x3_impl = 1;          // x3_impl     x3 (1, default: conv64_x3.hip, three fp16 products) | q8 (2: conv64_q8.hip, the two correction products on fp8 operands)
+    int x3_impl = 0;          // x3_impl     auto (0, default: q8 for the SR nets, x3 for the DN nets -- see forward) | x3 (1: conv64_x3.hip, three fp16 products) |
+                              //             q8 (2: conv64_q8.hip, the two correction products on fp8 operands)
     int k48 = 1;              // k48         1 (default): kernels that can skip the zero k-slice of the 48-channel nets do | 0: they run all four (A/B)
     int arsb_impl = 3;        // arsb_impl   v3 (3, default: arsb32c.hip, 32x32x16 MFMAs, waves in lock-step, vertical continuation: ten rows per patch, no recomputed
                               //             m rows) | v2 (2: arsb32.hip, the same without continuation, eight rows per patch) | v1 (1: arsb_fused.hip, 16x16x32 MFMAs)
@@ -121,7 +122,7 @@ struct NetOptions {
         if (key == "sp_impl") { const int t = tri(v, "sp", "auto", "rw", -1); if (t < 0) return false; sp_impl = t; return true; }
         if (key == "tail_split") { const int t = tri(v, "0", "r", "ru", -1); if (t < 0) return false; tail_split = t; return true; }
         if (key == "tail_form") { const int t = tri(v, "planes", "sums", nullptr, -1); if (t < 0) return false; tail_form = t; return true; }
-        if (key == "x3_impl") { const int t = tri(v, nullptr, "x3", "q8", -1); if (t < 1) return false; x3_impl = t; return true; }
+        if (key == "x3_impl") { const int t = tri(v, "auto", "x3", "q8", -1); if (t < 0) return false; x3_impl = t; return true; }
         if (key == "k48") { const int t = onoff(v); if (t < 0) return false; k48 = t; return true; }
         if (key == "arsb_impl") { const int t = (v && !strcmp(v, "v3")) ? 3 : tri(v, nullptr, "v1", "v2", -1); if (t < 1) return false; arsb_impl = t; return true; }
         if (key == "conv1x1") return flag(conv1x1);
@@ -412,6 +413,9 @@ static unsigned char to_e4m3(float v)
 static void pack_q8(const Param& W, ConvLayer& L, BlobBuilder& bb, float fold)
 {
     const int cout = (int)W.shape[0], cin = (int)W.shape[1];
+    // a weight of 1.75 or more would saturate (448 / 2^8) and its correction product would be wrong by the excess: such a layer keeps conv64_x3
+    for (size_t i = 0; i < (size_t)cout * cin * 9; ++i)
+        if (!(std::fabs(W.data[i] * fold) < 1.75f)) return;
     L.wq_hi8 = bb.take((size_t)9 * 2 * 64 * 32);
     L.wq_lo8 = bb.take((size_t)9 * 2 * 64 * 32);
     for (int tap = 0; tap < 9; ++tap)
@@ -806,8 +810,11 @@ struct Fwd {
                 if (pool_out && !res && L.slope == 1.f) { q.pool = pool_out; q.pool_slabs = pool_slabs; }
                 const int rec = prof_begin(key, 3 * 2.0 * (double)B * H * W * L.cout * L.cin * L.taps);
                 bool ok = false;
-                if (n.opt.x3_impl == 2 && mixed && L.wq_hi8 && !q.pool) {      // the two correction products on fp8 operands (conv64_q8.hip): 'mixed' only --
-                                                                                // 'fp16x3' promises 2e-5, fp8 corrections deliver ~15 bits
+                // The two correction products on fp8 operands (conv64_q8.hip): 'mixed' only -- 'fp16x3' promises 2e-5, fp8 corrections deliver ~15 bits.
+                // auto: the SR nets, whose all-tile sweep keeps its margin with it (worst 8.1e-4 either way, profiles/r03/m_conv64_q8.txt); the DN nets
+                // (dn_lite5 7.2e-4 -> 8.6e-4 of the 1e-3 bar) stay on three fp16 products.
+                const bool use_q8 = n.opt.x3_impl == 2 || (n.opt.x3_impl == 0 && n.scale > 1);
+                if (use_q8 && mixed && L.wq_hi8 && !q.pool) {
                     ConvX3Args q8 = q;
                     q8.wq_hi16 = blob<half_t>(L.w_hi); q8.wq_hi8 = blob<unsigned char>(L.wq_hi8); q8.wq_lo8 = blob<unsigned char>(L.wq_lo8);
                     ok = launch_conv64_q8(q8, n.max_groups, s);

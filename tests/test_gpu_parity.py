@@ -731,8 +731,33 @@ def test_exact_layers_with_fp8_corrections(key, dev):
                 assert np.isfinite(y8).all(), (key, shape, kind)
                 assert np.abs(y8 - want).max() <= TOL, (key, shape, kind, float(np.abs(y8 - want).max()), float(np.abs(y3 - want).max()))
                 assert np.abs(y8 - y3).max() <= 8e-4, (key, shape, kind, float(np.abs(y8 - y3).max()))      # (pointwise, noise; the error against the oracle moves by ~1e-4)
+                y8b = m(xd)[-1].cpu().numpy()
+                assert np.array_equal(y8, y8b), (key, shape, kind)      # (same launch twice: the conversions' half-register writes once raced)
+        # activations beyond the fp8 range (1856 = 4 x 464): the conversions saturate, the corrections of those pixels lose their meaning (2^-11 of the value) and
+        # nothing else happens -- in particular no NaN, which is what the conversion instruction produces when MODE.FP16_OVFL is off
+        x = gd.noise_image(29, (3, 40, 72))[:, None] * 6000.0
+        xd = torch.from_numpy(x).to(dev)
+        y3 = m.set_option('x3_impl', 'x3')(xd)[-1].cpu().numpy()
+        y8 = m.set_option('x3_impl', 'q8')(xd)[-1].cpu().numpy()
+        assert np.isfinite(y3).all() and np.abs(y3).max() > 1856.0, (key, float(np.abs(y3).max()))
+        assert np.isfinite(y8).all(), key
+        assert np.abs(y8 - y3).max() <= 2e-3 * np.abs(y3).max(), (key, float(np.abs(y8 - y3).max()), float(np.abs(y3).max()))
     finally:
-        m.set_option('x3_impl', 'x3')
+        m.set_option('x3_impl', 'auto')
+
+
+def test_fp8_corrections_default_by_family(dev):
+    """x3_impl = auto: the SR nets run their exact layers through conv64_q8 (bit-equal to the explicit setting), the DN nets through conv64_x3."""
+    for key, same_as in (('a2', 'q8'), ('dn_lite5', 'x3')):
+        m = module_for(key)
+        try:
+            xd = torch.from_numpy(gd.noise_image(31, (2, 40, 72))[:, None]).to(dev)
+            ya = m.set_option('x3_impl', 'auto')(xd)[-1]
+            for impl in ('x3', 'q8'):
+                yi = m.set_option('x3_impl', impl)(xd)[-1]
+                assert torch.equal(ya, yi) == (impl == same_as), (key, impl)
+        finally:
+            m.set_option('x3_impl', 'auto')
 
 
 RESIZE = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(G, 'resize', '*.npz')) if 'scale_factors' not in p)
@@ -879,7 +904,7 @@ def test_split_operand_conv_single_launch(dev):
             taps = {}
             want = onets.forward(arch, sd, x, 'torch', taps).numpy()
             xd = torch.from_numpy(x).to(dev)
-            m = module_for(key, 'mixed').set_exact_blocks(6).set_debug(True)
+            m = module_for(key, 'mixed').set_exact_blocks(6).set_debug(True).set_option('x3_impl', 'x3')      # (conv64_q8's fp8 corrections have their own test)
             res = {}
             for fuse in ('0', '1'):
                 y = m.set_option('x3_fuse', fuse)(xd)[-1].cpu().numpy()
@@ -893,4 +918,4 @@ def test_split_operand_conv_single_launch(dev):
             assert np.abs(res['1'][0] - want).max() <= TOL
     finally:
         if m is not None:
-            m.set_option('x3_fuse', 1).set_debug(False).set_exact_blocks(-1)
+            m.set_option('x3_fuse', 1).set_option('x3_impl', 'auto').set_debug(False).set_exact_blocks(-1)
