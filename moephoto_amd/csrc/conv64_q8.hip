@@ -74,8 +74,9 @@ constexpr OpList yrow_ops(int i, bool act)
     }
     return r;
 }
-// SHORT pass, row step s (a_lo row 4h + s: 3, 6, 9, 9, 6, 3 fp8 MFMAs).  EPI 2: the residual words of all four output rows are requested in steps 0, 1 (the
-// fp16 fragment registers are free in this pass) and added to a row's accumulator once its own products of this pass are in (row i: steps i .. i+2)
+// SHORT pass, row step s (a_lo row 4h + s: 3, 6, 9, 9, 6, 3 fp8 MFMAs).  EPI 2: the residual words of all four output rows are requested at the head of the
+// patch, ahead of the first conversion (64 registers nobody else wants until the long pass: a load takes 3-4k cycles at this kernel's 4 TB/s, requested
+// inside this pass they were waited for) and added to a row's accumulator once its own products of this pass are in (row i: steps i .. i+2)
 // -- and the pass carries the DMA of a_lo[p+1] (its buffer is free since the conversion that opened the patch)
 constexpr OpList short_ops(int s, bool res)
 {
@@ -86,10 +87,7 @@ constexpr OpList short_ops(int s, bool res)
     if (s == 3) r = dma_ops(0, 6, 9);
     if (s == 4) r = dma_ops(0, 9, 11);
     if (!res) return r;
-    if (s == 0) r.push(OP_RLD, 0);
-    if (s == 1) r.push(OP_RLD, 1);
-    if (s == 2) r.push(OP_RLD, 2);
-    if (s == 3) { r.push(OP_RLD, 3); r.push(OP_RADD, 0, 0); r.push(OP_RADD, 0, 1); }
+    if (s == 3) { r.push(OP_RADD, 0, 0); r.push(OP_RADD, 0, 1); }
     if (s == 4) { r.push(OP_RADD, 1, 0); r.push(OP_RADD, 1, 1); }
     if (s == 5) { r.push(OP_RADD, 2, 0); r.push(OP_RADD, 2, 1); }
     return r;
@@ -114,6 +112,14 @@ constexpr int stores_per_patch = 16;
 #endif
 
 struct Item { int b, pyi, pxi; };
+
+// experiment (tools/mk_variant.sh q8nolo conv64_q8.hip -DQ8_NOLO): the low-part tensors' descriptors cover nothing -- loads and DMA return zero, stores are dropped,
+// the instruction stream is the same: what the launches would take without those bytes through HBM (profiles/r03/o_stream_bytes.txt)
+#ifdef Q8_NOLO
+#define Q8_LO_BYTES(n) 0u
+#else
+#define Q8_LO_BYTES(n) (n)
+#endif
 
 // cycle-level trace (tools/mk_variant.sh traceq8 conv64_q8.hip -DQ8_TRACE; tools/show_trace_q8.py): s_memtime stamps of patches 4 and 7 of the first eight
 // workgroups, buffered in LDS and written to a.pool (repurposed: 8 x 2 x 4 x 32 x 8 bytes) when the workgroup is done
@@ -197,11 +203,11 @@ __global__ __launch_bounds__(256) void conv64_q8_kernel(ConvX3Args a)
     const unsigned in_pad = (unsigned)(a.W + 1) * 128u;
     const unsigned nbytes = (unsigned)a.B * a.H * a.W * 128u;
     const __amdgpu_buffer_rsrc_t rhi = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.in_hi - in_pad), 0, nbytes + in_pad, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rlo = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.in_lo - in_pad), 0, nbytes + in_pad, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rlo = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.in_lo - in_pad), 0, Q8_LO_BYTES(nbytes + in_pad), 0x00020000);
     const __amdgpu_buffer_rsrc_t rrh = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? a.res_hi : a.in_hi), 0, nbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rrl = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? a.res_lo : a.in_hi), 0, nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrl = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? a.res_lo : a.in_hi), 0, Q8_LO_BYTES(nbytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t ryh = __builtin_amdgcn_make_buffer_rsrc((void*)a.out_hi, 0, nbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ryl = __builtin_amdgcn_make_buffer_rsrc((void*)a.out_lo, 0, nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ryl = __builtin_amdgcn_make_buffer_rsrc((void*)a.out_lo, 0, Q8_LO_BYTES(nbytes), 0x00020000);
     const int qlane = w4 * 8 + (lane >> 3);
     unsigned d_off = 0, d_r = 0, d_cc = 0;
     auto piece_addr = [&](int i) {
@@ -351,6 +357,15 @@ __global__ __launch_bounds__(256) void conv64_q8_kernel(ConvX3Args a)
         const unsigned vo = (x0 + j < a.W) ? lane_ob : kOOR;
         auto row_so = [&](int i) { return (y0 + 4 * h + i < a.H) ? so0 + (unsigned)(i * a.W * 128) : kOOR; };
 
+        auto op_rld = [&](auto I_) __attribute__((always_inline)) {
+            constexpr int i = decltype(I_)::value;
+            const unsigned so = row_so(i);
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                rl[i][o] = __builtin_amdgcn_raw_buffer_load_b128(rrh, vo + (unsigned)(o * 32), so, 0);
+                rl[i][2 + o] = __builtin_amdgcn_raw_buffer_load_b128(rrl, vo + (unsigned)(o * 32), so, 0);
+            }
+        };
         Q8_STAMP(0)
         // a_hi[p] and a_lo[p] have landed: everything but the stores issued behind the last DMA piece of the patch before (first patch: the prologue's pieces)
         if (p == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -359,6 +374,7 @@ __global__ __launch_bounds__(256) void conv64_q8_kernel(ConvX3Args a)
         __builtin_amdgcn_s_barrier();                         // ... for every wave, and everybody has left the long pass of the patch before (the fp8 image is free)
         asm volatile("" ::: "memory");
         Q8_STAMP(1)
+        if (RES) { op_rld(std::integral_constant<int, 0>{}); op_rld(std::integral_constant<int, 1>{}); op_rld(std::integral_constant<int, 2>{}); op_rld(std::integral_constant<int, 3>{}); }
         to_fp8_image(lbase);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         Q8_STAMP(2)
@@ -374,15 +390,6 @@ __global__ __launch_bounds__(256) void conv64_q8_kernel(ConvX3Args a)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rlo, (__attribute__((address_space(3))) void*)((char*)smem + dlo + i * 4096), 16, piece_off(i, yan, xan, has_next), orgn, 0, 0);
             else
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rhi, (__attribute__((address_space(3))) void*)((char*)smem + dnx + i * 4096), 16, piece_off(i, yan, xan, has_next), orgn, 0, 0);
-        };
-        auto op_rld = [&](auto I_) __attribute__((always_inline)) {
-            constexpr int i = decltype(I_)::value;
-            const unsigned so = row_so(i);
-#pragma unroll
-            for (int o = 0; o < 2; ++o) {
-                rl[i][o] = __builtin_amdgcn_raw_buffer_load_b128(rrh, vo + (unsigned)(o * 32), so, 0);
-                rl[i][2 + o] = __builtin_amdgcn_raw_buffer_load_b128(rrl, vo + (unsigned)(o * 32), so, 0);
-            }
         };
         auto op_radd = [&](auto I_, auto O_) __attribute__((always_inline)) {      // acc += res_hi + res_lo 2^-11 for the eight channels of slot o
             constexpr int i = decltype(I_)::value, o = decltype(O_)::value;

@@ -55,12 +55,14 @@ def layer_names(arch):
     return out
 
 
-def forward(arch, sd, x, w16=(), a16=(), stream16=False, corr8=(), shifts=(8, 4)):
+def forward(arch, sd, x, w16=(), a16=(), stream16=False, corr8=(), shifts=(8, 4), lo8=False):
     """w16 / a16: names of the convs whose weights / input activations are rounded to fp16 ('all' = every conv);
     stream16: the trunk stream is stored as fp16 after conv_input2 and after every ARSB.
     corr8: convs computed as  conv(w16, a16) + conv(fp8(w - w16), fp8(a16)) + conv(fp8(w16), fp8(a - a16))  -- the split-operand form with its two
     correction products on fp8 operands (scaled by 2^shifts[0] for weights, 2^shifts[1] for activations): a study for the block-scaled fp8 MFMA, which
-    runs at twice the fp16 rate (`python tests/emu_precision.py corr8`)."""
+    runs at twice the fp16 rate (`python tests/emu_precision.py corr8`).
+    lo8: the trunk stream is stored as fp16 + an fp8 e4m3 low part ((t - fp16(t)) 2^9, the operand the fp8 correction product reads anyway): 192 instead of
+    256 bytes a pixel through HBM, ~15 bits of the value (`python tests/emu_precision.py lo8`)."""
     T = lambda k: torch.from_numpy(np.asarray(sd[k], dtype=np.float32))
     r = 3 if arch == 'net3x' else 2
 
@@ -77,14 +79,17 @@ def forward(arch, sd, x, w16=(), a16=(), stream16=False, corr8=(), shifts=(8, 4)
     x = torch.from_numpy(np.asarray(x, dtype=np.float32))
     out = prelu(F.conv2d(x, T('conv_input.weight'), padding=1), float(T('relu.weight')[0]))       # the stem is fp32 in every mode
     t = conv('input2', out, T('conv_input2.weight'))
+    s8 = (lambda v: r16(v) + q8(v - r16(v), 9)) if lo8 else (lambda v: v)
     if stream16:
         t = r16(t)
+    t = s8(t)
     for i in range(1, 7):
         p = 'convt_F{}.0.'.format(i)
         m = prelu(conv('c1_%d' % i, t, T(p + 'conv_1.weight')), float(T(p + 'relu.weight')[0]))
         t = t + conv('c2_%d' % i, m, T(p + 'conv_2.weight') * float(T(p + 'scale.scale')[0]))    # ScaleLayer folded into the weights (fp32 product)
         if stream16:
             t = r16(t)
+        t = s8(t)
     if arch == 'netdn':
         return conv('r.tail', t, T('convt_R1.weight')) + conv('u.tail', out, T('u.weight'))
 
@@ -213,6 +218,21 @@ def main(argv):
     cmd = argv[1] if len(argv) > 1 else 'budget'
     if cmd == 'lite':
         lite_budget(tuple(argv[2:]) or ('lite2', 'lite4', 'lite8'))
+        return
+    if cmd == 'lo8':        # the trunk stream's low part stored as fp8: error against fp32 beside the present form (both with fp8 corrections on the exact layers)
+        for key in (argv[2:] or ['a2', 'a3', 'a4', 'dn_lite5']):
+            arch, sd = gd.MODELS[key][0], _load(key)
+            n = DEFAULT_EXACT[arch]
+            ex = ['input2'] + ['c%d_%d' % (j, i) for i in range(1, n + 1) for j in (1, 2)]
+            for kind, shape, seed in (('noise', (3, 96, 96), 5), ('noise-u8', (3, 256, 256), 0), ('noise-u8', (3, 256, 256), 1), ('natural', (3, 40, 264), 5)):
+                x = gd.natural_image(seed, shape) if kind == 'natural' else gd.noise_image(seed, shape) if kind == 'noise' else gd.noise_u8(seed, shape).astype(np.float32) / 255.0
+                x = x[:, None]
+                with torch.no_grad():
+                    want = forward(arch, sd, x)
+                    w16, a16, s16 = mode_sets(arch, 'mixed', n)
+                    e = [float((forward(arch, sd, x, w16, a16, s16, corr8=ex, lo8=l) - want).abs().max()) for l in (False, True)]
+                    e16 = float((forward(arch, sd, x, w16, a16, True, corr8=ex) - want).abs().max())
+                print('%-9s %-8s n=%d: hi+lo stream %.3e | hi + fp8 lo %.3e | fp16 stream %.3e' % (key, kind, n, e[0], e[1], e16), flush=True)
         return
     if cmd == 'corr8':      # the exact layers of 'mixed' with fp8 correction products: error against fp32, beside the present form
         for key in (argv[2:] or ['a2', 'a4', 'dn_lite5']):
