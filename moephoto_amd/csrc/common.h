@@ -149,6 +149,8 @@ struct ConvX3Args {
     // conv64_q8.hip only: w_hi as A fragments of v_mfma_f32_32x32x16_f16 (ConvLayer::w_hi, pack_conv order), w_hi 2^8 and w_lo 2^8 as fp8 e4m3
     // A fragments of v_mfma_scale_f32_32x32x64_f8f6f4: [tap 9][channel half 2][lane 64][32 bytes]
     const half_t* wq_hi16; const unsigned char* wq_hi8; const unsigned char* wq_lo8;
+    // conv64_q8.hip only: in_lo (and res_lo) / out_lo hold fp8 e4m3 words -- (v - fp16(v)) 2^11 / 4, one byte a channel, [B][H][W][64] -- instead of fp16
+    int in8, out8;
 };
 bool launch_conv64_x3(ConvX3Args a, int max_groups, hipStream_t s);   // false: not applicable (caller uses the three-launch form)
 hipError_t conv64_x3_init();

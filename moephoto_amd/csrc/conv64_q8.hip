@@ -40,9 +40,13 @@ constexpr int NDMA_W = 11;                     // 1-KiB pieces per wave: 44 >= 3
 constexpr int XBYTES = NDMA_W * 4 * 1024;      // 45,056
 constexpr int ROWB = XW * 128, ROWB8 = XW * 64;
 constexpr int Q8BYTES = 22 * 1024;             // fp8 image: 340 x 64 = 21,760 B
-constexpr int LDS_BYTES = 3 * XBYTES + Q8BYTES;      // 157,696
+constexpr int NDMA8_W = 6;                     // IN8: 1-KiB pieces of the fp8 a_lo image per wave (22 of the 24 exist; the other two land in DUMP)
+constexpr int DUMP = 3 * XBYTES + Q8BYTES;     // 1 KiB nobody reads
+constexpr int LDS_BYTES = DUMP + 1024;         // 158,720
 
 typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+typedef float f2_t __attribute__((ext_vector_type(2)));
 typedef int i8v_t __attribute__((ext_vector_type(8)));
 typedef _Float16 h2v_t __attribute__((ext_vector_type(2)));
 typedef short s2v_t __attribute__((ext_vector_type(2)));
@@ -78,14 +82,22 @@ constexpr OpList yrow_ops(int i, bool act)
 // patch, ahead of the first conversion (64 registers nobody else wants until the long pass: a load takes 3-4k cycles at this kernel's 4 TB/s, requested
 // inside this pass they were waited for) and added to a row's accumulator once its own products of this pass are in (row i: steps i .. i+2)
 // -- and the pass carries the DMA of a_lo[p+1] (its buffer is free since the conversion that opened the patch)
-constexpr OpList short_ops(int s, bool res)
+constexpr OpList short_ops(int s, bool res, bool in8)
 {
     OpList r;
-    if (s == 0) r = dma_ops(0, 0, 1);
-    if (s == 1) r = dma_ops(0, 1, 3);
-    if (s == 2) r = dma_ops(0, 3, 6);
-    if (s == 3) r = dma_ops(0, 6, 9);
-    if (s == 4) r = dma_ops(0, 9, 11);
+    if (!in8) {
+        if (s == 0) r = dma_ops(0, 0, 1);
+        if (s == 1) r = dma_ops(0, 1, 3);
+        if (s == 2) r = dma_ops(0, 3, 6);
+        if (s == 3) r = dma_ops(0, 6, 9);
+        if (s == 4) r = dma_ops(0, 9, 11);
+    } else {                                   // the fp8 low part: six 1-KiB pieces per wave (16 pixels each)
+        if (s == 0) r = dma_ops(0, 0, 1);
+        if (s == 1) r = dma_ops(0, 1, 2);
+        if (s == 2) r = dma_ops(0, 2, 4);
+        if (s == 3) r = dma_ops(0, 4, 5);
+        if (s == 4) r = dma_ops(0, 5, 6);
+    }
     if (!res) return r;
     if (s == 3) { r.push(OP_RADD, 0, 0); r.push(OP_RADD, 0, 1); }
     if (s == 4) { r.push(OP_RADD, 1, 0); r.push(OP_RADD, 1, 1); }
@@ -132,15 +144,20 @@ constexpr int TRACE_LDS = 0;
 #endif
 
 // EPI 0 plain | 1 PReLU (fp32, slope <= 1) | 2 + residual (hi + lo 2^-11)
-template <int EPI>
+// IN8 / OUT8: the low part of the input (and of the residual) / of the output is stored as fp8 e4m3 -- the word the correction product reads, (v - fp16(v)) 2^11 / 4
+// (ConvX3Args::in8 / out8): 64 bytes a pixel instead of 128, and the a_lo image comes by DMA instead of through a conversion
+template <int EPI, bool IN8, bool OUT8>
 __global__ __launch_bounds__(256) void conv64_q8_kernel(ConvX3Args a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr unsigned kOOR = 0xFFFF0000u;
     constexpr bool RES = EPI == 2, ACT = EPI == 1;
+    // MODE.FP16_OVFL for the whole kernel: with it the fp8 conversions saturate at +-448 (without: NaN beyond 464, i.e. for activations beyond 1856 --
+    // tools/micro/cvt_ovfl_probe.hip).  The epilogue's fp16 conversions then clamp at 65504 where IEEE gives infinity: beyond the range either way.
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1\n\ts_nop 3" ::: "memory");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
-    const unsigned lbase = lds0 + 2u * XBYTES, qbase = lds0 + 3u * XBYTES;
+    const unsigned lbase = lds0 + 2u * XBYTES, qbase = lds0 + 3u * XBYTES;      // lbase: a_lo as fp16 (IN8: two fp8 a_lo images, patches p & 1), qbase: the fp8 image the conversions write
     const int tid = threadIdx.x, lane = tid & 63;
     const int w4 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = w4 & 1, h = w4 >> 1;
@@ -203,11 +220,12 @@ __global__ __launch_bounds__(256) void conv64_q8_kernel(ConvX3Args a)
     const unsigned in_pad = (unsigned)(a.W + 1) * 128u;
     const unsigned nbytes = (unsigned)a.B * a.H * a.W * 128u;
     const __amdgpu_buffer_rsrc_t rhi = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.in_hi - in_pad), 0, nbytes + in_pad, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rlo = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.in_lo - in_pad), 0, Q8_LO_BYTES(nbytes + in_pad), 0x00020000);
+    const unsigned in_pad_lo = IN8 ? in_pad / 2 : in_pad, nbytes_in_lo = IN8 ? nbytes / 2 : nbytes, nbytes_out_lo = OUT8 ? nbytes / 2 : nbytes;
+    const __amdgpu_buffer_rsrc_t rlo = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.in_lo - in_pad_lo), 0, Q8_LO_BYTES(nbytes_in_lo + in_pad_lo), 0x00020000);
     const __amdgpu_buffer_rsrc_t rrh = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? a.res_hi : a.in_hi), 0, nbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rrl = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? a.res_lo : a.in_hi), 0, Q8_LO_BYTES(nbytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrl = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? a.res_lo : a.in_hi), 0, Q8_LO_BYTES(nbytes_in_lo), 0x00020000);      // (the residual's format is the input's)
     const __amdgpu_buffer_rsrc_t ryh = __builtin_amdgcn_make_buffer_rsrc((void*)a.out_hi, 0, nbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ryl = __builtin_amdgcn_make_buffer_rsrc((void*)a.out_lo, 0, Q8_LO_BYTES(nbytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ryl = __builtin_amdgcn_make_buffer_rsrc((void*)a.out_lo, 0, Q8_LO_BYTES(nbytes_out_lo), 0x00020000);
     const int qlane = w4 * 8 + (lane >> 3);
     unsigned d_off = 0, d_r = 0, d_cc = 0;
     auto piece_addr = [&](int i) {
@@ -224,6 +242,22 @@ __global__ __launch_bounds__(256) void conv64_q8_kernel(ConvX3Args a)
         return ok ? d_off : kOOR;
     };
     auto origin = [&](const Item& it) { return (unsigned)((it.b * a.H + it.pyi * TH - 1) * a.W + it.pxi * TW - 1 + a.W + 1) * 128u; };
+    // IN8: the a_lo image is fetched as it is read -- 64 bytes a pixel, 16 pixels per 1-KiB piece, piece i of wave w is piece 4 i + w of the image (22 pieces);
+    // lane l writes physical slot l & 3 of pixel 16 (4 i + w) + (l >> 2) and fetches the logical slot behind it (fp8 image swizzle: s ^ ((col >> 2) & 3))
+    const int qlane8 = w4 * 16 + (lane >> 2);
+    auto piece8_addr = [&](int i) {
+        unsigned q = (unsigned)(i * 64 + qlane8);
+        asm volatile("" : "+v"(q));
+        d_r = __umul24(q, 241u) >> 13;
+        d_cc = (unsigned)(__mul24((int)d_r, -XW) + (int)q);
+        const unsigned sl = (unsigned)(lane & 3) ^ ((d_cc >> 2) & 3u);
+        d_off = ((__umul24(d_r, (unsigned)a.W) + d_cc) << 6) | (sl << 4);
+    };
+    auto piece8_off = [&](int i, int ya, int xa, bool live) {
+        bool ok = ((unsigned)(ya + (int)d_r) < (unsigned)a.H) & ((unsigned)(xa + (int)d_cc) < (unsigned)a.W) & live;
+        if (i * 64 + 63 >= NPIX) ok &= (i * 64 + qlane8 < NPIX);
+        return ok ? d_off : kOOR;
+    };
 
     // ---- LDS addressing.  fp16 image: pixel (row, col) at (row * 34 + col) * 128, 16-B slot s (8 channels) at s ^ ((col >> 1) & 7); B fragment (dx, ks):
     // lane (j, hh) reads slot 2 ks + hh of column j + dx.  fp8 image: pixel at (row * 34 + col) * 64, 16-B slot s (16 channels) at s ^ ((col >> 2) & 3); B
@@ -246,26 +280,29 @@ __global__ __launch_bounds__(256) void conv64_q8_kernel(ConvX3Args a)
 
     // fp16 patch -> fp8 image (all 256 threads): unit u = (pixel q, 16-channel slot s8): two 16-byte reads, eight conversions (value / 4), one 16-byte
     // write; six units per thread, all twelve reads first.  Units behind the last pixel repeat unit (339, s8): same data to the same place, no branch.
+    const float quarter = 4.0f;                               // the source is DIVIDED by the scale operand
+    // four packed fp16 pairs -> two words of four fp8 each.  One block, the two words' conversions alternating, a wait state at its end: a conversion writes
+    // HALF a register, and gfx950 wants one wait state between such a write and the next VALU use of the register (the half-word is not forwarded).  The
+    // compiler's hazard recognizer places that state for its own instructions and cannot see into inline asm: issued back to back, the second conversion
+    // of a word at times kept a stale first half -- results that changed from run to run (tools/diag_q8_batch.py).
+    // (inline asm: through __builtin_amdgcn_cvt_scalef32_pk_fp8_f16 this compiler converted the first word of a slot four times and read nothing else of
+    // it -- found with the constant-image experiment of tools/diag_q8.py)
+    auto cvt4 = [&](unsigned a0, unsigned a1, unsigned b0, unsigned b1, unsigned& p0, unsigned& p1) __attribute__((always_inline)) {
+        asm volatile("v_cvt_scalef32_pk_fp8_f16 %0, %2, %6\n\t"
+                     "v_cvt_scalef32_pk_fp8_f16 %1, %4, %6\n\t"
+                     "v_cvt_scalef32_pk_fp8_f16 %0, %3, %6 op_sel:[0,0,1]\n\t"
+                     "v_cvt_scalef32_pk_fp8_f16 %1, %5, %6 op_sel:[0,0,1]\n\t"
+                     "s_nop 0"
+                     : "=&v"(p0), "=&v"(p1) : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(quarter));
+    };
     auto to_fp8_image = [&](unsigned srcbase) {
-        const float quarter = 4.0f;                           // the source is DIVIDED by the scale operand
-        // (inline asm: through __builtin_amdgcn_cvt_scalef32_pk_fp8_f16 this compiler converted the first word of a slot four times and read
-        // nothing else of it -- found with the constant-image experiment of tools/diag_q8.py)
         auto cvt16 = [&](const u4_t& w0, const u4_t& w1) {
             u4_t d = {0u, 0u, 0u, 0u};
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 unsigned p0, p1;
                 const unsigned a0 = w0[2 * k], a1 = w0[2 * k + 1], b0 = w1[2 * k], b1 = w1[2 * k + 1];
-                // One block, the two words' conversions alternating, a wait state at its end: a conversion writes HALF a register, and gfx950 wants one
-                // wait state between such a write and the next VALU use of the register (the half-word is not forwarded).  The compiler's hazard
-                // recognizer places that state for its own instructions and cannot see into inline asm: issued back to back, the second conversion of a
-                // word at times kept a stale first half -- results that changed from run to run (tools/diag_q8_batch.py).
-                asm volatile("v_cvt_scalef32_pk_fp8_f16 %0, %2, %6\n\t"
-                             "v_cvt_scalef32_pk_fp8_f16 %1, %4, %6\n\t"
-                             "v_cvt_scalef32_pk_fp8_f16 %0, %3, %6 op_sel:[0,0,1]\n\t"
-                             "v_cvt_scalef32_pk_fp8_f16 %1, %5, %6 op_sel:[0,0,1]\n\t"
-                             "s_nop 0"
-                             : "=&v"(p0), "=&v"(p1) : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(quarter));
+                cvt4(a0, a1, b0, b1, p0, p1);
                 d[k] = p0; d[2 + k] = p1;
             }
 #ifdef Q8_CONST_IMAGE
@@ -273,9 +310,6 @@ __global__ __launch_bounds__(256) void conv64_q8_kernel(ConvX3Args a)
 #endif
             return d;
         };
-        // MODE.FP16_OVFL for the length of the conversion: with it the fp8 conversions saturate at +-448 (without: NaN beyond 464, i.e. for activations beyond
-        // 1856 -- tools/micro/cvt_ovfl_probe.hip); the epilogues' fp16 conversions keep their IEEE overflow, so it is switched off again behind the last one
-        asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1\n\ts_nop 3" ::: "memory");
         // units 0..3: pixel tid (0..255), all four 16-channel slots -- consecutive lanes are consecutive pixels with the same logical slot, the access pattern
         // both images are swizzled for; the pixel's row / column arithmetic is done once
         {
@@ -317,7 +351,6 @@ __global__ __launch_bounds__(256) void conv64_q8_kernel(ConvX3Args a)
                 asm volatile("ds_write_b128 %0, %1" ::"v"(adr), "v"(d) : "memory");
             }
         }
-        asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 0\n\ts_nop 3" ::: "memory");
     };
 
     float16_t acc[4];
@@ -335,7 +368,16 @@ __global__ __launch_bounds__(256) void conv64_q8_kernel(ConvX3Args a)
             piece_addr(i);
             const unsigned off = piece_off(i, it_cur.pyi * TH - 1, it_cur.pxi * TW - 1, true);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rhi, (__attribute__((address_space(3))) void*)(smem + (i * 4 + w4) * 1024), 16, off, org, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rlo, (__attribute__((address_space(3))) void*)(smem + 2 * XBYTES + (i * 4 + w4) * 1024), 16, off, org, 0, 0);
+            if (!IN8) __builtin_amdgcn_raw_ptr_buffer_load_lds(rlo, (__attribute__((address_space(3))) void*)(smem + 2 * XBYTES + (i * 4 + w4) * 1024), 16, off, org, 0, 0);
+        }
+        if (IN8) {
+#pragma unroll
+            for (int i = 0; i < NDMA8_W; ++i) {
+                piece8_addr(i);
+                const unsigned off = piece8_off(i, it_cur.pyi * TH - 1, it_cur.pxi * TW - 1, true);
+                const int dst = (i * 4 + w4 < 22) ? 2 * XBYTES + (i * 4 + w4) * 1024 : DUMP;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rlo, (__attribute__((address_space(3))) void*)(smem + dst), 16, off, org >> 1, 0, 0);
+            }
         }
     }
 
@@ -346,7 +388,9 @@ __global__ __launch_bounds__(256) void conv64_q8_kernel(ConvX3Args a)
         const unsigned xcur = lds0 + (unsigned)((p & 1) * XBYTES);
         const unsigned orgn = (unsigned)__builtin_amdgcn_readfirstlane((int)origin(itn));
         const int yan = __builtin_amdgcn_readfirstlane(itn.pyi * TH - 1), xan = __builtin_amdgcn_readfirstlane(itn.pxi * TW - 1);
-        const unsigned dlo = (unsigned)__builtin_amdgcn_readfirstlane(2 * XBYTES + w4 * 1024), dnx = (unsigned)__builtin_amdgcn_readfirstlane(((p + 1) & 1) * XBYTES + w4 * 1024);
+        const unsigned dlo = (unsigned)__builtin_amdgcn_readfirstlane(2 * XBYTES + (IN8 ? ((p + 1) & 1) * Q8BYTES : 0) + w4 * 1024), dnx = (unsigned)__builtin_amdgcn_readfirstlane(((p + 1) & 1) * XBYTES + w4 * 1024);
+        const unsigned dlo5 = (unsigned)__builtin_amdgcn_readfirstlane(w4 < 2 ? (int)dlo + 5 * 4096 : DUMP);      // IN8: pieces 22, 23 of the image do not exist
+        const unsigned qshort = IN8 ? (unsigned)(p & 1) * Q8BYTES - (unsigned)XBYTES : 0u;      // short pass: where its fp8 image lies relative to qbase
         const int y0 = it.pyi * TH, x0 = it.pxi * TW;
 #ifdef Q8_TRACE
         const bool trace_on = a.pool && g < 8 && (p == 4 || p == 7);
@@ -356,6 +400,8 @@ __global__ __launch_bounds__(256) void conv64_q8_kernel(ConvX3Args a)
         const unsigned so0 = (unsigned)(((it.b * a.H + y0 + 4 * h) * a.W + x0) * 128);
         const unsigned vo = (x0 + j < a.W) ? lane_ob : kOOR;
         auto row_so = [&](int i) { return (y0 + 4 * h + i < a.H) ? so0 + (unsigned)(i * a.W * 128) : kOOR; };
+        const unsigned vo8 = (x0 + j < a.W) ? lane_ob >> 1 : kOOR;      // the same for a tensor of 64 bytes a pixel (fp8 low parts)
+        auto row_so8 = [&](int i) { return (y0 + 4 * h + i < a.H) ? (so0 >> 1) + (unsigned)(i * a.W * 64) : kOOR; };
 
         auto op_rld = [&](auto I_) __attribute__((always_inline)) {
             constexpr int i = decltype(I_)::value;
@@ -363,7 +409,11 @@ __global__ __launch_bounds__(256) void conv64_q8_kernel(ConvX3Args a)
 #pragma unroll
             for (int o = 0; o < 2; ++o) {
                 rl[i][o] = __builtin_amdgcn_raw_buffer_load_b128(rrh, vo + (unsigned)(o * 32), so, 0);
-                rl[i][2 + o] = __builtin_amdgcn_raw_buffer_load_b128(rrl, vo + (unsigned)(o * 32), so, 0);
+                if (!IN8) rl[i][2 + o] = __builtin_amdgcn_raw_buffer_load_b128(rrl, vo + (unsigned)(o * 32), so, 0);
+                else {
+                    const u2_t t = __builtin_amdgcn_raw_buffer_load_b64(rrl, vo8 + (unsigned)(o * 16), row_so8(i), 0);
+                    rl[i][2 + o][0] = t[0]; rl[i][2 + o][1] = t[1];
+                }
             }
         };
         Q8_STAMP(0)
@@ -375,17 +425,22 @@ __global__ __launch_bounds__(256) void conv64_q8_kernel(ConvX3Args a)
         asm volatile("" ::: "memory");
         Q8_STAMP(1)
         if (RES) { op_rld(std::integral_constant<int, 0>{}); op_rld(std::integral_constant<int, 1>{}); op_rld(std::integral_constant<int, 2>{}); op_rld(std::integral_constant<int, 3>{}); }
-        to_fp8_image(lbase);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        Q8_STAMP(2)
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+        if (!IN8) {
+            to_fp8_image(lbase);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            Q8_STAMP(2)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
         Q8_STAMP(3)
 
         // ---- micro-ops ------------------------------------------------------------------------------------------------------------------------------------
         auto op_dma = [&](auto IMG_, auto I_, auto HALF_) __attribute__((always_inline)) {      // image 0: a_lo of the next patch, 1: its a_hi
             constexpr int img = decltype(IMG_)::value, i = decltype(I_)::value, half = decltype(HALF_)::value;
-            if constexpr (half == 0) piece_addr(i);
+            if constexpr (img == 0 && IN8) {
+                if constexpr (half == 0) piece8_addr(i);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rlo, (__attribute__((address_space(3))) void*)((char*)smem + (i == 5 ? dlo5 : dlo + i * 4096)), 16, piece8_off(i, yan, xan, has_next), orgn >> 1, 0, 0);
+            } else if constexpr (half == 0) piece_addr(i);
             else if constexpr (img == 0)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rlo, (__attribute__((address_space(3))) void*)((char*)smem + dlo + i * 4096), 16, piece_off(i, yan, xan, has_next), orgn, 0, 0);
             else
@@ -397,7 +452,11 @@ __global__ __launch_bounds__(256) void conv64_q8_kernel(ConvX3Args a)
             for (int k = 0; k < 4; ++k) {
                 float v0 = acc[i][8 * o + 2 * k], v1 = acc[i][8 * o + 2 * k + 1];
                 v0 = mix_lo(rl[i][o][k], 1.0f, v0); v1 = mix_hi(rl[i][o][k], 1.0f, v1);
-                v0 = mix_lo(rl[i][2 + o][k], 0.00048828125f, v0); v1 = mix_hi(rl[i][2 + o][k], 0.00048828125f, v1);
+                if (!IN8) { v0 = mix_lo(rl[i][2 + o][k], 0.00048828125f, v0); v1 = mix_hi(rl[i][2 + o][k], 0.00048828125f, v1); }
+                else {      // fp8 low part: the stored word is lo / 4, lo in units of 2^-11
+                    const f2_t f = (k & 1) ? __builtin_amdgcn_cvt_pk_f32_fp8((int)rl[i][2 + o][k >> 1], true) : __builtin_amdgcn_cvt_pk_f32_fp8((int)rl[i][2 + o][k >> 1], false);
+                    v0 = __builtin_fmaf(f[0], 0.001953125f, v0); v1 = __builtin_fmaf(f[1], 0.001953125f, v1);
+                }
                 acc[i][8 * o + 2 * k] = v0; acc[i][8 * o + 2 * k + 1] = v1;
             }
         };
@@ -416,12 +475,17 @@ __global__ __launch_bounds__(256) void conv64_q8_kernel(ConvX3Args a)
             const unsigned so = row_so(i), vv = vo + (unsigned)(o * 32);
             const u4_t dh = {sh[0], sh[1], sh[2], sh[3]}, dl = {sl[0], sl[1], sl[2], sl[3]};
             __builtin_amdgcn_raw_buffer_store_b128(dh, ryh, vv, so, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(dl, ryl, vv, so, 0);
+            if (!OUT8) __builtin_amdgcn_raw_buffer_store_b128(dl, ryl, vv, so, 0);
+            else {
+                unsigned p0, p1;
+                cvt4(sl[0], sl[1], sl[2], sl[3], p0, p1);
+                __builtin_amdgcn_raw_buffer_store_b64(u2_t{p0, p1}, ryl, vo8 + (unsigned)(o * 16), row_so8(i), 0);
+            }
         };
         // the ops [f n / NCH, (f + 1) n / NCH) of a list: PH 1 the short pass (3 chunks), 2 the long pass (12 chunks), 3 row 3's epilogue behind it (all ops)
         auto run_ops = [&](auto PH_, auto S_, auto F_) __attribute__((always_inline)) {
             constexpr int PH = decltype(PH_)::value, S = decltype(S_)::value, F = decltype(F_)::value;
-            constexpr OpList L = PH == 1 ? short_ops(S, RES) : PH == 2 ? long_ops(S, ACT) : yrow_ops(3, ACT);
+            constexpr OpList L = PH == 1 ? short_ops(S, RES, IN8) : PH == 2 ? long_ops(S, ACT) : yrow_ops(3, ACT);
             constexpr int NCH = PH == 1 ? 3 : 12;
             constexpr int lo = PH < 3 ? F * L.n / NCH : 0, hi = PH < 3 ? (F + 1) * L.n / NCH : L.n;
             auto run = [&](auto I_) __attribute__((always_inline)) {
@@ -442,17 +506,17 @@ __global__ __launch_bounds__(256) void conv64_q8_kernel(ConvX3Args a)
             Q8_OP(32) Q8_OP(33) Q8_OP(34) Q8_OP(35) Q8_OP(36) Q8_OP(37) Q8_OP(38) Q8_OP(39)
 #undef Q8_OP
         };
-        auto read_q8 = [&](int dx, int row) {             // the fp8 B fragment dx of image row 4h + row
+        auto read_q8 = [&](int dx, int row, unsigned rel = 0u) {      // the fp8 B fragment dx of image row 4h + row (rel: the image's offset from qbase, a multiple of 32)
             unsigned ad = fq[dx];
             asm volatile("" : "+v"(ad));                      // (see fa_of)
-            ad += (unsigned)(row * ROWB8);                    // (image rows are 2,176 bytes: bit 4 of a row offset is clear)
+            ad += (unsigned)(row * ROWB8) + rel;              // (image rows are 2,176 bytes: bit 4 of a row offset is clear)
             const u4_t lo4 = *(lds_u4_t)(ad), hi4 = *(lds_u4_t)(ad ^ 16u);
             return i8v_t{(int)lo4[0], (int)lo4[1], (int)lo4[2], (int)lo4[3], (int)hi4[0], (int)hi4[1], (int)hi4[2], (int)hi4[3]};
         };
 
         // ================= SHORT pass: a_lo rows 4h .. 4h+5: acc = w_hi8 a_lo8 (fp8) ===================================================================================
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) fr8[dx] = read_q8(dx, 0);
+        for (int dx = 0; dx < 3; ++dx) fr8[dx] = read_q8(dx, 0, qshort);
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] = zero16;      // (explicit: the scaled MFMA takes no literal as its C operand, a zero tuple of sixteen registers would be kept)
         auto step_s = [&](auto S_) __attribute__((always_inline)) {
@@ -466,7 +530,7 @@ __global__ __launch_bounds__(256) void conv64_q8_kernel(ConvX3Args a)
                     if (i >= 0 && i < 4 && !(Q8_DBG & 2))
                         acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wh8[dy * 3 + dx], fr8[(dx + 4 - (s & 3)) & 3], acc[i], 0, 0, 0, scale_a, 0, scale_b);
                 }
-                if (s < 5) fr8[(dx + 3 - (s & 3)) & 3] = read_q8(dx, s + 1);
+                if (s < 5) fr8[(dx + 3 - (s & 3)) & 3] = read_q8(dx, s + 1, qshort);
                 run_ops(std::integral_constant<int, 1>{}, S_, DX_);
 #pragma unroll
                 for (int i_ = 0; i_ < 3; ++i_) {
@@ -564,10 +628,10 @@ __global__ __launch_bounds__(256) void conv64_q8_kernel(ConvX3Args a)
 #endif
 }
 
-template <int EPI>
+template <int EPI, bool IN8, bool OUT8>
 hipError_t set_limit()
 {
-    return hipFuncSetAttribute((const void*)conv64_q8_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + TRACE_LDS);
+    return hipFuncSetAttribute((const void*)conv64_q8_kernel<EPI, IN8, OUT8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + TRACE_LDS);
 }
 
 }  // namespace
@@ -575,9 +639,13 @@ hipError_t set_limit()
 hipError_t conv64_q8_init()
 {
     hipError_t e;
-    if ((e = set_limit<0>()) != hipSuccess) return e;
-    if ((e = set_limit<1>()) != hipSuccess) return e;
-    return set_limit<2>();
+    if ((e = set_limit<0, false, false>()) != hipSuccess) return e;
+    if ((e = set_limit<0, false, true>()) != hipSuccess) return e;
+    if ((e = set_limit<1, false, false>()) != hipSuccess) return e;
+    if ((e = set_limit<1, true, true>()) != hipSuccess) return e;
+    if ((e = set_limit<2, false, false>()) != hipSuccess) return e;
+    if ((e = set_limit<2, true, true>()) != hipSuccess) return e;
+    return set_limit<2, true, false>();
 }
 
 // false: the layer does not fit this kernel (caller uses conv64_x3)
@@ -611,8 +679,19 @@ bool launch_conv64_q8(ConvX3Args a, int max_groups, hipStream_t s)
     const long long items = (long long)a.B * a.px * a.py;
     const int G = (int)std::min<long long>(items, max_groups);
     const dim3 grid(G), blk(256);
-    if (a.res_hi) conv64_q8_kernel<2><<<grid, blk, LDS_BYTES + TRACE_LDS, s>>>(a);
-    else if (a.slope != 1.f) conv64_q8_kernel<1><<<grid, blk, LDS_BYTES + TRACE_LDS, s>>>(a);
-    else conv64_q8_kernel<0><<<grid, blk, LDS_BYTES + TRACE_LDS, s>>>(a);
+    // formats of the low parts (in8: input and residual, out8: output) -- the combinations a chain of these layers needs (engine.cpp, forward):
+    //   conv_input2 fp16 -> fp8 | conv_1 fp8 -> fp8 | conv_2 fp8 -> fp8, and fp8 -> fp16 for the last one (the fused ARSB kernels read fp16 low parts)
+    const int epi = a.res_hi ? 2 : a.slope != 1.f ? 1 : 0, fmt = epi * 4 + (a.in8 ? 2 : 0) + (a.out8 ? 1 : 0);
+    const size_t lds = LDS_BYTES + TRACE_LDS;
+    switch (fmt) {
+    case 0: conv64_q8_kernel<0, false, false><<<grid, blk, lds, s>>>(a); break;
+    case 1: conv64_q8_kernel<0, false, true><<<grid, blk, lds, s>>>(a); break;
+    case 4: conv64_q8_kernel<1, false, false><<<grid, blk, lds, s>>>(a); break;
+    case 7: conv64_q8_kernel<1, true, true><<<grid, blk, lds, s>>>(a); break;
+    case 8: conv64_q8_kernel<2, false, false><<<grid, blk, lds, s>>>(a); break;
+    case 11: conv64_q8_kernel<2, true, true><<<grid, blk, lds, s>>>(a); break;
+    case 10: conv64_q8_kernel<2, true, false><<<grid, blk, lds, s>>>(a); break;
+    default: return false;
+    }
     return true;
 }

@@ -64,7 +64,9 @@ struct ConvLayer {               // one MFMA convolution
     int nfrag() const { return nseg * taps * 8; }
 };
 
-struct Act { half_t* hi = nullptr; half_t* lo = nullptr; };
+// an activation tensor: fp16 [B][H][W][C] and (split operands / the trunk stream of 'mixed') its low part, (v - fp16(v)) 2^11, as fp16 in the same layout --
+// or, lo8, as the fp8 e4m3 word of that value / 4 (one byte a channel): the form conv64_q8.hip reads and writes between its own layers
+struct Act { half_t* hi = nullptr; half_t* lo = nullptr; bool lo8 = false; };
 
 struct Arena {                   // bump allocator over the net's workspace (dry run when base == nullptr)
     char* base = nullptr;
@@ -89,6 +91,7 @@ struct NetOptions {
     bool conv1x1 = true;      // conv1x1     lite's 1x1 layers on conv1x1.hip (0: generic kernel)
     bool x3_fuse = true;      // x3_fuse     split-operand 3x3 64->64 layers as ONE launch (conv64_x3.hip; 0: three launches)
     bool arsb_fuse = true;    // arsb_fuse   single-pass ARSBs as one launch (0: two launches)
+    int lo8 = 1;              // lo8         on (default): between conv64_q8 layers the low parts travel as fp8 words (64 instead of 128 bytes a pixel) | off
     int x3_impl = 0;          // x3_impl     auto (0, default: q8 for the SR nets, x3 for the DN nets -- see forward) | x3 (1: conv64_x3.hip, three fp16 products) |
                               //             q8 (2: conv64_q8.hip, the two correction products on fp8 operands)
     int k48 = 1;              // k48         1 (default): kernels that can skip the zero k-slice of the 48-channel nets do | 0: they run all four (A/B)
@@ -122,6 +125,7 @@ struct NetOptions {
         if (key == "sp_impl") { const int t = tri(v, "sp", "auto", "rw", -1); if (t < 0) return false; sp_impl = t; return true; }
         if (key == "tail_split") { const int t = tri(v, "0", "r", "ru", -1); if (t < 0) return false; tail_split = t; return true; }
         if (key == "tail_form") { const int t = tri(v, "planes", "sums", nullptr, -1); if (t < 0) return false; tail_form = t; return true; }
+        if (key == "lo8") { const int t = onoff(v); if (t < 0) return false; lo8 = t; return true; }
         if (key == "x3_impl") { const int t = tri(v, "auto", "x3", "q8", -1); if (t < 0) return false; x3_impl = t; return true; }
         if (key == "k48") { const int t = onoff(v); if (t < 0) return false; k48 = t; return true; }
         if (key == "arsb_impl") { const int t = (v && !strcmp(v, "v3")) ? 3 : tri(v, nullptr, "v1", "v2", -1); if (t < 1) return false; arsb_impl = t; return true; }
@@ -140,7 +144,7 @@ struct NetOptions {
     void from_env()
     {
         static const char* const names[][2] = {{"MOE_CONV_IMPL", "conv_impl"}, {"MOE_SP_IMPL", "sp_impl"}, {"MOE_TAIL_SPLIT", "tail_split"}, {"MOE_TAIL_FORM", "tail_form"},
-                                               {"MOE_CONV1X1", "conv1x1"}, {"MOE_ARSB_IMPL", "arsb_impl"}, {"MOE_K48", "k48"}, {"MOE_X3_IMPL", "x3_impl"}, {"MOE_X3_FUSE", "x3_fuse"}, {"MOE_ARSB_FUSE", "arsb_fuse"}, {"MOE_FUSE_TAIL", "fuse_tail"},
+                                               {"MOE_CONV1X1", "conv1x1"}, {"MOE_ARSB_IMPL", "arsb_impl"}, {"MOE_K48", "k48"}, {"MOE_X3_IMPL", "x3_impl"}, {"MOE_LO8", "lo8"}, {"MOE_X3_FUSE", "x3_fuse"}, {"MOE_ARSB_FUSE", "arsb_fuse"}, {"MOE_FUSE_TAIL", "fuse_tail"},
                                                {"MOE_SEDN_FUSE", "sedn_fuse"}, {"MOE_POOL_FUSE", "pool_fuse"}, {"MOE_DBG", "dbg"}, {"MOE_TRACE_KEY", "trace_key"},
                                                {"MOE_TILES_PER_BATCH", "tiles_per_batch"}, {"MOE_MAX_GROUPS", "max_groups"}};
         for (const auto& nv : names)
@@ -679,6 +683,18 @@ struct Fwd {
 
     // one convolution layer: in [B][H][W][64*nseg] -> out [B][H*r][W*r][r>1 ? 64 : 64*nchunks]
     // returns false only when asked for the fused tail (tplanes != nullptr) and the fused kernel cannot take the layer
+    // The two correction products on fp8 operands (conv64_q8.hip): 'mixed' only -- 'fp16x3' promises 2e-5, fp8 corrections deliver ~15 bits.
+    // auto: the SR nets, whose all-tile sweep keeps its margin with it (worst 8.1e-4 either way, profiles/r03/m_conv64_q8.txt); the DN nets
+    // (dn_lite5 7.2e-4 -> 8.6e-4 of the 1e-3 bar) stay on three fp16 products.
+    bool use_q8() const { return mixed && (n.opt.x3_impl == 2 || (n.opt.x3_impl == 0 && n.scale > 1)); }
+    // what conv() asks of a layer before it hands it to conv64_q8 (besides the tensors' own conditions)
+    bool q8_capable(const ConvLayer& L) const
+    {
+        return n.opt.x3_fuse && n.opt.conv_impl == 2 && L.k == 3 && L.r == 1 && L.nchunks == 1 && L.nseg == 1 && !L.per_plane && L.wq_hi8 && L.w_arsb_lo && !L.has_bias && L.slope <= 1.f &&
+               (long long)B * Hq * Wq * 128 + (Wq + 1ll) * 128 < (1ll << 32) - 65536;
+    }
+    int Hq = 0, Wq = 0;      // the trunk's resolution (set by forward before it plans the chain)
+
     bool conv(const std::string& key, const Act& in, const Act& out, const Act* res, int H, int W, const half_t* plane_w = nullptr,
               const half_t* plane_w_lo = nullptr, const half_t* tail_w = nullptr, float* tplanes = nullptr,
               const float* tail1_w = nullptr, float* tail1_out = nullptr, bool exact = false)
@@ -686,6 +702,8 @@ struct Fwd {
         if (dry()) return true;
         const bool x3 = this->x3 || exact;      // split operands for this layer (every layer under FP16X3, selected ones under MIXED)
         const ConvLayer& L = n.convs[n.conv_index.at(key)];
+        const bool any8 = in.lo8 || out.lo8 || (res && res->lo8);      // fp8 low parts: conv64_q8 or nothing (the caller planned the chain with q8_chain_ok)
+        if (any8 && !(x3 && use_q8() && q8_capable(L) && !direct)) return false;
         const int out_cs = L.r > 1 ? 64 : 64 * L.nchunks;
         if (direct) {
             DirectConvArgs d{};
@@ -813,12 +831,13 @@ struct Fwd {
                 // The two correction products on fp8 operands (conv64_q8.hip): 'mixed' only -- 'fp16x3' promises 2e-5, fp8 corrections deliver ~15 bits.
                 // auto: the SR nets, whose all-tile sweep keeps its margin with it (worst 8.1e-4 either way, profiles/r03/m_conv64_q8.txt); the DN nets
                 // (dn_lite5 7.2e-4 -> 8.6e-4 of the 1e-3 bar) stay on three fp16 products.
-                const bool use_q8 = n.opt.x3_impl == 2 || (n.opt.x3_impl == 0 && n.scale > 1);
-                if (use_q8 && mixed && L.wq_hi8 && !q.pool) {
+                if (use_q8() && L.wq_hi8 && !q.pool && (!res || res->lo8 == in.lo8)) {
                     ConvX3Args q8 = q;
                     q8.wq_hi16 = blob<half_t>(L.w_hi); q8.wq_hi8 = blob<unsigned char>(L.wq_hi8); q8.wq_lo8 = blob<unsigned char>(L.wq_lo8);
+                    q8.in8 = in.lo8; q8.out8 = out.lo8;
                     ok = launch_conv64_q8(q8, n.max_groups, s);
                 }
+                if (!ok && any8) { prof_end(rec); return false; }
                 if (!ok) ok = launch_conv64_x3(q, n.max_groups, s);
                 prof_end(rec);
                 if (ok) { pool_done = q.pool != nullptr; return true; }
@@ -976,6 +995,16 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
                 return fail(MOE_EINVAL, "layer %s: %d planes of %dx%d exceed the conv kernel's addressing range (use smaller tiles)", key.c_str(), B, h, w);
             return (int)MOE_OK;
         };
+        // The chain of split-operand layers (conv_input2, the first nx ARSBs) on conv64_q8 passes its low parts as the fp8 words its correction products read
+        // (Act::lo8): three quarters of the bytes of layers that are held by bytes (profiles/r03/o_stream_bytes.txt), no conversion of a_lo inside the kernel.
+        // The last conv_2 writes an fp16 low part again -- into the stem's low-part buffer, which conv_input2 was the only reader of (its own buffer still
+        // holds the fp8 residual it reads) -- for the fused ARSB kernels behind it.  Debug taps read fp16 low parts: no chain under set_debug.
+        f.Hq = h; f.Wq = w;
+        bool chain8 = mixed && f.use_q8() && n.opt.lo8 && n.arch != MOE_ARCH_NETDN && !n.debug && !f.direct && nx >= 1 && A.lo && Bb.lo && Cc.lo;
+        for (int i = 0; chain8 && i <= nx; ++i)
+            for (int j = (i == 0 ? 2 : 1); chain8 && j <= 2; ++j)
+                chain8 = f.q8_capable(n.convs[n.conv_index.at(i == 0 ? std::string("input2") : "c" + std::to_string(j) + "_" + std::to_string(i))]);
+        Bb.lo8 = chain8;
         if (int rc = trunk_conv("input2", A, Bb, nullptr, mixed)) return rc;
         f.tap("input2", Bb, h, w, 64, n.C);
         // single-pass ARSBs run as ONE kernel (arsb_fused.hip: conv_1's output never leaves the CU) that streams cur -> oth;
@@ -1019,10 +1048,13 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
             }
             Act m = oth;
             if (mixed && !ex) m.lo = nullptr;                    // single-pass ARSB: conv_1's output is an fp16 operand only
+            m.lo8 = ex && chain8;
             Act bin = cur;
             if (mixed && !ex) bin.lo = nullptr;
             if (int rc = trunk_conv(k1, bin, m, nullptr, ex)) return rc;
-            if (int rc = trunk_conv(k2, m, cur, &cur, ex)) return rc;
+            const Act resid = cur;
+            if (ex && chain8 && i == nx) { cur.lo = A.lo; cur.lo8 = false; }      // (see chain8)
+            if (int rc = trunk_conv(k2, m, cur, &resid, ex)) return rc;
             f.tap("arsb" + std::to_string(i), cur, h, w, 64, n.C);
         }
         Bb = cur;

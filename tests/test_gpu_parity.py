@@ -746,6 +746,33 @@ def test_exact_layers_with_fp8_corrections(key, dev):
         m.set_option('x3_impl', 'auto')
 
 
+@pytest.mark.parametrize('key,blocks', [('a2', -1), ('a4', -1), ('a3', -1), ('a2', 6), ('a4', 3)])
+def test_fp8_low_part_chain(key, blocks, dev):
+    """Option lo8 (default on): between the conv64_q8 layers of a net the low parts of the activations travel as the fp8 words the correction products
+    read (64 instead of 128 bytes a pixel; the last conv_2 of the chain writes fp16 low parts for the fused ARSB kernels).  The convolutions see the same
+    operands either way; the residual additions see ~15 instead of 22 bits of the stream: the outputs agree to a small fraction of the tolerance, both
+    hold the tolerance against the oracle, ragged shapes included, and a launch repeated gives the same bits."""
+    arch = gd.MODELS[key][0]
+    sd = gd.state_dict_for(key, load_state_dict_file)
+    m = module_for(key)
+    try:
+        m.set_exact_blocks(blocks)
+        for shape in ((3, 24, 40), (2, 40, 264), (3, 9, 35), (1, 88, 64), (2, 33, 31)):
+            for kind in ('natural', 'noise'):
+                x = (gd.natural_image(37, shape) if kind == 'natural' else gd.noise_image(37, shape))[:, None]
+                want = onets.forward(arch, sd, x).numpy()
+                xd = torch.from_numpy(x).to(dev)
+                y16 = m.set_option('x3_impl', 'q8').set_option('lo8', 'off')(xd)[-1].cpu().numpy()
+                y8 = m.set_option('lo8', 'on')(xd)[-1].cpu().numpy()
+                y8b = m(xd)[-1].cpu().numpy()
+                assert np.isfinite(y8).all(), (key, shape, kind)
+                assert np.array_equal(y8, y8b), (key, shape, kind)
+                assert np.abs(y8 - want).max() <= TOL, (key, shape, kind, float(np.abs(y8 - want).max()), float(np.abs(y16 - want).max()))
+                assert 0 < np.abs(y8 - y16).max() <= 6e-4, (key, shape, kind, float(np.abs(y8 - y16).max()), float(np.abs(y8 - want).max()), float(np.abs(y16 - want).max()))      # (pointwise, noise: 3e-4 .. 4.3e-4, as tests/emu_precision.py lo8 predicts; the error against the oracle moves by < 1e-4 either way, fullsize sweep)
+    finally:
+        m.set_option('x3_impl', 'auto').set_option('lo8', 'on').set_exact_blocks(-1)
+
+
 def test_fp8_corrections_default_by_family(dev):
     """x3_impl = auto: the SR nets run their exact layers through conv64_q8 (bit-equal to the explicit setting), the DN nets through conv64_x3."""
     for key, same_as in (('a2', 'q8'), ('dn_lite5', 'x3')):

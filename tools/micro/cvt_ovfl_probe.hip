@@ -18,6 +18,14 @@ __global__ void k(const unsigned* x, unsigned* y, float sc, int n, int ovfl)
     const float big = 1e6f * (float)(threadIdx.x + 1);
     y[64 + threadIdx.x] = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)big);
 }
+// the decode conv64_q8.hip uses for fp8 residual words: __builtin_amdgcn_cvt_pk_f32_fp8(word, sel) -> bytes 2 sel, 2 sel + 1 as OCP e4m3?
+typedef float f2 __attribute__((ext_vector_type(2)));
+__global__ void kd(const unsigned* x, float* y, int n)
+{
+    if ((int)threadIdx.x >= n) return;
+    const f2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)x[threadIdx.x], false), hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)x[threadIdx.x], true);
+    y[4 * threadIdx.x] = lo[0]; y[4 * threadIdx.x + 1] = lo[1]; y[4 * threadIdx.x + 2] = hi[0]; y[4 * threadIdx.x + 3] = hi[1];
+}
 static float e4m3(unsigned char v)
 {
     const int s = v >> 7, e = (v >> 3) & 15, m = v & 7;
@@ -36,6 +44,17 @@ int main()
         unsigned y[128]; hipMemcpy(y, dy, 128 * 4, hipMemcpyDeviceToHost);
         printf("scale operand 4, FP16_OVFL %d:\n", ovfl);
         for (int i = 0; i < n; ++i) printf("  (%g, %g) -> bytes %02x %02x = %g %g   (word %08x; fp16(1e6 (i+1)) behind it = %04x)\n", (float)hx[i][0], (float)hx[i][1], y[i] & 255, (y[i] >> 8) & 255, e4m3(y[i] & 255), e4m3((y[i] >> 8) & 255), y[i], y[64 + i]);
+    }
+    {
+        unsigned w[64]; srand(3);
+        for (int i = 0; i < 64; ++i) { w[i] = (unsigned)rand() ^ ((unsigned)rand() << 16); for (int b = 0; b < 4; ++b) if (((w[i] >> (8 * b)) & 0x7F) == 0x7F) w[i] ^= 1u << (8 * b); }
+        float* dz; hipMalloc(&dz, 256 * 4);
+        hipMemcpy(dx, w, sizeof w, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(kd, dim3(1), dim3(64), 0, 0, dx, dz, 64);
+        float z[256]; hipMemcpy(z, dz, sizeof z, hipMemcpyDeviceToHost);
+        int bad = 0;
+        for (int i = 0; i < 64; ++i) for (int b = 0; b < 4; ++b) bad += z[4 * i + b] != e4m3((w[i] >> (8 * b)) & 255);
+        printf("cvt_pk_f32_fp8(word, sel): byte 2 sel + {0, 1} as OCP e4m3 -- %d of 256 values differ\n", bad);
     }
     return 0;
 }
