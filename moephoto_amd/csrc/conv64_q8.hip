@@ -92,11 +92,10 @@ constexpr OpList short_ops(int s, bool res, bool in8)
         if (s == 3) r = dma_ops(0, 6, 9);
         if (s == 4) r = dma_ops(0, 9, 11);
     } else {                                   // the fp8 low part: six 1-KiB pieces per wave (16 pixels each)
-        if (s == 0) r = dma_ops(0, 0, 1);
-        if (s == 1) r = dma_ops(0, 1, 2);
-        if (s == 2) r = dma_ops(0, 2, 4);
-        if (s == 3) r = dma_ops(0, 4, 5);
-        if (s == 4) r = dma_ops(0, 5, 6);
+        if (s == 2) r = dma_ops(0, 0, 2);      // (not in steps 0, 1: the pass opens ~300 cycles behind the last store of the patch before, and a request
+        if (s == 3) r = dma_ops(0, 2, 4);      // issued behind stores in flight held the wave for ~1.4k cycles)
+        if (s == 4) r = dma_ops(0, 4, 5);
+        if (s == 5) r = dma_ops(0, 5, 6);
     }
     if (!res) return r;
     if (s == 3) { r.push(OP_RADD, 0, 0); r.push(OP_RADD, 0, 1); }
@@ -552,6 +551,8 @@ __global__ __launch_bounds__(256) void conv64_q8_kernel(ConvX3Args a)
         __builtin_amdgcn_s_barrier();                                    // nobody reads the fp8 image (a_lo) any more
         asm volatile("" ::: "memory");
         Q8_STAMP(11)
+#pragma unroll
+        for (int f = 0; f < 12; ++f) fr[f] = *(lds_h8_t)(xcur + fa_of(f));      // the long pass's first fp16 fragments: a_hi has been there since the head of the patch
         to_fp8_image(xcur);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         Q8_STAMP(12)
@@ -560,8 +561,6 @@ __global__ __launch_bounds__(256) void conv64_q8_kernel(ConvX3Args a)
         Q8_STAMP(13)
 
         // ================= LONG pass: a_hi rows 4h .. 4h+5: acc += w_hi a_hi (fp16) + w_lo8 a_hi8 (fp8); DMA of the next patch, then the rows' epilogues ============
-#pragma unroll
-        for (int f = 0; f < 12; ++f) fr[f] = *(lds_h8_t)(xcur + fa_of(f));
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) fr8[dx] = read_q8(dx, 0);
         Q8_STAMP(14)
@@ -577,26 +576,44 @@ __global__ __launch_bounds__(256) void conv64_q8_kernel(ConvX3Args a)
                     if (i >= 0 && i < 4)
                         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w16[(dy * 3 + dx) * 4 + ks], fr[(f + 13 - s) % 13], acc[i], 0, 0, 0);
                 }
-                if (ks == 3 && !(Q8_DBG & 1)) {       // the tap column's fp8 products (one MFMA covers all 64 input channels of a tap) behind its last fp16 k-slice
+                // the tap column's fp8 products (one MFMA covers all 64 input channels of a tap) behind its last fp16 k-slice.  Steps with ONE output row (0, 5)
+                // issue their three behind the step's last fp16 MFMA instead: every product of such a step goes to the same accumulator, and between an
+                // fp16 and an fp8 MFMA on one accumulator the result is not forwarded (8 + 2 resp. 16 + 2 passes of wait) -- one change of kind, not six
+                constexpr bool late8 = nm == 1;
+                if (!(Q8_DBG & 1) && (late8 ? f == 11 : ks == 3)) {
 #pragma unroll
-                    for (int dy = 0; dy < 3; ++dy) {
-                        const int i = s - dy;
-                        if (i >= 0 && i < 4)
-                            acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wl8[dy * 3 + dx], fr8[(dx + 4 - (s & 3)) & 3], acc[i], 0, 0, 0, scale_a, 0, scale_b);
-                    }
+                    for (int d8 = (late8 ? 0 : dx); d8 <= dx; ++d8)
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy) {
+                            const int i = s - dy;
+                            if (i >= 0 && i < 4)
+                                acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wl8[dy * 3 + d8], fr8[(d8 + 4 - (s & 3)) & 3], acc[i], 0, 0, 0, scale_a, 0, scale_b);
+                        }
                 }
                 if (s < 5) {
                     fr[(f + 12 - s) % 13] = *(lds_h8_t)(xcur + fa_of(f) + (unsigned)((s + 1) * ROWB));
-                    if (ks == 0) fr8[(dx + 3 - (s & 3)) & 3] = read_q8(dx, s + 1);      // (fragment dx of the next row into the set fragment dx - 1 of this row has left)
+                    if (!late8 && ks == 0) fr8[(dx + 3 - (s & 3)) & 3] = read_q8(dx, s + 1);      // (fragment dx of the next row into the set fragment dx - 1 of this row has left)
+                    if (late8 && f == 11) {
+#pragma unroll
+                        for (int d8 = 0; d8 < 3; ++d8) fr8[(d8 + 3 - (s & 3)) & 3] = read_q8(d8, s + 1);
+                    }
                 }
                 run_ops(std::integral_constant<int, 2>{}, S_, F_);
 #pragma unroll
                 for (int i_ = 0; i_ < 3; ++i_) {
                     if (i_ < nm) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (i_ == 0 && s < 5) __builtin_amdgcn_sched_group_barrier(0x100, ks == 0 ? 3 : 1, 0);
+                    if (i_ == 0 && s < 5) __builtin_amdgcn_sched_group_barrier(0x100, (ks == 0 && !late8) ? 3 : 1, 0);
                     if (i_ < nm) __builtin_amdgcn_sched_group_barrier(0x006, 5, 0);
                 }
-                if (ks == 3) {
+                if (late8 && f == 11) {
+#pragma unroll
+                    for (int i_ = 0; i_ < 3; ++i_) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (s < 5) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x006, 10, 0);
+                    }
+                }
+                if (!late8 && ks == 3) {
 #pragma unroll
                     for (int i_ = 0; i_ < 3; ++i_) {
                         if (i_ < nm) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
