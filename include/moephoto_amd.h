@@ -122,7 +122,9 @@ int moe_net_get_profile(moe_net* net, double* total_ms, int64_t* launches, doubl
 int moe_net_set_exact_blocks(moe_net* net, int blocks);
 /* Kernel-form switches of one net, for A/B measurements and the parity tests that compare forms of one layer in-process
  * ("sp_impl" = "auto" | "rw" | "sp", "arsb_fuse" / "x3_fuse" / "conv1x1" / "fuse_tail" / "sedn_fuse" / "pool_fuse" = "0" | "1",
- * "tail_split" = "0" | "r" | "ru", "tail_form" = "sums" | "planes", "conv_impl" = "sp" | "v1", "tiles_per_batch", "max_groups").
+ * "tail_split" = "0" | "r" | "ru", "tail_form" = "sums" | "planes", "conv_impl" = "sp" | "v1", "tiles_per_batch", "max_groups",
+ * "arsb_impl" = "v1" | "v2" | "v3", "k48" = "0" | "1", "x3_impl" = "auto" | "x3" | "q8" (the split-operand layers' kernel: three fp16 products, or the two
+ * corrections on fp8 operands; auto = q8 for the SR nets), "lo8" = "on" | "off" (fp8 low parts between conv64_q8 layers)).
  * Defaults come from the MOE_* environment variables of the same names ONCE, at moe_net_create; the forward path itself reads no
  * environment.  The reference has no such switches: its forward is torch.nn (python/imageProcess.py:391-395). */
 int moe_net_set_option(moe_net* net, const char* key, const char* value);
