@@ -223,7 +223,11 @@ __global__ __launch_bounds__(256) void conv64_q8_kernel(ConvX3Args a)
     const __amdgpu_buffer_rsrc_t rlo = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.in_lo - in_pad_lo), 0, Q8_LO_BYTES(nbytes_in_lo + in_pad_lo), 0x00020000);
     const __amdgpu_buffer_rsrc_t rrh = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? a.res_hi : a.in_hi), 0, nbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rrl = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? a.res_lo : a.in_hi), 0, Q8_LO_BYTES(nbytes_in_lo), 0x00020000);      // (the residual's format is the input's)
+#ifdef Q8_NOST        // (experiment: what the stores cost)
+    const __amdgpu_buffer_rsrc_t ryh = __builtin_amdgcn_make_buffer_rsrc((void*)a.out_hi, 0, 0u, 0x00020000);
+#else
     const __amdgpu_buffer_rsrc_t ryh = __builtin_amdgcn_make_buffer_rsrc((void*)a.out_hi, 0, nbytes, 0x00020000);
+#endif
     const __amdgpu_buffer_rsrc_t ryl = __builtin_amdgcn_make_buffer_rsrc((void*)a.out_lo, 0, Q8_LO_BYTES(nbytes_out_lo), 0x00020000);
     const int qlane = w4 * 8 + (lane >> 3);
     unsigned d_off = 0, d_r = 0, d_cc = 0;
@@ -553,7 +557,9 @@ __global__ __launch_bounds__(256) void conv64_q8_kernel(ConvX3Args a)
         Q8_STAMP(11)
 #pragma unroll
         for (int f = 0; f < 12; ++f) fr[f] = *(lds_h8_t)(xcur + fa_of(f));      // the long pass's first fp16 fragments: a_hi has been there since the head of the patch
+#ifndef Q8_NOCVT      // (experiment: what the a_hi conversion costs)
         to_fp8_image(xcur);
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         Q8_STAMP(12)
         __builtin_amdgcn_s_barrier();
