@@ -192,6 +192,7 @@ struct StemArgs {
     half_t* out;                     // [B][H][W][64]
     half_t* out_lo;                  // FP16X3 low part or nullptr
     int B, H, W, taps;
+    int out_lo8;                     // the low part as fp8 e4m3 words of lo / 4, one byte a channel (what conv64_q8 with in8 reads: ConvX3Args)
 };
 void launch_stem(const StemArgs& a, hipStream_t s);
 

@@ -664,6 +664,7 @@ hipError_t conv64_q8_init()
     hipError_t e;
     if ((e = set_limit<0, false, false>()) != hipSuccess) return e;
     if ((e = set_limit<0, false, true>()) != hipSuccess) return e;
+    if ((e = set_limit<0, true, true>()) != hipSuccess) return e;
     if ((e = set_limit<1, false, false>()) != hipSuccess) return e;
     if ((e = set_limit<1, true, true>()) != hipSuccess) return e;
     if ((e = set_limit<2, false, false>()) != hipSuccess) return e;
@@ -703,12 +704,13 @@ bool launch_conv64_q8(ConvX3Args a, int max_groups, hipStream_t s)
     const int G = (int)std::min<long long>(items, max_groups);
     const dim3 grid(G), blk(256);
     // formats of the low parts (in8: input and residual, out8: output) -- the combinations a chain of these layers needs (engine.cpp, forward):
-    //   conv_input2 fp16 -> fp8 | conv_1 fp8 -> fp8 | conv_2 fp8 -> fp8, and fp8 -> fp16 for the last one (the fused ARSB kernels read fp16 low parts)
+    //   conv_input2 fp8 (the stem writes it) or fp16 -> fp8 | conv_1 fp8 -> fp8 | conv_2 fp8 -> fp8, and fp8 -> fp16 for the last one (the fused ARSB kernels read fp16 low parts)
     const int epi = a.res_hi ? 2 : a.slope != 1.f ? 1 : 0, fmt = epi * 4 + (a.in8 ? 2 : 0) + (a.out8 ? 1 : 0);
     const size_t lds = LDS_BYTES + TRACE_LDS;
     switch (fmt) {
     case 0: conv64_q8_kernel<0, false, false><<<grid, blk, lds, s>>>(a); break;
     case 1: conv64_q8_kernel<0, false, true><<<grid, blk, lds, s>>>(a); break;
+    case 3: conv64_q8_kernel<0, true, true><<<grid, blk, lds, s>>>(a); break;
     case 4: conv64_q8_kernel<1, false, false><<<grid, blk, lds, s>>>(a); break;
     case 7: conv64_q8_kernel<1, true, true><<<grid, blk, lds, s>>>(a); break;
     case 8: conv64_q8_kernel<2, false, false><<<grid, blk, lds, s>>>(a); break;

@@ -962,7 +962,7 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         StemArgs a{};
         a.x = x; a.x_dtype = x_dtype; a.x_off = x_off_dev; a.sB = sB; a.sH = sH; a.sW = sW;
         a.w = f.small<float>("stem"); a.slope = n.scalars.at("stem_slope");
-        a.out = out.hi; a.out_lo = out.lo; a.B = B; a.H = h; a.W = w; a.taps = (int)n.scalars.at("stem_taps");
+        a.out = out.hi; a.out_lo = out.lo; a.out_lo8 = out.lo8; a.B = B; a.H = h; a.W = w; a.taps = (int)n.scalars.at("stem_taps");
         launch_stem(a, s);
     };
     auto tail = [&](const Act* r, const Act* u, int H, int W, bool skip) {
@@ -986,8 +986,6 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         const bool mixed = f.mixed;
         const int nx = mixed ? exact_blocks_of(n) : 0;
         Act A = f.act(P, 64, mixed), Bb = f.act(P, 64, mixed), Cc = f.act(P, 64, mixed);
-        stem(A);
-        f.tap("stem", A, h, w, 64, n.C);
         if (mixed && n.opt.conv_impl != 2)
             return fail(MOE_EINVAL, "precision 'mixed' runs on the fast 3x3 kernels only: conv_impl=v1 (MOE_CONV_IMPL=v1) is a debugging switch for 'fp16' / 'fp16x3'");
         auto trunk_conv = [&](const std::string& key, const Act& in, const Act& out, const Act* res, bool exact) {
@@ -998,13 +996,16 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         // The chain of split-operand layers (conv_input2, the first nx ARSBs) on conv64_q8 passes its low parts as the fp8 words its correction products read
         // (Act::lo8): three quarters of the bytes of layers that are held by bytes (profiles/r03/o_stream_bytes.txt), no conversion of a_lo inside the kernel.
         // The last conv_2 writes an fp16 low part again -- into the stem's low-part buffer, which conv_input2 was the only reader of (its own buffer still
-        // holds the fp8 residual it reads) -- for the fused ARSB kernels behind it.  Debug taps read fp16 low parts: no chain under set_debug.
+        // holds the fp8 residual it reads) -- for the fused ARSB kernels behind it.  The stem writes its low part in that form too (conv_input2 is its only
+        // reader: the U branch takes the fp16 part).  Debug taps read fp16 low parts: no chain under set_debug.
         f.Hq = h; f.Wq = w;
         bool chain8 = mixed && f.use_q8() && n.opt.lo8 && n.arch != MOE_ARCH_NETDN && !n.debug && !f.direct && nx >= 1 && A.lo && Bb.lo && Cc.lo;
         for (int i = 0; chain8 && i <= nx; ++i)
             for (int j = (i == 0 ? 2 : 1); chain8 && j <= 2; ++j)
                 chain8 = f.q8_capable(n.convs[n.conv_index.at(i == 0 ? std::string("input2") : "c" + std::to_string(j) + "_" + std::to_string(i))]);
-        Bb.lo8 = chain8;
+        A.lo8 = Bb.lo8 = chain8;
+        stem(A);
+        f.tap("stem", A, h, w, 64, n.C);
         if (int rc = trunk_conv("input2", A, Bb, nullptr, mixed)) return rc;
         f.tap("input2", Bb, h, w, 64, n.C);
         // single-pass ARSBs run as ONE kernel (arsb_fused.hip: conv_1's output never leaves the CU) that streams cur -> oth;
@@ -1059,7 +1060,7 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         }
         Bb = cur;
         if (n.arch == MOE_ARCH_NETDN) { tail(&Bb, &A, h, w, false); return MOE_OK; }
-        if (mixed) { A.lo = nullptr; Bb.lo = nullptr; }          // the upsampler convs take the fp16 parts
+        if (mixed) { A.lo = nullptr; Bb.lo = nullptr; A.lo8 = Bb.lo8 = false; }      // the upsampler convs take the fp16 parts
         // two upsampler branches: R on the trunk output, U on the stem output (models.py:117-123)
         Act fin[2];
         float* tp[2] = {nullptr, nullptr};

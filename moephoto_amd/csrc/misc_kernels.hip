@@ -26,6 +26,8 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
     __shared__ float w[TAPS * 64];
     for (int i = threadIdx.x; i < TAPS * 64; i += 256) w[i] = a.w[i];
     __syncthreads();
+    // fp8 low parts: MODE.FP16_OVFL makes the conversion saturate (+-448) instead of producing NaN (conv64_q8.hip runs the same way)
+    if (a.out_lo8) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1\n\ts_nop 3" ::: "memory");
     constexpr int PX = 4;
     const int nq = (a.W + PX - 1) / PX;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -76,7 +78,22 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
             half8_t l;
 #pragma unroll
             for (int e = 0; e < 8; ++e) l[e] = (half_t)((prelu(acc[e], a.slope) - (float)o[e]) * 2048.f);
-            *(half8_t*)(a.out_lo + p * 64 + cg) = l;
+            if (!a.out_lo8) *(half8_t*)(a.out_lo + p * 64 + cg) = l;
+            else {
+                // the eight values / 4 as e4m3: the word conv64_q8's own conversion would make of them (its cvt4: one asm block, the two words' conversions
+                // alternating, a wait state behind the half-register writes)
+                typedef unsigned u4v __attribute__((ext_vector_type(4)));
+                const u4v lw = __builtin_bit_cast(u4v, l);
+                unsigned p0, p1;
+                const float quarter = 4.0f;
+                asm volatile("v_cvt_scalef32_pk_fp8_f16 %0, %2, %6\n\t"
+                             "v_cvt_scalef32_pk_fp8_f16 %1, %4, %6\n\t"
+                             "v_cvt_scalef32_pk_fp8_f16 %0, %3, %6 op_sel:[0,0,1]\n\t"
+                             "v_cvt_scalef32_pk_fp8_f16 %1, %5, %6 op_sel:[0,0,1]\n\t"
+                             "s_nop 0"
+                             : "=&v"(p0), "=&v"(p1) : "v"(lw[0]), "v"(lw[1]), "v"(lw[2]), "v"(lw[3]), "v"(quarter));
+                *(uint2*)((unsigned char*)a.out_lo + p * 64 + cg) = make_uint2(p0, p1);
+            }
         }
     }
 }
