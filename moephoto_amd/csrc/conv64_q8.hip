@@ -8,22 +8,28 @@
 // fp16 form on every model and input class, profiles/r03/j_fp8_corrections_emulation.txt).  v_mfma_scale_f32_32x32x64_f8f6f4 runs at twice the fp16 rate and
 // its E8M0 scales fold the 2^-11 (and the operands' own power-of-two scalings) in, so ALL THREE products accumulate in one accumulator set and an exact
 // layer costs 1 + 1/2 + 1/2 = 2 product-times instead of conv64_x3.hip's 3.  Operand layout of the scaled MFMA and the conversion's semantics:
-// tools/micro/mfma_scale_probe.hip, cvt_scale_probe.hip (32 consecutive k per lane; uniform scales in byte 0; no saturation: NaN beyond 464 after scaling).
+// tools/micro/mfma_scale_probe.hip, cvt_scale_probe.hip, cvt_ovfl_probe.hip (32 consecutive k per lane; uniform scales in byte 0; the conversion divides by
+// its scale operand and gives NaN beyond 464 unless MODE.FP16_OVFL is set -- the kernel runs with it: saturation at +-448).
 //
-// Drop-in for conv64_x3.hip (same tensors in and out): the fp8 images are made INSIDE the workgroup from the fp16 patches it has fetched.
+// Drop-in for conv64_x3.hip (same tensors in and out) -- and, between two layers of this kernel, a cheaper interface: the low part of an activation tensor as
+// the fp8 word the correction product reads anyway (ConvX3Args::in8 / out8, template parameters IN8 / OUT8; engine.cpp plans the chain: Act::lo8).  These
+// layers are held by their bytes (profiles/r03/o_stream_bytes.txt): 384 / 576 instead of 512 / 768 bytes a pixel, and the a_lo image arrives by DMA.
 //
 //   wave (c, h)   output channels 32c .. 32c+31, output rows 4h .. 4h+3 of the 8 x 32 patch (arsb32.hip's conv_2 half)
 //   weights       36 fp16 A fragments of w_hi (144 registers) + 9 + 9 fp8 A fragments (one per tap: 32 rows x 64 k) of w_lo 2^8 and w_hi 2^8 (144): 256 in
 //                 AGPRs, the last four fp8 fragments in arch VGPRs
-//   LDS           a_hi patch 10 x 34 x 128 B double buffered; a_lo patch single buffered (only live between its landing and its conversion); ONE fp8 image
-//                 10 x 34 x 64 B that holds a_hi / 4 during pass 1 and a_lo / 4 during pass 2: 3 x 45,056 + 22,528 = 157,696 B
-//   patch p       barrier | a_lo -> fp8 image | barrier | SHORT pass: rows of the image (w_hi8 x a_lo8: 36 fp8 MFMAs per wave; EPI 2: the residual words of
-//                 output rows 0, 1 are requested) | barrier | a_hi -> fp8 image | barrier | LONG pass: rows of a_hi (144 fp16 MFMAs) and of the image
-//                 (w_lo8 x a_hi8: 36 fp8 MFMAs); row steps 0..2 carry the DMA of a_lo[p+1] and a_hi[p+1] (+ EPI 2: residual adds and the words of rows
-//                 2, 3), row steps 3..5 the epilogues and stores of output rows 0..2 (a row is complete two steps after its first one), row 3 behind
-//                 the pass.  The first form ran the long pass first and finished the rows in the short one: 2.3k cycles of MFMA cannot hide 700
-//                 instructions of epilogue (cycle trace: 4.3k for that pass, 23k per patch; profiles/r03/m_conv64_q8.txt).
-//   loads and stores in separate stretches (arsb32c.hip): DMA and residual loads by the end of row step 2, stores from row step 3 on; the wait that
+//   LDS           a_hi patch 10 x 34 x 128 B double buffered; a_lo: the fp16 patch single buffered (only live between its landing and its conversion) or
+//                 -- IN8 -- two fp8 images (patches p & 1) in the same 45 KB, filled by DMA; ONE fp8 image 10 x 34 x 64 B that the conversions write
+//                 (a_lo / 4 for the short pass unless IN8, then a_hi / 4 for the long pass); 1 KB that takes the two DMA pieces an fp8 image does not
+//                 have: 3 x 45,056 + 22,528 + 1,024 = 158,720 B
+//   patch p       counted wait + barrier | EPI 2: the residual words of all four rows are requested | [a_lo -> fp8 image | barrier] | SHORT pass: rows of
+//                 the a_lo image (w_hi8 x a_lo8: 36 fp8 MFMAs per wave), the DMA of a_lo[p+1], EPI 2: the residual added to a row once its products of
+//                 this pass are in | barrier | first fp16 fragments, a_hi -> fp8 image | barrier | LONG pass: rows of a_hi (144 fp16 MFMAs) and of its
+//                 image (w_lo8 x a_hi8: 36 fp8 MFMAs); row steps 0..2 carry the DMA of a_hi[p+1], row steps 3..5 the epilogues and stores of output rows
+//                 0..2 (a row is complete two steps after its first one), row 3 behind the pass.  The first form ran the long pass first and finished the
+//                 rows in the short one: 2.3k cycles of MFMA cannot hide 700 instructions of epilogue (cycle trace: 4.3k for that pass, 23k per patch;
+//                 profiles/r03/m_conv64_q8.txt, which also has the ablations -- what a patch spends where -- and the forms that were tried and dropped).
+//   loads and stores in separate stretches (arsb32c.hip): DMA and residual loads before row step 3 of the long pass, stores from there on; the wait that
 //   opens a patch counts (all but the sixteen stores behind the last DMA piece).
 #include "common.h"
 #include "rowtile.h"
