@@ -67,6 +67,17 @@ GROUPS = [
 ]
 
 
+# The split-operand layers (conv_input2, ARSB 1 of Net4x: conv64_q8.hip) are held by their bytes, not by the matrix pipe: their roofline object is
+# an HBM one.  Algorithmic bytes per LR pixel and plane, hi + low part in and out (+ the residual): with the fp8 low parts of a conv64_q8 chain 192 in + 192 out |
+# 192 + 192 | 192 + 192 (residual) + 256 (fp16 low part again for the fused ARSB kernels); with fp16 low parts 512 | 512 | 768
+HBM_KEYS = ['input2', 'c1_', 'c2_']
+
+
+def _exact_bytes_px():
+    chain = os.environ.get('MOE_X3_IMPL', 'auto') in ('auto', 'q8') and os.environ.get('MOE_LO8', 'on') not in ('0', 'off')
+    return (384 + 384 + 640) if chain else (512 + 512 + 768)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -183,7 +194,7 @@ def main():
     in_mp = nframes * FRAME[1] * FRAME[2] / 1e6
     for _ in range(args.warmup):
         step(frames)
-    model.set_profile(','.join(g[0] for g in GROUPS))      # hipEvent pairs on the launch stream around the launches of each group
+    model.set_profile(','.join([g[0] for g in GROUPS] + HBM_KEYS))      # hipEvent pairs on the launch stream around the launches of each group
     dt = timed(frames, args.steps)
     profs = model.get_profile(all_keys=True)
     model.set_profile(None)
@@ -238,6 +249,23 @@ def main():
         trunk = [k for k in kernels if k['layer_key'] == 'arsb']
         if trunk:
             res['roofline_trunk'] = trunk[0]
+    hb = profs[len(GROUPS):len(GROUPS) + len(HBM_KEYS)]
+    if len(hb) == len(HBM_KEYS) and all(p['launches'] > 0 and p['total_ms'] > 0 for p in hb):
+        secs = sum(p['total_ms'] for p in hb) / 1e3
+        launches = sum(p['launches'] for p in hb)
+        alg = 3.0 * FRAME[1] * FRAME[2] * _exact_bytes_px() * frames_timed                # algorithmic bytes of the three layers in the timed steps
+        peak_gbs = 8000.0                                                                   # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+        k = {'bound': 'hbm', 'kernel': 'conv64_q8_kernel (conv_input2 + the two convs of ARSB 1 with split operands: fp16 product + two fp8 correction products, fp8 low parts '
+                                       'between the layers) -- or conv64_x3_kernel under MOE_X3_IMPL=x3', 'layer_key': 'exact',
+             'achieved': round(alg / secs / 1e9, 1), 'peak': peak_gbs, 'unit': 'GB/s', 'frac': round(alg / secs / 1e9 / peak_gbs, 4),
+             'bytes_per_pixel_algorithmic': _exact_bytes_px(), 'launches': launches, 'avg_launch_ms': round(secs * 1e3 / launches, 4),
+             'ms_per_frame': round(secs * 1e3 / frames_timed, 3), 'share_of_step': round(secs * 1e3 / frames_timed / ms_per_step, 4)}
+        t = pmc.get('exact')
+        k['traffic'] = int(t['hbm_bytes_per_frame'] / max(1, t['launches_per_frame'])) if t else None
+        if t:
+            k['traffic_note'] = t.get('note', '')
+            k['achieved_measured_bytes'] = round(t['hbm_bytes_per_frame'] * frames_timed / secs / 1e9, 1)      # the PMC passes' bytes over this run's time
+        res['roofline_hbm'] = k
 
     # ---- sustained leg (power-capped part: a 0.5 s burst flatters the clock), with the clock / power sampled beside it ------------
     if args.sustain > 0:
