@@ -48,3 +48,35 @@ def test_emulation_equals_oracle_in_fp32():
             a = emu.forward(arch, sd, x)
         b = onets.forward(arch, sd, x)
         assert float((a - b).abs().max()) <= 2e-6
+
+
+@pytest.mark.parametrize('key', ['a2', 'a4', 'dn_lite5'])
+def test_fp8_corrections_and_fp8_low_part_budget(key):
+    """conv64_q8.hip's arithmetic on the CPU: the split-operand layers' two correction products on OCP e4m3 operands (`corr8`), and the trunk stream's low
+    part stored as the e4m3 word of (t - fp16(t)) 2^9 (`lo8`: ~15 instead of 22 bits of the stream).  Both stay inside the budget of the all-fp16 form;
+    an fp16-only stream (11 bits) does not on NetDN -- which is why the low part exists at all."""
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    arch = gd.MODELS[key][0]
+    sd = gd.state_dict_for(key, load_state_dict_file)
+    n = emu.DEFAULT_EXACT[arch]
+    ex = ['input2'] + ['c%d_%d' % (j, i) for i in range(1, n + 1) for j in (1, 2)]
+    x = gd.noise_image(5, (3, 1, 64, 64))
+    w16, a16, s16 = emu.mode_sets(arch, 'mixed', n)
+    with torch.no_grad():
+        want = emu.forward(arch, sd, x)
+        e_x3 = float((emu.forward(arch, sd, x, w16, a16, s16) - want).abs().max())
+        e_q8 = float((emu.forward(arch, sd, x, w16, a16, s16, corr8=ex) - want).abs().max())
+        e_lo8 = float((emu.forward(arch, sd, x, w16, a16, s16, corr8=ex, lo8=True) - want).abs().max())
+        e_s16 = float((emu.forward(arch, sd, x, w16, a16, True, corr8=ex) - want).abs().max())
+    assert e_q8 <= 8.5e-4 and e_lo8 <= 8.5e-4, (key, e_x3, e_q8, e_lo8)
+    assert abs(e_q8 - e_x3) <= 1.5e-4 and abs(e_lo8 - e_q8) <= 1.5e-4, (key, e_x3, e_q8, e_lo8)
+    if key == 'dn_lite5':
+        assert e_s16 > 1e-3, (key, e_s16)
+
+
+def test_e4m3_rounding_of_the_emulation():
+    """emu.q8 = OCP e4m3 with round-to-nearest-even and saturation at 448 (what to_e4m3 in engine.cpp and v_cvt_scalef32_pk_fp8_f16 under MODE.FP16_OVFL do)."""
+    v = torch.tensor([0.0, 1.0, 1.0625, 1.1875, 17.0, 18.0, 19.0, 447.0, 448.0, 464.0, 1000.0, 2.0 ** -9, 2.0 ** -10, 3.0 * 2.0 ** -11, -0.3])
+    got = emu.q8(v, 0)
+    want = torch.tensor([0.0, 1.0, 1.0, 1.25, 16.0, 18.0, 20.0, 448.0, 448.0, 448.0, 448.0, 2.0 ** -9, 0.0, 2.0 ** -9, -0.3125])
+    assert torch.equal(got, want), (got, want)
