@@ -34,6 +34,28 @@ def q8(x, shift):
     return v.to(torch.float8_e4m3fn).float() * float(2.0 ** -shift)
 
 
+def q6_block(x, dim, fmt='e2m3'):
+    """x in an MX-style block format: blocks of 32 along `dim` share a power-of-two scale (chosen so that the block's largest magnitude fits the element format),
+    elements are OCP fp6 e2m3 (1, 1.125 .. 7.5; subnormals in steps of 0.125) or e3m2 (0.25 .. 28; subnormals in steps of 0.0625), round to nearest even.
+    What v_mfma_scale_f32_32x32x64_f8f6f4 would read with fp6 operands and per-block scales (4x the fp16 rate instead of fp8's 2x)."""
+    mb, emax, emin = {'e2m3': (3, 2, 0), 'e3m2': (2, 4, -2), 'e2m1': (1, 2, 0)}[fmt]      # (e2m1 = OCP fp4: 0.5, 1, 1.5, 2, 3, 4, 6)
+    top = (2.0 - 2.0 ** -mb) * 2.0 ** emax
+    xs = x.movedim(dim, -1)
+    n0 = xs.shape[-1]
+    if n0 % 32:                                                      # (48-channel nets: the engine pads to 64 with zeros)
+        xs = F.pad(xs, (0, 32 - n0 % 32))
+    shp = xs.shape
+    b = xs.reshape(shp[:-1] + (shp[-1] // 32, 32))
+    amax = b.abs().amax(dim=-1, keepdim=True).clamp_min(1e-30)
+    sc = torch.exp2(torch.ceil(torch.log2(amax / top)))              # smallest power of two with amax / sc <= top
+    v = b / sc
+    e = torch.floor(torch.log2(v.abs().clamp_min(2.0 ** emin))).clamp(emin, emax)
+    step = torch.exp2(e - mb)
+    q = torch.round(v / step) * step                                 # (torch.round: half to even)
+    q = q.clamp(-top, top)
+    return (q * sc).reshape(shp)[..., :n0].movedim(-1, dim)
+
+
 def prelu(x, a):
     return torch.where(x >= 0, x, x * a)
 
@@ -55,7 +77,7 @@ def layer_names(arch):
     return out
 
 
-def forward(arch, sd, x, w16=(), a16=(), stream16=False, corr8=(), shifts=(8, 4), lo8=False):
+def forward(arch, sd, x, w16=(), a16=(), stream16=False, corr8=(), shifts=(8, 4), lo8=False, corr6=None):
     """w16 / a16: names of the convs whose weights / input activations are rounded to fp16 ('all' = every conv);
     stream16: the trunk stream is stored as fp16 after conv_input2 and after every ARSB.
     corr8: convs computed as  conv(w16, a16) + conv(fp8(w - w16), fp8(a16)) + conv(fp8(w16), fp8(a - a16))  -- the split-operand form with its two
@@ -67,6 +89,10 @@ def forward(arch, sd, x, w16=(), a16=(), stream16=False, corr8=(), shifts=(8, 4)
     r = 3 if arch == 'net3x' else 2
 
     def conv(name, v, w, b=None):
+        if name in corr8 and corr6:      # the two correction products on block-scaled fp6 operands (blocks of 32 input channels)
+            wh, vh = r16(w), r16(v)
+            return (F.conv2d(vh, wh, b, padding=1) + F.conv2d(q6_block(vh, 1, corr6), q6_block(w - wh, 1, corr6), None, padding=1)
+                    + F.conv2d(q6_block(v - vh, 1, corr6), q6_block(wh, 1, corr6), None, padding=1))
         if name in corr8:
             wh, vh = r16(w), r16(v)
             sw, sa = shifts
@@ -218,6 +244,22 @@ def main(argv):
     cmd = argv[1] if len(argv) > 1 else 'budget'
     if cmd == 'lite':
         lite_budget(tuple(argv[2:]) or ('lite2', 'lite4', 'lite8'))
+        return
+    if cmd == 'corr6':      # the correction products on block-scaled fp6 instead of fp8 (4x instead of 2x the fp16 MFMA rate): does the budget hold?
+        for key in (argv[2:] or ['a2', 'a3', 'a4', 'dn_lite5']):
+            arch, sd = gd.MODELS[key][0], _load(key)
+            n = DEFAULT_EXACT[arch]
+            ex = ['input2'] + ['c%d_%d' % (j, i) for i in range(1, n + 1) for j in (1, 2)]
+            for kind, shape, seed in (('noise', (3, 96, 96), 5), ('noise-u8', (3, 256, 256), 0), ('noise-u8', (3, 256, 256), 1), ('natural', (3, 40, 264), 5)):
+                x = gd.natural_image(seed, shape) if kind == 'natural' else gd.noise_image(seed, shape) if kind == 'noise' else gd.noise_u8(seed, shape).astype(np.float32) / 255.0
+                x = x[:, None]
+                with torch.no_grad():
+                    want = forward(arch, sd, x)
+                    w16, a16, s16 = mode_sets(arch, 'mixed', n)
+                    e8 = float((forward(arch, sd, x, w16, a16, s16, corr8=ex, lo8=True) - want).abs().max())
+                    e6 = [float((forward(arch, sd, x, w16, a16, s16, corr8=ex, lo8=True, corr6=f) - want).abs().max()) for f in ('e2m3', 'e3m2', 'e2m1')]
+                    e0 = float((forward(arch, sd, x, w16 | set(ex), a16 | set(ex), s16, lo8=True) - want).abs().max())
+                print('%-9s %-8s n=%d: fp8 corrections %.3e | fp6 e2m3 blocks %.3e | fp6 e3m2 blocks %.3e | fp4 e2m1 blocks %.3e | no corrections %.3e' % (key, kind, n, e8, e6[0], e6[1], e6[2], e0), flush=True)
         return
     if cmd == 'lo8':        # the trunk stream's low part stored as fp8: error against fp32 beside the present form (both with fp8 corrections on the exact layers)
         for key in (argv[2:] or ['a2', 'a3', 'a4', 'dn_lite5']):
