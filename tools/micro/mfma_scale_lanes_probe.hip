@@ -22,6 +22,24 @@ __global__ void k(const unsigned* A, const unsigned* B, const int* sa, const int
     for (int r = 0; r < 16; ++r) D[l * 16 + r] = c[r];
 }
 
+// v_cvt_scalef32_pk_fp4_f16: two fp16 -> two e2m1 nibbles (one byte), source divided by the scale operand?  op_sel picks the destination byte?
+__global__ void kc(const unsigned* x, unsigned* y, float sc, int n)
+{
+    if ((int)threadIdx.x >= n) return;
+    const unsigned a = x[threadIdx.x], b = x[(threadIdx.x + 1) % n];
+    unsigned p = 0xAAAAAAAAu, q = 0xAAAAAAAAu;
+    asm volatile("v_cvt_scalef32_pk_fp4_f16 %0, %1, %2\n\ts_nop 1" : "+v"(p) : "v"(a), "v"(sc));
+    asm volatile("v_cvt_scalef32_pk_fp4_f16 %0, %1, %2 op_sel:[0,0,1,0]\n\ts_nop 1" : "+v"(q) : "v"(b), "v"(sc));
+    y[2 * threadIdx.x] = p; y[2 * threadIdx.x + 1] = q;
+}
+
+static float e2m1(unsigned v)      // OCP fp4: s ee m, bias 1: 0, 0.5, 1, 1.5, 2, 3, 4, 6
+{
+    const int s = (v >> 3) & 1, e = (v >> 1) & 3, m = v & 1;
+    const float f = e == 0 ? m * 0.5f : std::ldexp(1.0f + m * 0.5f, e - 1);
+    return s ? -f : f;
+}
+
 static float e2m3(unsigned v)      // OCP fp6 e2m3: s eeMMM, bias 1
 {
     const int s = (v >> 5) & 1, e = (v >> 3) & 3, m = v & 7;
@@ -87,6 +105,43 @@ int main()
             if (kq < 8 || D[0] != want) printf("  k %2d: D[0][0] = %g (hypothesis %g)%s\n", kq, D[0], want, D[0] == want ? "" : "   <-- differs");
         }
         printf("  %d of 64 k agree with the hypothesis\n", good);
+    }
+    // ---- (3) fp4 e2m1 A operand (cbsz 4): 32 values in 16 bytes (4 VGPRs), nibble t at bits [4t, 4t+4)? ----
+    {
+        std::vector<unsigned> A(64 * 8, 0);
+        for (int l = 0; l < 64; ++l) {
+            unsigned char bytes[32] = {};
+            for (int t = 0; t < 32; ++t) bytes[t >> 1] |= (unsigned char)((1 + (t % 7)) << (4 * (t & 1)));
+            memcpy(&A[l * 8], bytes, 32);
+        }
+        (void)hipMemcpy(dA, A.data(), 64 * 8 * 4, hipMemcpyHostToDevice);
+        printf("fp4 e2m1 A operand (cbsz 4), B = fp8 unit vector e_k: D[0][0] per k; code of slot t = 1 + t %% 7 -> value e2m1(code):\n  ");
+        for (int kq = 0; kq < 64; ++kq) {
+            std::vector<unsigned> B(64 * 8, 0);
+            for (int j = 0; j < 32; ++j) { const int l = j + 32 * (kq >> 5); ((unsigned char*)&B[l * 8])[kq & 31] = 0x38; }
+            (void)hipMemcpy(dB, B.data(), 64 * 8 * 4, hipMemcpyHostToDevice);
+            hipLaunchKernelGGL(k<4>, dim3(1), dim3(64), 0, 0, dA, dB, dsa, dsb, dD);
+            (void)hipMemcpy(D, dD, sizeof D, hipMemcpyDeviceToHost);
+            printf("%g%s", D[0], (kq & 15) == 15 ? "\n  " : " ");
+        }
+        printf("(slot values in stream order: ");
+        for (int t = 0; t < 16; ++t) printf("%g ", e2m1(1 + (t % 7)));
+        printf("...)\n");
+    }
+    // ---- (4) the fp4 conversion ----
+    {
+        const float xs[] = {0.f, 0.2f, 0.25f, 0.3f, 0.5f, 0.75f, 1.f, 1.25f, 1.5f, 1.75f, 2.f, 2.5f, 3.f, 3.5f, 4.f, 5.f, 6.f, 7.f, 100.f, -1.25f};
+        const int n = sizeof xs / sizeof xs[0];
+        unsigned hx[32];
+        for (int i = 0; i < n; ++i) { const _Float16 h0 = (_Float16)xs[i], h1 = (_Float16)(-xs[i]); unsigned short u0, u1; memcpy(&u0, &h0, 2); memcpy(&u1, &h1, 2); hx[i] = u0 | ((unsigned)u1 << 16); }
+        unsigned* dy; (void)hipMalloc(&dy, 64 * 4);
+        (void)hipMemcpy(dA, hx, n * 4, hipMemcpyHostToDevice);
+        for (float sc : {1.0f, 4.0f}) {
+            hipLaunchKernelGGL(kc, dim3(1), dim3(64), 0, 0, dA, dy, sc, n);
+            unsigned y[64]; (void)hipMemcpy(y, dy, 2 * n * 4, hipMemcpyDeviceToHost);
+            printf("v_cvt_scalef32_pk_fp4_f16, scale operand %g (destination preset 0xAAAAAAAA; second column: op_sel:[0,0,1,0] on the NEXT input):\n", sc);
+            for (int i = 0; i < n; ++i) printf("  (%g, %g) -> %08x = (%g, %g)      | %08x\n", xs[i], -xs[i], y[2 * i], e2m1(y[2 * i] & 15), e2m1((y[2 * i] >> 4) & 15), y[2 * i + 1]);
+        }
     }
     return 0;
 }
