@@ -140,6 +140,9 @@ struct Item { int b, pyi, pxi; };
 
 // cycle-level trace (tools/mk_variant.sh traceq8 conv64_q8.hip -DQ8_TRACE; tools/show_trace_q8.py): s_memtime stamps of patches 4 and 7 of the first eight
 // workgroups, buffered in LDS and written to a.pool (repurposed: 8 x 2 x 4 x 32 x 8 bytes) when the workgroup is done
+#if defined(Q8_TRACE) && !defined(Q8_STEPWAIT)
+#define Q8_STEPWAIT      // the stamps are inline-asm LDS stores inside the passes: the compiler's counted lgkmcnt waits would be one short
+#endif
 #ifdef Q8_TRACE
 constexpr int TRACE_LDS = 2 * 4 * 32 * 8 + 4 * 32 * 8;
 #define Q8_STAMP(SLOT) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); const unsigned tb_ = tbase; asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(tb_), "v"(t_), "n"((SLOT) * 8) : "memory"); }      // (unconditional, to a dummy slot when off: a branch per stamp splits the pinned regions and spills; an LDS store: a flat one would drain vmcnt)
