@@ -112,6 +112,33 @@ hipError_t conv3x3_sp_init();
 bool launch_conv3x3_rw(const ConvArgs& a, hipStream_t s);   // false: not applicable, use conv3x3_sp
 hipError_t conv3x3_rw_init();
 
+// The last upsampler stage (3x3, 64 -> 256, + bias, PixelShuffle(2), PReLU) with the 64 -> 1 tail conv, all four phases in one workgroup (conv3x3_ps4.hip)
+struct Ps4Args {
+    const half_t* in;        // [B][H][W][64]
+    const half_t* wpk;       // pack_conv fragments [phase 4][72][lane 64][8]
+    const float* bias;       // [256] fp32 in packed output-channel order (ConvLayer::bias)
+    const half_t* tail_w;    // eight A fragments of the tail conv (engine.cpp tail(): "<key>.frag")
+    float* plane;            // out: [B][2H][2W] fp32, this branch's tail-conv sums without the terms that cross a 32-pixel column
+    float* apron;            // out: [side 2][B][px][2H] fp32, those terms (side 0: for the column to the right, 1: to the left)
+    float slope;             // PReLU slope (< 1)
+    int B, H, W;             // the conv's input size
+    int split;               // the tail conv's activation operand as hi + lo 2^-11 (MOE_PREC_MIXED, R branch)
+};
+bool launch_conv3x3_ps4(const Ps4Args& a, int max_groups, hipStream_t s);   // false: not applicable (caller keeps conv3x3_rw + tapsum4)
+bool ps4_applicable(int B, int H, int W);                                    // the shape conditions of the launcher (planning)
+size_t ps4_plane_bytes(int B, int H, int W);
+size_t ps4_apron_bytes(int B, int H, int W);
+hipError_t conv3x3_ps4_init();
+// y = plane_0 + plane_1 + the column aprons of both (conv3x3_ps4.hip), cast to the caller's type
+struct TailAddArgs {
+    const float* p0; const float* p1;      // [B][H][W] fp32 (p1 may be nullptr)
+    const float* a0; const float* a1;      // [2][B][px][H]
+    void* y; int y_dtype; const long long* y_off;
+    int B, H, W, px;                       // HR size; px: 32-pixel columns of the conv input (64 HR columns each)
+    int vec_ok;                            // every output row start is 16-byte aligned
+};
+void launch_tailadd(const TailAddArgs& a, hipStream_t s);
+
 // One fused ARSB  y = x + conv_2(PReLU(conv_1(x)))  (arsb_fused.hip; conv_2's weights carry the ScaleLayer factor)
 struct ArsbArgs {
     const half_t* x_hi; const half_t* x_lo;   // stream in  [B][H][W][64] (x_lo: low part in units of 2^-11, or nullptr)

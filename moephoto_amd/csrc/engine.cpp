@@ -88,6 +88,8 @@ struct NetOptions {
     int sp_impl = 1;          // sp_impl     auto (1: conv3x3_rw where it wins) | rw (2: conv3x3_rw for every epilogue it compiles) | sp (0: conv3x3_sp only)
     int tail_split = 1;       // tail_split  0 | r (1, default: the R branch's fused tail also splits its activation operand) | ru (2)
     int tail_form = 1;        // tail_form   sums (1, default: phase-class sums + aprons from conv3x3_rw, tapsum4) | planes (0: nine tap planes per phase, tapsum2)
+    int up_impl = 1;          // up_impl     ps4 (1, default: the fused-tail up-conv with all four phases in one workgroup, conv3x3_ps4.hip + tailadd) | rw (0: conv3x3_rw
+                              //             per phase, phase-class sums, tapsum4 -- round 3's form, kept for A/B and for shapes ps4 does not take)
     bool conv1x1 = true;      // conv1x1     lite's 1x1 layers on conv1x1.hip (0: generic kernel)
     bool x3_fuse = true;      // x3_fuse     split-operand 3x3 64->64 layers as ONE launch (conv64_x3.hip; 0: three launches)
     bool arsb_fuse = true;    // arsb_fuse   single-pass ARSBs as one launch (0: two launches)
@@ -125,6 +127,7 @@ struct NetOptions {
         if (key == "sp_impl") { const int t = tri(v, "sp", "auto", "rw", -1); if (t < 0) return false; sp_impl = t; return true; }
         if (key == "tail_split") { const int t = tri(v, "0", "r", "ru", -1); if (t < 0) return false; tail_split = t; return true; }
         if (key == "tail_form") { const int t = tri(v, "planes", "sums", nullptr, -1); if (t < 0) return false; tail_form = t; return true; }
+        if (key == "up_impl") { const int t = tri(v, "rw", "ps4", nullptr, -1); if (t < 0) return false; up_impl = t; return true; }
         if (key == "lo8") { const int t = onoff(v); if (t < 0) return false; lo8 = t; return true; }
         if (key == "x3_impl") { const int t = tri(v, "auto", "x3", "q8", -1); if (t < 0) return false; x3_impl = t; return true; }
         if (key == "k48") { const int t = onoff(v); if (t < 0) return false; k48 = t; return true; }
@@ -143,7 +146,7 @@ struct NetOptions {
     }
     void from_env()
     {
-        static const char* const names[][2] = {{"MOE_CONV_IMPL", "conv_impl"}, {"MOE_SP_IMPL", "sp_impl"}, {"MOE_TAIL_SPLIT", "tail_split"}, {"MOE_TAIL_FORM", "tail_form"},
+        static const char* const names[][2] = {{"MOE_CONV_IMPL", "conv_impl"}, {"MOE_SP_IMPL", "sp_impl"}, {"MOE_TAIL_SPLIT", "tail_split"}, {"MOE_TAIL_FORM", "tail_form"}, {"MOE_UP_IMPL", "up_impl"},
                                                {"MOE_CONV1X1", "conv1x1"}, {"MOE_ARSB_IMPL", "arsb_impl"}, {"MOE_K48", "k48"}, {"MOE_X3_IMPL", "x3_impl"}, {"MOE_LO8", "lo8"}, {"MOE_X3_FUSE", "x3_fuse"}, {"MOE_ARSB_FUSE", "arsb_fuse"}, {"MOE_FUSE_TAIL", "fuse_tail"},
                                                {"MOE_SEDN_FUSE", "sedn_fuse"}, {"MOE_POOL_FUSE", "pool_fuse"}, {"MOE_DBG", "dbg"}, {"MOE_TRACE_KEY", "trace_key"},
                                                {"MOE_TILES_PER_BATCH", "tiles_per_batch"}, {"MOE_MAX_GROUPS", "max_groups"}};
@@ -1065,6 +1068,7 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         Act fin[2];
         float* tp[2] = {nullptr, nullptr};
         const bool fuse = can_fuse_tail(n, f, B, h, w);      // last upsampler conv + 64->1 tail conv in one kernel
+        bool ps4 = false;
         int H = h, W = w;
         {   // form of the fused tail's output: phase-class sums when the last stage is a x2 shuffle the register-weight kernel takes
             int hl = h, wl = w;
@@ -1076,12 +1080,34 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
                 ok = ok && it != n.conv_index.end() && n.convs[it->second].slope < 1.f;
             }
             f.tail_form = ok ? 1 : 0;
+            // the same layer with all four phases in one workgroup (conv3x3_ps4.hip): one fp32 plane + column aprons per branch, added by tailadd
+            ps4 = ok && n.opt.up_impl == 1 && ps4_applicable(B, hl, wl) && (2 * wl) % 8 == 0;
         }
+        float* ps_plane[2] = {nullptr, nullptr};
+        float* ps_apron[2] = {nullptr, nullptr};
         for (int br = 0; br < 2; ++br) {
             Act cur = br == 0 ? Bb : A;
             H = h; W = w;
             for (int st = 0; st < n.stages; ++st) {
                 const std::string key = std::string(br == 0 ? "convt_R1" : "u") + ".up" + std::to_string(st);
+                if (ps4 && st == n.stages - 1) {
+                    ps_plane[br] = (float*)f.ar.take(ps4_plane_bytes(B, H, W) + 4096);
+                    ps_apron[br] = (float*)f.ar.take(ps4_apron_bytes(B, H, W) + 4096);
+                    if (!f.dry()) {
+                        const ConvLayer& L = n.convs[n.conv_index.at(key)];
+                        Ps4Args q{};
+                        q.in = cur.hi; q.wpk = f.blob<half_t>(L.w_hi); q.bias = L.has_bias ? f.blob<float>(L.bias) : f.small<float>("zero_bias");
+                        q.tail_w = f.small<half_t>(br == 0 ? "tail_r.frag" : "tail_u.frag");
+                        q.plane = ps_plane[br]; q.apron = ps_apron[br]; q.slope = L.slope; q.B = B; q.H = H; q.W = W;
+                        q.split = (f.mixed && f.tail_split_for(key)) ? 1 : 0;
+                        const int rec = f.prof_begin(key, 2.0 * (double)B * H * W * L.cout * L.cin * L.taps);
+                        const bool done = launch_conv3x3_ps4(q, n.max_groups, s);
+                        f.prof_end(rec);
+                        if (!done) return fail(MOE_EINVAL, "fused tail kernel (ps4) rejected layer %s", key.c_str());
+                    }
+                    H *= n.r; W *= n.r;
+                    continue;
+                }
                 if (fuse && st == n.stages - 1) {
                     tp[br] = (float*)f.ar.take(f.tail_form == 1 ? (size_t)tailsum_layout(B, H, W).total * 4 + 4096 : (size_t)9 * B * H * n.r * W * n.r * 4 + 4096);
                     const half_t* frag = f.dry() ? nullptr : f.small<half_t>(br == 0 ? "tail_r.frag" : "tail_u.frag");
@@ -1097,6 +1123,18 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
                 cur = nxt;
             }
             fin[br] = cur;
+        }
+        if (ps4) {
+            if (!f.dry()) {
+                TailAddArgs t{};
+                t.p0 = ps_plane[0]; t.p1 = ps_plane[1]; t.a0 = ps_apron[0]; t.a1 = ps_apron[1];
+                t.y = y; t.y_dtype = y_dtype; t.y_off = y_off_dev; t.B = B; t.H = H; t.W = W; t.px = (W / 2 + kTileW - 1) / kTileW;
+                t.vec_ok = f.y_vec;
+                const int rec = f.prof_begin("tailadd", 0.0);
+                launch_tailadd(t, s);
+                f.prof_end(rec);
+            }
+            return MOE_OK;
         }
         if (fuse) {
             if (!f.dry()) {

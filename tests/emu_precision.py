@@ -56,6 +56,30 @@ def q6_block(x, dim, fmt='e2m3'):
     return (q * sc).reshape(shp)[..., :n0].movedim(-1, dim)
 
 
+_WBT = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float32)
+_WG = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float32)
+_WAT = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float32)
+
+
+def wino_conv(v, w, b, mode='v1'):
+    """3x3 conv (zero pad 1, even H and W) as Winograd F(2x2, 3x3): Y = A^T [(G g G^T) . (B^T d B)] A with the transformed weights U and the transformed
+    4x4 input tiles V rounded to fp16 (the MFMA operands of a Winograd-domain kernel), fp32 accumulation over the input channels and an fp32 output transform.
+    `v` is expected to hold fp16 values already.  mode 'v1': V formed in fp32, one rounding; 'v2': two 1-D passes in fp16 arithmetic (a rounding after
+    each); 'v32': nothing rounded (checks the transform itself)."""
+    Bn, C, H, W = v.shape
+    d = F.pad(v, (1, 1, 1, 1)).unfold(2, 4, 2).unfold(3, 4, 2)          # (B, C, H/2, W/2, 4, 4)
+    if mode == 'v2':
+        V = r16(torch.einsum('bchwik,lk->bchwil', r16(torch.einsum('ij,bchwjk->bchwik', _WBT, d)), _WBT))
+    else:
+        V = torch.einsum('ij,bchwjk,lk->bchwil', _WBT, d, _WBT)
+        V = V if mode == 'v32' else r16(V)
+    U = torch.einsum('ij,ocjk,lk->ocil', _WG, w, _WG)
+    U = U if mode == 'v32' else r16(U)
+    M = torch.einsum('ocil,bchwil->bohwil', U, V)
+    Y = torch.einsum('ij,bohwjk,lk->bohwil', _WAT, M, _WAT).permute(0, 1, 2, 4, 3, 5).reshape(Bn, w.shape[0], H, W)
+    return Y if b is None else Y + b.view(1, -1, 1, 1)
+
+
 def prelu(x, a):
     return torch.where(x >= 0, x, x * a)
 
@@ -77,7 +101,7 @@ def layer_names(arch):
     return out
 
 
-def forward(arch, sd, x, w16=(), a16=(), stream16=False, corr8=(), shifts=(8, 4), lo8=False, corr6=None):
+def forward(arch, sd, x, w16=(), a16=(), stream16=False, corr8=(), shifts=(8, 4), lo8=False, corr6=None, wino=(), wino_mode='v1'):
     """w16 / a16: names of the convs whose weights / input activations are rounded to fp16 ('all' = every conv);
     stream16: the trunk stream is stored as fp16 after conv_input2 and after every ARSB.
     corr8: convs computed as  conv(w16, a16) + conv(fp8(w - w16), fp8(a16)) + conv(fp8(w16), fp8(a - a16))  -- the split-operand form with its two
@@ -89,6 +113,8 @@ def forward(arch, sd, x, w16=(), a16=(), stream16=False, corr8=(), shifts=(8, 4)
     r = 3 if arch == 'net3x' else 2
 
     def conv(name, v, w, b=None):
+        if name in wino:                 # Winograd-domain kernel: fp16 activations in, U and V rounded to fp16
+            return wino_conv(r16(v), w, b, wino_mode)
         if name in corr8 and corr6:      # the two correction products on block-scaled fp6 operands (blocks of 32 input channels)
             wh, vh = r16(w), r16(v)
             return (F.conv2d(vh, wh, b, padding=1) + F.conv2d(q6_block(vh, 1, corr6), q6_block(w - wh, 1, corr6), None, padding=1)
