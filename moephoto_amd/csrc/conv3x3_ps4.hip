@@ -39,6 +39,9 @@
 #ifndef PS4_FILL
 #define PS4_FILL 5        // VALU / SALU slots pinned behind each MFMA of a chunk
 #endif
+#ifndef PS4_ABL
+#define PS4_ABL 0         // timing ablations (tools/mk_variant.sh; results are wrong): 1 no row epilogue (PReLU, tail GEMM, image writes), 2 no finishing / DMA ops,
+#endif                    // 4 no bias reload, 8 no fragment reads, 16 no barrier, 32 no tail MFMAs only, 64 no DMA of the next block, 128 (with 64) both ring halves filled with real data at the head of a strip
 
 namespace {
 
@@ -93,8 +96,8 @@ constexpr OpList row_ops(bool split)
     for (int k = 0; k < 5; ++k) r.push(OP_TW, k);
     return r;
 }
-// what else a block carries: step 0 the finishing task of four rows published by the last barrier (its stores go out before this block's loads),
-// steps 1, 2 the DMA pieces of the next block (address half + issue half), step 3 nothing (the barrier sits in front of its chunk 10)
+// what else a block carries: step 0 the finishing task of four rows published by the last barrier (its stores go out before this block's loads), behind
+// it and in step 1 the DMA pieces of the next block (address half + issue half): two row steps ahead of the barrier in front of chunk 10 of step 3
 constexpr OpList extra_ops(int e)
 {
     OpList r;
@@ -103,9 +106,9 @@ constexpr OpList extra_ops(int e)
         for (int dy = 0; dy < 3; ++dy) { r.push(OP_FR, dy, 0); r.push(OP_FR, dy, 1); r.push(OP_FR, dy, 2); }
         r.push(OP_FS);
         r.push(OP_AR); r.push(OP_AS);
+        r.push(OP_DMA, 0, 0); r.push(OP_DMA, 0, 1);
     }
-    if (e == 1) for (int m = 0; m < 3; ++m) { r.push(OP_DMA, m, 0); r.push(OP_DMA, m, 1); }
-    if (e == 2) for (int m = 3; m < 5; ++m) { r.push(OP_DMA, m, 0); r.push(OP_DMA, m, 1); }
+    if (e == 1) for (int m = 1; m < 5; ++m) { r.push(OP_DMA, m, 0); r.push(OP_DMA, m, 1); }
     return r;
 }
 constexpr int count_kind(const OpList& l, int lo, int hi, int kind) { int n = 0; for (int i = lo; i < hi; ++i) n += l.op[i].kind == kind; return n; }
@@ -252,6 +255,10 @@ __global__ __launch_bounds__(256) void conv3x3_ps4_kernel(Ps4Args a)
                 const bool mine = m < 4 || w4 == 0;
                 char* dst = smem + (m < 4 ? (w4 + 4 * m) * 1024 : (mine ? 16 * 1024 : OFF_DUMP));
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)dst, 16, piece_off(ya, xa, mine), org, 0, 0);
+#if PS4_ABL & 128
+                // (ablation: real data in BOTH ring halves once per strip, no DMA afterwards -- what the stream costs with the operands' bits toggling but nothing fetched)
+                if (m < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(dst + BLKB), 16, piece_off(ya + 4 * RB, xa, mine), org + (unsigned)(4 * RB * W) * 128u, 0, 0);
+#endif
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s)
@@ -264,11 +271,12 @@ __global__ __launch_bounds__(256) void conv3x3_ps4_kernel(Ps4Args a)
             fr[1] = *(lds_h8_t)(fa[0] ^ 32u);
         }
 
-        auto block = [&](int k, auto BUF_) __attribute__((always_inline)) {
+        auto block = [&](int k, auto BUF_, auto LAST_) __attribute__((always_inline)) {
             constexpr int BUF = decltype(BUF_)::value;
+            constexpr bool LAST = decltype(LAST_)::value;     // the iteration behind the last input block: only its finishing task is wanted
             const int Rk = RB * (s0 - 1 + k);                 // first input row of this block
             // the next block's DMA
-            const bool live = k + 2 < nblk;                   // (the last iteration's input is never used)
+            const bool live = k + 2 < nblk;                   // (the last iteration has no input)
             const int yan = Rk + RB, xan = x0 - 1;
             const unsigned orgn = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((b * H + yan + RB) * W + xan + 1) * 128u));
             // finishing task of this wave: conv row yf, published by the previous block's barrier
@@ -276,7 +284,7 @@ __global__ __launch_bounds__(256) void conv3x3_ps4_kernel(Ps4Args a)
             const bool f_ok = (yf >= ylo) & (yf < yhi);
             unsigned fb[3];
             float2_t fs[2] = {{0.f, 0.f}, {0.f, 0.f}};
-            float2_t fv[6];
+            float2_t fv[2];
             float av[3];
 
             auto step = [&](auto E_) __attribute__((always_inline)) {
@@ -322,7 +330,13 @@ __global__ __launch_bounds__(256) void conv3x3_ps4_kernel(Ps4Args a)
                 };
                 auto op_bi = [&](auto CG_) __attribute__((always_inline)) {           // the drained slot becomes the accumulator of conv row Rk + e + 2: bias in
                     constexpr int cg = decltype(CG_)::value;
-                    acc[SL][cg] = *(const __attribute__((address_space(3))) float16_t*)(bias_ad + cg * 128);
+                    // (four 16-byte loads: a 64-byte load is split by the compiler into pieces without memory operands, and in front of such a piece it
+                    // waits for every LDS-DMA in flight with vmcnt(0) -- four full fetch latencies per block, 1.0 of 7.1 ms of the R branch)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4_t t = *(const __attribute__((address_space(3))) float4_t*)(bias_ad + (unsigned)(cg * 128 + q * 16));
+                        acc[SL][cg][4 * q] = t[0]; acc[SL][cg][4 * q + 1] = t[1]; acc[SL][cg][4 * q + 2] = t[2]; acc[SL][cg][4 * q + 3] = t[3];
+                    }
                 };
                 auto op_dma = [&](auto M_, auto HALF_) __attribute__((always_inline)) {
                     constexpr int m = decltype(M_)::value, half = decltype(HALF_)::value;
@@ -347,13 +361,12 @@ __global__ __launch_bounds__(256) void conv3x3_ps4_kernel(Ps4Args a)
                 auto op_fr = [&](auto DY_, auto DX_) __attribute__((always_inline)) {
                     constexpr int dy = decltype(DY_)::value, dx = decltype(DX_)::value;
                     constexpr int j0 = dx == 1 ? 0 : 1, j1 = dx == 1 ? 1 : 0;
-                    if constexpr (dx > 0) { fs[0] = fs[0] + fv[2 * (dx - 1)]; fs[1] = fs[1] + fv[2 * (dx - 1) + 1]; }      // the pair read one op earlier
-                    else if constexpr (dy > 0) { fs[0] = fs[0] + fv[4]; fs[1] = fs[1] + fv[5]; }
-                    fv[2 * dx] = *(const __attribute__((address_space(3))) float2_t*)(fb[dy] + (unsigned)((j0 * 9 + dx) * 128));
-                    fv[2 * dx + 1] = *(const __attribute__((address_space(3))) float2_t*)(fb[dy] + (unsigned)((j1 * 9 + dx) * 128));
+                    if constexpr (dx > 0 || dy > 0) { fs[0] = fs[0] + fv[0]; fs[1] = fs[1] + fv[1]; }      // the pair read one op earlier
+                    fv[0] = *(const __attribute__((address_space(3))) float2_t*)(fb[dy] + (unsigned)((j0 * 9 + dx) * 128));
+                    fv[1] = *(const __attribute__((address_space(3))) float2_t*)(fb[dy] + (unsigned)((j1 * 9 + dx) * 128));
                 };
                 auto op_fs = [&]() __attribute__((always_inline)) {
-                    fs[0] = fs[0] + fv[4]; fs[1] = fs[1] + fv[5];
+                    fs[0] = fs[0] + fv[0]; fs[1] = fs[1] + fv[1];
                     const float4_t o4 = {fs[0][0], fs[1][0], fs[0][1], fs[1][1]};      // HR columns 2 x .. 2 x + 3 of the pair
                     const bool ok = f_ok & (lane < 32) & (x0 + 2 * f_xp < W);
                     const unsigned vo = ok ? (unsigned)(f_i * 2 * W + 4 * f_xp) * 4u : kOOR;
@@ -377,78 +390,107 @@ __global__ __launch_bounds__(256) void conv3x3_ps4_kernel(Ps4Args a)
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rap, vo, f_ok ? so : 0u, 0);
                 };
 
+                if constexpr (LAST) {
+                    if constexpr (e == 0 && !(PS4_ABL & 2)) {
+                        op_fa();
+                        op_fr(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); op_fr(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}); op_fr(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+                        op_fr(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}); op_fr(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}); op_fr(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+                        op_fr(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}); op_fr(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}); op_fr(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+                        op_fs();
+                        op_ar(); op_as();
+                    }
+                    return;
+                }
                 auto chunk = [&](auto F_) __attribute__((always_inline)) {
                     constexpr int f = decltype(F_)::value;
                     constexpr int dx = f >> 2, ks = f & 3;
-                    if (e == 3 && f == 10) {
+                    if (e == 3 && f == 10 && !(PS4_ABL & 16)) {
                         // this block's T rows are written, the next block's pieces have landed, nobody reads this block's input rows any more (the last
                         // fragments are in registers); vmcnt(0) also covers this block's stores, issued three row steps ago
                         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_s_barrier();
                         asm volatile("" ::: "memory");
                     }
+                    constexpr OpList LM = row_ops(SPLIT);
+                    constexpr OpList LX = extra_ops(e);
+                    // A chunk is two halves of three MFMAs, each followed by its slice of the op lists: at most one tail MFMA per half, so that two of them (a chain
+                    // on one accumulator) are always three conv MFMAs apart -- issued back to back, the second waits out the first (the eight of a row of the R
+                    // branch cost 15 % of the kernel for 10 % of its MFMAs)
+                    auto half = [&](auto HC_) __attribute__((always_inline)) {
+                        constexpr int hc = decltype(HC_)::value;
 #pragma unroll
-                    for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                        for (int cg = 0; cg < 2; ++cg) {
+                        for (int u = 3 * hc; u < 3 * hc + 3; ++u) {
+                            const int dy = u >> 1, cg = u & 1;
                             const int sl = (e + 1 - dy + 4) & 3;
                             acc[sl][cg] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cg][(dy * 3 + dx) * 4 + ks], fr[f % 3], acc[sl][cg], 0, 0, 0);
                         }
-                    {   // the fragment of chunk f + 2
-                        constexpr int f2 = (f + 2) % 12;
-                        constexpr int rowsel = f + 2 < 12 ? BUF * RB + e : (e < 3 ? BUF * RB + e + 1 : (BUF ^ 1) * RB);
-                        fr[(f + 2) % 3] = *(lds_h8_t)((fa[f2 >> 2] ^ (unsigned)((f2 & 3) * 32)) + (unsigned)(rowsel * ROWB));
-                    }
-                    constexpr OpList LM = row_ops(SPLIT);
-                    constexpr OpList LX = extra_ops(e);
-                    constexpr int m_lo = f < 10 ? f * LM.n / 10 : LM.n, m_hi = f < 10 ? (f + 1) * LM.n / 10 : LM.n;
-                    constexpr int x_lo = f * LX.n / 12, x_hi = (f + 1) * LX.n / 12;
-                    auto runm = [&](auto I_) __attribute__((always_inline)) {
-                        constexpr int I = decltype(I_)::value;
-                        if constexpr (I >= m_lo && I < m_hi) {
-                            constexpr Op o = LM.op[I];
-                            if constexpr (o.kind == OP_P) op_p(std::integral_constant<int, o.a>{}, std::integral_constant<int, o.b>{}, std::integral_constant<int, o.c>{});
-                            if constexpr (o.kind == OP_WL) op_wl(std::integral_constant<int, o.a>{}, std::integral_constant<int, o.b>{});
-                            if constexpr (o.kind == OP_TM) op_tm(std::integral_constant<int, o.a>{}, std::integral_constant<int, o.b>{}, std::integral_constant<int, o.c>{});
-                            if constexpr (o.kind == OP_TW) op_tw(std::integral_constant<int, o.a>{});
+                        if constexpr (hc == 0) {      // the fragment of chunk f + 2
+                            constexpr int f2 = (f + 2) % 12;
+                            constexpr int rowsel = f + 2 < 12 ? BUF * RB + e : (e < 3 ? BUF * RB + e + 1 : (BUF ^ 1) * RB);
+                            if (!(PS4_ABL & 8)) fr[(f + 2) % 3] = *(lds_h8_t)((fa[f2 >> 2] ^ (unsigned)((f2 & 3) * 32)) + (unsigned)(rowsel * ROWB));
                         }
-                    };
-                    auto runx = [&](auto I_) __attribute__((always_inline)) {
-                        constexpr int I = decltype(I_)::value;
-                        if constexpr (I >= x_lo && I < x_hi) {
-                            constexpr Op o = LX.op[I];
-                            if constexpr (o.kind == OP_DMA) op_dma(std::integral_constant<int, o.a>{}, std::integral_constant<int, o.b>{});
-                            if constexpr (o.kind == OP_FA) op_fa();
-                            if constexpr (o.kind == OP_FR) op_fr(std::integral_constant<int, o.a>{}, std::integral_constant<int, o.b>{});
-                            if constexpr (o.kind == OP_FS) op_fs();
-                            if constexpr (o.kind == OP_AR) op_ar();
-                            if constexpr (o.kind == OP_AS) op_as();
-                        }
-                    };
+                        constexpr int h = 2 * f + hc;
+                        constexpr int m_lo = f < 10 ? h * LM.n / 20 : LM.n, m_hi = f < 10 ? (h + 1) * LM.n / 20 : LM.n;
+                        constexpr int x_lo = h * LX.n / 24, x_hi = (h + 1) * LX.n / 24;
+                        auto runm = [&](auto I_) __attribute__((always_inline)) {
+                            constexpr int I = decltype(I_)::value;
+                            if constexpr (I >= m_lo && I < m_hi && !(PS4_ABL & 1)) {
+                                constexpr Op o = LM.op[I];
+                                if constexpr (o.kind == OP_P) op_p(std::integral_constant<int, o.a>{}, std::integral_constant<int, o.b>{}, std::integral_constant<int, o.c>{});
+                                if constexpr (o.kind == OP_WL) op_wl(std::integral_constant<int, o.a>{}, std::integral_constant<int, o.b>{});
+                                if constexpr (o.kind == OP_TM && !(PS4_ABL & 32)) op_tm(std::integral_constant<int, o.a>{}, std::integral_constant<int, o.b>{}, std::integral_constant<int, o.c>{});
+                                if constexpr (o.kind == OP_TW) op_tw(std::integral_constant<int, o.a>{});
+                            }
+                        };
+                        auto runx = [&](auto I_) __attribute__((always_inline)) {
+                            constexpr int I = decltype(I_)::value;
+                            if constexpr (I >= x_lo && I < x_hi) {
+                                constexpr Op o = LX.op[I];
+                                if constexpr (o.kind != OP_DMA && (PS4_ABL & 2)) return;
+                                if constexpr (o.kind == OP_DMA && (PS4_ABL & 64)) return;
+                                if constexpr (o.kind == OP_DMA) op_dma(std::integral_constant<int, o.a>{}, std::integral_constant<int, o.b>{});
+                                if constexpr (o.kind == OP_FA) op_fa();
+                                if constexpr (o.kind == OP_FR) op_fr(std::integral_constant<int, o.a>{}, std::integral_constant<int, o.b>{});
+                                if constexpr (o.kind == OP_FS) op_fs();
+                                if constexpr (o.kind == OP_AR) op_ar();
+                                if constexpr (o.kind == OP_AS) op_as();
+                            }
+                        };
 #define PS4_M(I) runm(std::integral_constant<int, I>{});
-                    PS4_M(0) PS4_M(1) PS4_M(2) PS4_M(3) PS4_M(4) PS4_M(5) PS4_M(6) PS4_M(7) PS4_M(8) PS4_M(9) PS4_M(10) PS4_M(11) PS4_M(12) PS4_M(13) PS4_M(14) PS4_M(15)
-                    PS4_M(16) PS4_M(17) PS4_M(18) PS4_M(19) PS4_M(20) PS4_M(21) PS4_M(22) PS4_M(23) PS4_M(24) PS4_M(25) PS4_M(26) PS4_M(27) PS4_M(28) PS4_M(29) PS4_M(30) PS4_M(31)
-                    PS4_M(32) PS4_M(33) PS4_M(34) PS4_M(35) PS4_M(36) PS4_M(37) PS4_M(38) PS4_M(39) PS4_M(40) PS4_M(41) PS4_M(42) PS4_M(43) PS4_M(44) PS4_M(45) PS4_M(46) PS4_M(47)
+                        PS4_M(0) PS4_M(1) PS4_M(2) PS4_M(3) PS4_M(4) PS4_M(5) PS4_M(6) PS4_M(7) PS4_M(8) PS4_M(9) PS4_M(10) PS4_M(11) PS4_M(12) PS4_M(13) PS4_M(14) PS4_M(15)
+                        PS4_M(16) PS4_M(17) PS4_M(18) PS4_M(19) PS4_M(20) PS4_M(21) PS4_M(22) PS4_M(23) PS4_M(24) PS4_M(25) PS4_M(26) PS4_M(27) PS4_M(28) PS4_M(29) PS4_M(30) PS4_M(31)
+                        PS4_M(32) PS4_M(33) PS4_M(34) PS4_M(35) PS4_M(36) PS4_M(37) PS4_M(38) PS4_M(39) PS4_M(40) PS4_M(41) PS4_M(42) PS4_M(43) PS4_M(44) PS4_M(45) PS4_M(46) PS4_M(47)
 #undef PS4_M
 #define PS4_X(I) runx(std::integral_constant<int, I>{});
-                    PS4_X(0) PS4_X(1) PS4_X(2) PS4_X(3) PS4_X(4) PS4_X(5) PS4_X(6) PS4_X(7) PS4_X(8) PS4_X(9) PS4_X(10) PS4_X(11) PS4_X(12) PS4_X(13) PS4_X(14) PS4_X(15)
+                        PS4_X(0) PS4_X(1) PS4_X(2) PS4_X(3) PS4_X(4) PS4_X(5) PS4_X(6) PS4_X(7) PS4_X(8) PS4_X(9) PS4_X(10) PS4_X(11) PS4_X(12) PS4_X(13) PS4_X(14) PS4_X(15)
 #undef PS4_X
-                    if (f == 10) op_bi(std::integral_constant<int, 0>{});
-                    if (f == 11) op_bi(std::integral_constant<int, 1>{});
-                    constexpr int ntm = count_kind(LM, m_lo, m_hi, OP_TM);
+                        if (f == 10 && hc == 1 && !(PS4_ABL & 4)) op_bi(std::integral_constant<int, 0>{});
+                        if (f == 11 && hc == 1 && !(PS4_ABL & 4)) op_bi(std::integral_constant<int, 1>{});
+                    };
+                    half(std::integral_constant<int, 0>{});
+                    half(std::integral_constant<int, 1>{});
 #ifndef PS4_NOPIN
 #pragma unroll
-                    for (int i_ = 0; i_ < 6; ++i_) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        if (i_ == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x006, PS4_FILL, 0);
-                    }
+                    for (int hc = 0; hc < 2; ++hc) {
+                        const int h = 2 * f + hc;
+                        const int m_lo = f < 10 ? h * LM.n / 20 : LM.n, m_hi = f < 10 ? (h + 1) * LM.n / 20 : LM.n;
+                        const int ntm = (PS4_ABL & 33) ? 0 : count_kind(LM, m_lo, m_hi, OP_TM);
 #pragma unroll
-                    for (int i_ = 0; i_ < 2; ++i_)
-                        if (i_ < ntm) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x006, PS4_FILL, 0); }
+                        for (int i_ = 0; i_ < 3; ++i_) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            if (i_ == 0 && hc == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x006, PS4_FILL, 0);
+                        }
+#pragma unroll
+                        for (int i_ = 0; i_ < 2; ++i_)
+                            if (i_ < ntm) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x006, PS4_FILL, 0); }
+                    }
 #endif
                     __builtin_amdgcn_sched_barrier(0);
                 };
+#if PS4_ABL
+                if constexpr (!LAST) asm volatile("" ::"v"(acc[SL][0]), "v"(acc[SL][1]), "v"(Gt));      // (ablation builds: the row's results stay live without its epilogue)
+#endif
 #define PS4_CHUNK(F) chunk(std::integral_constant<int, F>{});
                 PS4_CHUNK(0) PS4_CHUNK(1) PS4_CHUNK(2) PS4_CHUNK(3) PS4_CHUNK(4) PS4_CHUNK(5) PS4_CHUNK(6) PS4_CHUNK(7) PS4_CHUNK(8) PS4_CHUNK(9) PS4_CHUNK(10) PS4_CHUNK(11)
 #undef PS4_CHUNK
@@ -460,11 +502,12 @@ __global__ __launch_bounds__(256) void conv3x3_ps4_kernel(Ps4Args a)
         };
 
         int k = 0;
-        for (; k + 1 < nblk; k += 2) {
-            block(k, std::integral_constant<int, 0>{});
-            block(k + 1, std::integral_constant<int, 1>{});
+        for (; k + 2 < nblk; k += 2) {
+            block(k, std::integral_constant<int, 0>{}, std::false_type{});
+            block(k + 1, std::integral_constant<int, 1>{}, std::false_type{});
         }
-        if (k < nblk) block(k, std::integral_constant<int, 0>{});
+        if (k + 1 < nblk) { block(k, std::integral_constant<int, 0>{}, std::false_type{}); ++k; }
+        block(k, std::integral_constant<int, 0>{}, std::true_type{});      // (its ring half is not used)
     }
 #endif
 }
