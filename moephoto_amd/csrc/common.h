@@ -118,6 +118,7 @@ struct Ps4Args {
     const half_t* wpk;       // pack_conv fragments [phase 4][72][lane 64][8]
     const float* bias;       // [256] fp32 in packed output-channel order (ConvLayer::bias)
     const half_t* tail_w;    // eight A fragments of the tail conv (engine.cpp tail(): "<key>.frag")
+    half_t* out;             // store form (not the last stage): [B][2H][2W][64] fp16, PReLU'd and pixel-shuffled; plane / apron / tail_w unused
     float* plane;            // out: [B][2H][2W] fp32, this branch's tail-conv sums without the terms that cross a 32-pixel column
     float* apron;            // out: [side 2][B][px][2H] fp32, those terms (side 0: for the column to the right, 1: to the left)
     float slope;             // PReLU slope (< 1)

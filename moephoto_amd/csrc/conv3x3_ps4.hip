@@ -65,7 +65,7 @@ typedef float float2_t __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(3))) half8_t* lds_h8_t;
 
 // ---- what rides in the MFMA stream of a row step, as micro-ops (conv3x3_rw.hip, arsb32c.hip: an MFMA hides ~5 other instructions) --------------------
-enum OpKind : int { OP_NONE = 0, OP_P, OP_WL, OP_TM, OP_TW, OP_BI, OP_DMA, OP_FA, OP_FR, OP_FS, OP_AR, OP_AS };
+enum OpKind : int { OP_NONE = 0, OP_P, OP_WL, OP_TM, OP_TW, OP_BI, OP_DMA, OP_FA, OP_FR, OP_FS, OP_AR, OP_AS, OP_ST };
 struct Op { int kind, a, b, c; };
 struct OpList {
     int n = 0;
@@ -75,9 +75,17 @@ struct OpList {
 };
 // The row epilogue: per 16 channels (cg, half q) four PReLU ops (one channel pair each with the split, two without), then the tail MFMA(s) of that
 // slice.  Tail-weight fragments come from LDS into two rotating register sets (WL n -> set n & 1, TM n reads set n & 1).
-constexpr OpList row_ops(bool split)
+constexpr OpList row_ops(int epi)      // 0: store (PReLU, pixel shuffle), 1: fused tail, 2: fused tail with split activations
 {
     OpList r;
+    if (epi == 0) {                     // per 16 channels (cg, g): PReLU of four channel pairs, then their 16-byte store
+        for (int s = 0; s < 4; ++s) {
+            r.push(OP_P, s >> 1, 4 * (s & 1), 2); r.push(OP_P, s >> 1, 4 * (s & 1) + 2, 2);
+            r.push(OP_ST, s >> 1, s & 1);
+        }
+        return r;
+    }
+    const bool split = epi == 2;
     int nl = 0;
     auto wl = [&](int frag) { r.push(OP_WL, frag, nl & 1); ++nl; };
     int nt = 0;
@@ -98,9 +106,14 @@ constexpr OpList row_ops(bool split)
 }
 // what else a block carries: step 0 the finishing task of four rows published by the last barrier (its stores go out before this block's loads), behind
 // it and in step 1 the DMA pieces of the next block (address half + issue half): two row steps ahead of the barrier in front of chunk 10 of step 3
-constexpr OpList extra_ops(int e)
+constexpr OpList extra_ops(int e, bool tail)
 {
     OpList r;
+    if (!tail) {                        // (store form: the row's four stores go out in chunks 0 .. 4 of a step, the pieces in its chunks 6 .. 11)
+        if (e == 0) for (int m = 0; m < 3; ++m) { r.push(OP_DMA, m, 0); r.push(OP_DMA, m, 1); }
+        if (e == 1) for (int m = 3; m < 5; ++m) { r.push(OP_DMA, m, 0); r.push(OP_DMA, m, 1); }
+        return r;
+    }
     if (e == 0) {
         r.push(OP_FA);
         for (int dy = 0; dy < 3; ++dy) { r.push(OP_FR, dy, 0); r.push(OP_FR, dy, 1); r.push(OP_FR, dy, 2); }
@@ -113,10 +126,13 @@ constexpr OpList extra_ops(int e)
 }
 constexpr int count_kind(const OpList& l, int lo, int hi, int kind) { int n = 0; for (int i = lo; i < hi; ++i) n += l.op[i].kind == kind; return n; }
 
-template <bool SPLIT, bool MASK>
+// EPI 0: PReLU + pixel-shuffle stores (the other upsampler stages), 1: fused tail, 2: fused tail with the activation operand split (hi + lo 2^-11)
+template <int EPI, bool MASK>
 __global__ __launch_bounds__(256) void conv3x3_ps4_kernel(Ps4Args a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
+    constexpr bool TAIL = EPI >= 1, SPLIT = EPI == 2;
+    constexpr bool PERM = !TAIL;         // store form: channel order that makes a lane's registers 8g .. 8g+7 eight consecutive channels (16-byte stores, conv3x3_rw.hip)
     constexpr unsigned kOOR = 0xFFFF0000u;
     extern __shared__ __attribute__((aligned(1024))) char smem[];      // (fragment addresses XOR their k-slice bits: the base must be 128-byte aligned)
     const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
@@ -138,10 +154,15 @@ __global__ __launch_bounds__(256) void conv3x3_ps4_kernel(Ps4Args a)
     half8_t wf[2][36];
     {
         const half_t* wsrc = a.wpk + (long long)w4 * (72 * 512);
+        int src = lane;
+        if (PERM) {      // MFMA row i = 8q + 4h' + e (register 4q + e of the lanes hh = h') is given channel 16 (q >> 1) + 8 h' + 4 (q & 1) + e of its group
+            const int wi = lane & 31, wq = wi >> 3;
+            src = (lane & 32) | (16 * (wq >> 1) + 8 * ((wi >> 2) & 1) + 4 * (wq & 1) + (wi & 3));
+        }
 #pragma unroll
         for (int f = 0; f < 36; ++f) {
-            wf[0][f] = *(const half8_t*)(wsrc + ((f * 2 + 0) * 64 + lane) * 8);
-            wf[1][f] = *(const half8_t*)(wsrc + ((f * 2 + 1) * 64 + lane) * 8);
+            wf[0][f] = *(const half8_t*)(wsrc + ((f * 2 + 0) * 64 + src) * 8);
+            wf[1][f] = *(const half8_t*)(wsrc + ((f * 2 + 1) * 64 + src) * 8);
         }
 #pragma unroll
         for (int f = 0; f < 36; ++f) asm volatile("" : "+a"(wf[0][f]));
@@ -155,12 +176,14 @@ __global__ __launch_bounds__(256) void conv3x3_ps4_kernel(Ps4Args a)
     // the tap-image ring as zeros (the slots no lane ever writes -- the consumer column beyond the 32 pixels -- stay zero)
     {
         const int bw = tid >> 6, bcg = (tid >> 5) & 1, bhh = (tid >> 4) & 1, bq = (tid >> 2) & 3, be = tid & 3;
-        *(float*)(smem + OFF_BIAS + tid * 4) = a.bias[64 * bw + 32 * bcg + 8 * bq + 4 * bhh + be];
-        const u4_t* tsrc = (const u4_t*)a.tail_w;
-        *(u4_t*)(smem + OFF_TW + tid * 16) = tsrc[tid];
-        *(u4_t*)(smem + OFF_TW + 4096 + tid * 16) = SPLIT ? tsrc[256 + tid] : u4_t{0u, 0u, 0u, 0u};
-        const u4_t z = {0u, 0u, 0u, 0u};
-        for (int o = tid * 16; o < TROWS * TREC; o += 256 * 16) *(u4_t*)(smem + OFF_T + o) = z;
+        *(float*)(smem + OFF_BIAS + tid * 4) = a.bias[64 * bw + 32 * bcg + (PERM ? 16 * (bq >> 1) + 8 * bhh + 4 * (bq & 1) + be : 8 * bq + 4 * bhh + be)];
+        if (TAIL) {
+            const u4_t* tsrc = (const u4_t*)a.tail_w;
+            *(u4_t*)(smem + OFF_TW + tid * 16) = tsrc[tid];
+            *(u4_t*)(smem + OFF_TW + 4096 + tid * 16) = SPLIT ? tsrc[256 + tid] : u4_t{0u, 0u, 0u, 0u};
+            const u4_t z = {0u, 0u, 0u, 0u};
+            for (int o = tid * 16; o < TROWS * TREC; o += 256 * 16) *(u4_t*)(smem + OFF_T + o) = z;
+        }
     }
     const unsigned bias_ad = lds0 + (unsigned)(OFF_BIAS + ((w4 * 2 + 0) * 2 + hh) * 64);      // (cg 1: + 128)
     const unsigned tw_ad = lds0 + (unsigned)(OFF_TW + lane * 16);
@@ -168,8 +191,9 @@ __global__ __launch_bounds__(256) void conv3x3_ps4_kernel(Ps4Args a)
     // ---- input: raw-buffer descriptor shifted by four rows + one pixel so that every block origin is a non-negative offset --------------------------------
     const unsigned in_pad = (unsigned)(RB * W + 1) * 128u;
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.in - in_pad), 0, (unsigned)a.B * H * W * 128u + in_pad, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rpl = __builtin_amdgcn_make_buffer_rsrc((void*)a.plane, 0, (unsigned)a.B * H * W * 16u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rap = __builtin_amdgcn_make_buffer_rsrc((void*)a.apron, 0, (unsigned)a.B * px * H * 16u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rpl = TAIL ? __builtin_amdgcn_make_buffer_rsrc((void*)a.plane, 0, (unsigned)a.B * H * W * 16u, 0x00020000)
+                                            : __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (unsigned)a.B * H * W * 512u, 0x00020000);      // (store form: [B][2H][2W][64] fp16)
+    const __amdgpu_buffer_rsrc_t rap = __builtin_amdgcn_make_buffer_rsrc((void*)(TAIL ? (void*)a.apron : (void*)a.out), 0, TAIL ? (unsigned)a.B * px * H * 16u : 0u, 0x00020000);
     unsigned d_off = 0, d_r = 0, d_cc = 0;
     auto piece_addr = [&](int m) {                           // piece i = w4 + 4 m (m < 4) / 16 (m = 4): the lane's pixel of the 4 x 34 block, its logical 16-byte slot
         unsigned q = (unsigned)((m < 4 ? w4 + 4 * m : 16) * 8 + (lane >> 3));
@@ -238,7 +262,7 @@ __global__ __launch_bounds__(256) void conv3x3_ps4_kernel(Ps4Args a)
         const int s1 = min(nyb, s0 + (item_end - item));
         item += s1 - s0;
         const int x0 = pxi * kTileW;
-        const int nblk = s1 - s0 + 3;                         // input blocks s0 - 1 .. s1, then one more iteration for the last finishing tasks
+        const int nblk = s1 - s0 + 3;                         // input blocks s0 - 1 .. s1, then (fused tail) one more iteration for the last finishing tasks
         const bool okx = x0 + j < W;
         const int ylo = RB * s0, yhi = RB * s1;
 
@@ -310,6 +334,15 @@ __global__ __launch_bounds__(256) void conv3x3_ps4_kernel(Ps4Args a)
                         }
                         hX[k & 3] = hv; lX[k & 3] = lv;
                     }
+                };
+                // store form: channels 32 cg + 16 g + 8 hh .. + 7 of HR pixel (2 orow + pi, 2 (x0 + j) + pj): one 16-byte word
+                auto op_st = [&](auto CG_, auto G_) __attribute__((always_inline)) {
+                    constexpr int cg = decltype(CG_)::value, gq = decltype(G_)::value;
+                    const bool rok = (orow >= ylo) & (orow < yhi);
+                    const unsigned vo = okx ? (unsigned)(2 * j) * 128u + (unsigned)hh * 16u : kOOR;
+                    const unsigned so = rok ? ((unsigned)((b * 2 * H + 2 * orow + pi) * 2 * W + 2 * x0 + pj) * 128u + (unsigned)(64 * cg + 32 * gq)) : kOOR;
+                    const u4_t d = {hX[0], hX[1], hX[2], hX[3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(d, rpl, vo, so, 0);
                 };
                 auto op_wl = [&](auto F_, auto S_) __attribute__((always_inline)) {
                     constexpr int fg = decltype(F_)::value, st = decltype(S_)::value;
@@ -411,8 +444,8 @@ __global__ __launch_bounds__(256) void conv3x3_ps4_kernel(Ps4Args a)
                         __builtin_amdgcn_s_barrier();
                         asm volatile("" ::: "memory");
                     }
-                    constexpr OpList LM = row_ops(SPLIT);
-                    constexpr OpList LX = extra_ops(e);
+                    constexpr OpList LM = row_ops(EPI);
+                    constexpr OpList LX = extra_ops(e, TAIL);
                     // A chunk is two halves of three MFMAs, each followed by its slice of the op lists: at most one tail MFMA per half, so that two of them (a chain
                     // on one accumulator) are always three conv MFMAs apart -- issued back to back, the second waits out the first (the eight of a row of the R
                     // branch cost 15 % of the kernel for 10 % of its MFMAs)
@@ -430,8 +463,9 @@ __global__ __launch_bounds__(256) void conv3x3_ps4_kernel(Ps4Args a)
                             if (!(PS4_ABL & 8)) fr[(f + 2) % 3] = *(lds_h8_t)((fa[f2 >> 2] ^ (unsigned)((f2 & 3) * 32)) + (unsigned)(rowsel * ROWB));
                         }
                         constexpr int h = 2 * f + hc;
-                        constexpr int m_lo = f < 10 ? h * LM.n / 20 : LM.n, m_hi = f < 10 ? (h + 1) * LM.n / 20 : LM.n;
-                        constexpr int x_lo = h * LX.n / 24, x_hi = (h + 1) * LX.n / 24;
+                        constexpr int MH = TAIL ? 20 : 10;      // half-chunks the row's op list is dealt to
+                        constexpr int m_lo = h < MH ? h * LM.n / MH : LM.n, m_hi = h < MH ? (h + 1) * LM.n / MH : LM.n;
+                        constexpr int x_lo = TAIL ? h * LX.n / 24 : (h < 12 ? 0 : (h - 12) * LX.n / 12), x_hi = TAIL ? (h + 1) * LX.n / 24 : (h < 12 ? 0 : (h - 11) * LX.n / 12);
                         auto runm = [&](auto I_) __attribute__((always_inline)) {
                             constexpr int I = decltype(I_)::value;
                             if constexpr (I >= m_lo && I < m_hi && !(PS4_ABL & 1)) {
@@ -440,6 +474,7 @@ __global__ __launch_bounds__(256) void conv3x3_ps4_kernel(Ps4Args a)
                                 if constexpr (o.kind == OP_WL) op_wl(std::integral_constant<int, o.a>{}, std::integral_constant<int, o.b>{});
                                 if constexpr (o.kind == OP_TM && !(PS4_ABL & 32)) op_tm(std::integral_constant<int, o.a>{}, std::integral_constant<int, o.b>{}, std::integral_constant<int, o.c>{});
                                 if constexpr (o.kind == OP_TW) op_tw(std::integral_constant<int, o.a>{});
+                                if constexpr (o.kind == OP_ST) op_st(std::integral_constant<int, o.a>{}, std::integral_constant<int, o.b>{});
                             }
                         };
                         auto runx = [&](auto I_) __attribute__((always_inline)) {
@@ -473,7 +508,8 @@ __global__ __launch_bounds__(256) void conv3x3_ps4_kernel(Ps4Args a)
 #pragma unroll
                     for (int hc = 0; hc < 2; ++hc) {
                         const int h = 2 * f + hc;
-                        const int m_lo = f < 10 ? h * LM.n / 20 : LM.n, m_hi = f < 10 ? (h + 1) * LM.n / 20 : LM.n;
+                        const int MH = TAIL ? 20 : 10;
+                        const int m_lo = h < MH ? h * LM.n / MH : LM.n, m_hi = h < MH ? (h + 1) * LM.n / MH : LM.n;
                         const int ntm = (PS4_ABL & 33) ? 0 : count_kind(LM, m_lo, m_hi, OP_TM);
 #pragma unroll
                         for (int i_ = 0; i_ < 3; ++i_) {
@@ -483,7 +519,7 @@ __global__ __launch_bounds__(256) void conv3x3_ps4_kernel(Ps4Args a)
                         }
 #pragma unroll
                         for (int i_ = 0; i_ < 2; ++i_)
-                            if (i_ < ntm) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x006, PS4_FILL, 0); }
+                            if (TAIL && i_ < ntm) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x006, PS4_FILL, 0); }
                     }
 #endif
                     __builtin_amdgcn_sched_barrier(0);
@@ -507,7 +543,7 @@ __global__ __launch_bounds__(256) void conv3x3_ps4_kernel(Ps4Args a)
             block(k + 1, std::integral_constant<int, 1>{}, std::false_type{});
         }
         if (k + 1 < nblk) { block(k, std::integral_constant<int, 0>{}, std::false_type{}); ++k; }
-        block(k, std::integral_constant<int, 0>{}, std::true_type{});      // (its ring half is not used)
+        if (TAIL) block(k, std::integral_constant<int, 0>{}, std::true_type{});      // (its ring half is not used)
     }
 #endif
 }
@@ -571,10 +607,10 @@ __global__ __launch_bounds__(256) void tailadd_kernel(TailAddArgs a)
     }
 }
 
-template <bool SPLIT, bool MASK>
+template <int EPI, bool MASK>
 hipError_t set_limit()
 {
-    return hipFuncSetAttribute((const void*)conv3x3_ps4_kernel<SPLIT, MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    return hipFuncSetAttribute((const void*)conv3x3_ps4_kernel<EPI, MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
 }
 
 }  // namespace
@@ -582,10 +618,11 @@ hipError_t set_limit()
 hipError_t conv3x3_ps4_init()
 {
     hipError_t e;
-    if ((e = set_limit<false, false>()) != hipSuccess) return e;
-    if ((e = set_limit<false, true>()) != hipSuccess) return e;
-    if ((e = set_limit<true, false>()) != hipSuccess) return e;
-    return set_limit<true, true>();
+    if ((e = set_limit<0, true>()) != hipSuccess) return e;
+    if ((e = set_limit<1, false>()) != hipSuccess) return e;
+    if ((e = set_limit<1, true>()) != hipSuccess) return e;
+    if ((e = set_limit<2, false>()) != hipSuccess) return e;
+    return set_limit<2, true>();
 }
 
 // bytes of one branch's buffers: the fp32 plane [B][2H][2W] and the column aprons [side 2][B][px][2H]
@@ -607,12 +644,17 @@ bool launch_conv3x3_ps4(const Ps4Args& a, int max_groups, hipStream_t s)
     const long long items = (long long)a.B * px * (a.H / RB);
     const int G = (int)std::min<long long>(items, max_groups);
     const bool ragged = a.W % kTileW != 0;
+    if (a.out) {        // store form
+        if (a.plane || (long long)a.B * a.H * a.W * 512 >= (1ll << 32) - 65536) return false;
+        conv3x3_ps4_kernel<0, true><<<dim3(G), dim3(256), LDS_BYTES, s>>>(a);
+        return true;
+    }
     if (a.split) {
-        if (ragged) conv3x3_ps4_kernel<true, true><<<dim3(G), dim3(256), LDS_BYTES, s>>>(a);
-        else conv3x3_ps4_kernel<true, false><<<dim3(G), dim3(256), LDS_BYTES, s>>>(a);
+        if (ragged) conv3x3_ps4_kernel<2, true><<<dim3(G), dim3(256), LDS_BYTES, s>>>(a);
+        else conv3x3_ps4_kernel<2, false><<<dim3(G), dim3(256), LDS_BYTES, s>>>(a);
     } else {
-        if (ragged) conv3x3_ps4_kernel<false, true><<<dim3(G), dim3(256), LDS_BYTES, s>>>(a);
-        else conv3x3_ps4_kernel<false, false><<<dim3(G), dim3(256), LDS_BYTES, s>>>(a);
+        if (ragged) conv3x3_ps4_kernel<1, true><<<dim3(G), dim3(256), LDS_BYTES, s>>>(a);
+        else conv3x3_ps4_kernel<1, false><<<dim3(G), dim3(256), LDS_BYTES, s>>>(a);
     }
     return true;
 }

@@ -764,6 +764,12 @@ struct Fwd {
                 if (!(fast && launch_conv3x3_rw(ca, s))) fused_ok = false;
                 return;
             }
+            if (fast && n.opt.up_impl == 1 && !ca.tplanes && !ca.pool && ca.r == 2 && ca.nchunks == 4 && ca.in_cs == 64 && ca.acc_mode == 0 && !ca.res && !ca.out_lo && ca.scale == 1.f &&
+                !ca.dbg && L.has_bias) {
+                Ps4Args q{};      // the x2 upsampler stages that store their tensor: all four phases in one workgroup (conv3x3_ps4.hip, store form)
+                q.in = ca.in; q.wpk = ca.wpk; q.bias = ca.bias; q.out = ca.out; q.slope = ca.slope; q.B = ca.B; q.H = ca.H; q.W = ca.W;
+                if (launch_conv3x3_ps4(q, n.max_groups, s)) return;
+            }
             if (fast && rw_mode && !ca.tplanes && launch_conv3x3_rw(ca, s)) { pool_done = ca.pool != nullptr; return; }
             if (fast && launch_conv3x3_sp(ca, s)) return;
             if (ca.tplanes) { fused_ok = false; return; }

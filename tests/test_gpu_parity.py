@@ -946,3 +946,43 @@ def test_split_operand_conv_single_launch(dev):
     finally:
         if m is not None:
             m.set_option('x3_fuse', 1).set_option('x3_impl', 'auto').set_debug(False).set_exact_blocks(-1)
+
+
+@pytest.mark.parametrize('key', ['a2', 'a4'])
+def test_upconv_all_phases_in_one_workgroup_vs_per_phase_form(key, dev):
+    """Option up_impl = ps4 (default; conv3x3_ps4.hip: every x2 upsampler stage with all four pixel-shuffle phases in one workgroup, rows streamed down a
+    32-pixel column; the last stage carries the 64 -> 1 tail conv and leaves one fp32 plane + column aprons per branch, added by tailadd) against round 3's
+    form (up_impl = rw: one phase per workgroup, phase-class sums, tapsum4).  The conv sums are the same MFMAs in the same order (bit-identical); the tail's
+    nine products per output pixel are associated differently in fp32: the outputs agree to a few 1e-7 -- on shapes that are ragged against the 4-row blocks
+    and 32-pixel columns, with several planes and strips -- both hold the tolerance against the oracle, a launch repeated gives the same bits, and the
+    result does not depend on how the column-major ranges are cut (7 workgroups instead of one per CU: the rows above / below a range are recomputed)."""
+    arch = gd.MODELS[key][0]
+    sd = gd.state_dict_for(key, load_state_dict_file)
+    m = module_for(key)
+    shapes = ((3, 8, 8), (3, 24, 40), (2, 40, 264), (3, 16, 72), (1, 88, 64), (3, 64, 64)) if key == 'a4' else ((3, 24, 40), (2, 40, 264), (3, 8, 36), (1, 88, 64), (3, 128, 96), (4, 256, 256))
+    try:
+        for shape in shapes:
+            for kind in ('natural', 'noise'):
+                x = (gd.natural_image(31, shape) if kind == 'natural' else gd.noise_image(31, shape))[:, None]
+                xd = torch.from_numpy(x).to(dev)
+                y_rw = m.set_option('up_impl', 'rw')(xd)[-1].cpu().numpy()
+                y_ps = m.set_option('up_impl', 'ps4')(xd)[-1].cpu().numpy()
+                y_again = m(xd)[-1].cpu().numpy()
+                y_cut = m.set_option('max_groups', 7)(xd)[-1].cpu().numpy()
+                m.set_option('max_groups', 0)
+                assert np.isfinite(y_ps).all(), (key, shape, kind)
+                assert np.abs(y_ps - y_rw).max() <= 2e-6, (key, shape, kind, float(np.abs(y_ps - y_rw).max()))
+                assert np.array_equal(y_ps, y_again), (key, shape, kind)
+                assert np.array_equal(y_ps, y_cut), (key, shape, kind, float(np.abs(y_ps - y_cut).max()))
+                if shape[1] * shape[2] <= 128 * 128:
+                    want = onets.forward(arch, sd, x).numpy()
+                    assert np.abs(y_ps - want).max() <= TOL, (key, shape, kind, float(np.abs(y_ps - want).max()))
+        # an fp16 result tensor (the drop-in path's dtype): tailadd rounds once
+        x = gd.noise_image(7, (3, 24, 40))[:, None]
+        m16 = module_for(key, dtype=torch.float16)
+        y16 = m16(torch.from_numpy(x).to(dev).half())[-1].float().cpu().numpy()
+        m32 = module_for(key)
+        y32 = m32(torch.from_numpy(x.astype(np.float16).astype(np.float32)).to(dev))[-1].cpu().numpy()
+        assert np.abs(y16 - y32).max() <= HALF_OUT * max(1.0, float(np.abs(y32).max()) / 2), (key, float(np.abs(y16 - y32).max()))
+    finally:
+        m.set_option('up_impl', 'ps4').set_option('max_groups', 0)
