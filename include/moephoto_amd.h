@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MOE_ABI_VERSION 1
+#define MOE_ABI_VERSION 2      /* 2: MOE_PREC_AUTO, moe_net_resolved_precision (round 4); 1 also lacked a bump for moe_net_set_option / moe_device_info / moe_stitch_dev */
 
 /* error codes */
 #define MOE_OK 0
@@ -69,6 +69,10 @@ extern "C" {
                                 * tail convs see their weights to ~22 bits: <= 1e-3 vs the fp32 reference on every input
                                 * class at ~1.1-1.2x the FP16 time */
 
+#define MOE_PREC_AUTO 4        /* the family's default: MIXED for Net2x/3x/4x and NetDN, FP16 for SEDN, FP16X3 for lite -- the arithmetic that
+                                * holds 1e-3 max-abs against the reference's fp32 CPU path on every input class.  What a drop-in caller passes
+                                * (INTEGRATION.md section 1): the reference's own dtype policy is one line too (python/imageProcess.py:309-317) */
+
 typedef struct moe_net moe_net;
 typedef struct moe_plan moe_plan;
 
@@ -94,8 +98,11 @@ int moe_net_param_info(const moe_net* net, int index, const char** name, int64_t
 /* one load_state_dict entry: fp32, C-contiguous, host memory; copied */
 int moe_net_set_param(moe_net* net, const char* name, const float* data, const int64_t* shape, int ndim);
 /* pack + upload weights to HIP device `device`; strict like load_state_dict (every parameter set).
- * May be called again to move / change precision. */
+ * May be called again to move / change precision.  precision: MOE_PREC_AUTO for the family's default (what a drop-in caller
+ * passes), or a specific arithmetic (MIXED is refused for SEDN / lite, which have no such recipe). */
 int moe_net_finalize(moe_net* net, int device, int precision);
+/* what `precision` resolves to for this net's family (MOE_PREC_AUTO -> FP16 / FP16X3 / MIXED; anything else -> itself) */
+int moe_net_resolved_precision(const moe_net* net, int precision);
 /* device bytes of scratch a forward of B planes of h x w needs (allocated lazily, grow-only, owned by the net) */
 int64_t moe_net_workspace_bytes(const moe_net* net, int B, int h, int w);
 /* largest tile (pixels of one input plane) a forward accepts: the convolution kernels address their tensors with 32-bit byte

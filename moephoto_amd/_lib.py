@@ -13,9 +13,10 @@ LIB_PATH = os.path.join(HERE, 'libmoephoto_amd.so')
 OK, EINVAL, ENOMEM, EHIP, ESTATE = 0, -1, -2, -3, -4
 ARCH_NET2X, ARCH_NET3X, ARCH_NET4X, ARCH_NETDN, ARCH_SEDN, ARCH_LITE = range(6)
 F32, F16, U8, U16 = range(4)
-PREC_FP16, PREC_FP16X3, PREC_DEBUG_DIRECT, PREC_MIXED = range(4)
+PREC_FP16, PREC_FP16X3, PREC_DEBUG_DIRECT, PREC_MIXED, PREC_AUTO = range(5)
+ABI_VERSION = 2
 RESIZE_MODES = {'nearest': 0, 'bilinear': 1, 'bicubic': 2}
-PRECISIONS = {'fp16': PREC_FP16, 'fp16x3': PREC_FP16X3, 'debug_direct': PREC_DEBUG_DIRECT, 'mixed': PREC_MIXED}
+PRECISIONS = {'fp16': PREC_FP16, 'fp16x3': PREC_FP16X3, 'debug_direct': PREC_DEBUG_DIRECT, 'mixed': PREC_MIXED}       # ('auto' = PREC_AUTO is resolved by the library)
 
 _lib = None
 
@@ -46,6 +47,7 @@ def lib():
         'moe_net_param_info': (c_int, [c_vp, c_int, P(ctypes.c_char_p), P(c_i64), P(c_int)]),
         'moe_net_set_param': (c_int, [c_vp, ctypes.c_char_p, c_vp, P(c_i64), c_int]),
         'moe_net_finalize': (c_int, [c_vp, c_int, c_int]),
+        'moe_net_resolved_precision': (c_int, [c_vp, c_int]),
         'moe_net_workspace_bytes': (c_i64, [c_vp, c_int, c_int, c_int]),
         'moe_net_max_tile_pixels': (c_i64, [c_vp]),
         'moe_net_forward': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_int, c_vp, c_vp]),
@@ -77,14 +79,14 @@ def lib():
     for name, (res, args) in sig.items():
         fn = getattr(L, name)   # AttributeError here = header/library mismatch: fail loudly
         fn.restype, fn.argtypes = res, args
-    if L.moe_abi_version() != 1:
-        raise EngineError('libmoephoto_amd.so ABI version mismatch')
+    if L.moe_abi_version() != ABI_VERSION:
+        raise EngineError('libmoephoto_amd.so ABI version {} != {}: rebuild it (python -m moephoto_amd.build)'.format(L.moe_abi_version(), ABI_VERSION))
     _lib = L
     return L
 
 
 EXPORTS = ['moe_last_error', 'moe_abi_version', 'moe_device_count', 'moe_net_create', 'moe_net_destroy', 'moe_net_scale',
-           'moe_net_num_params', 'moe_net_param_info', 'moe_net_set_param', 'moe_net_finalize', 'moe_net_workspace_bytes',
+           'moe_net_num_params', 'moe_net_param_info', 'moe_net_set_param', 'moe_net_finalize', 'moe_net_resolved_precision', 'moe_net_workspace_bytes',
            'moe_net_max_tile_pixels', 'moe_net_forward', 'moe_net_set_profile', 'moe_net_get_profile', 'moe_net_get_profile_at', 'moe_net_set_exact_blocks', 'moe_net_set_debug', 'moe_net_set_option', 'moe_device_info', 'moe_stitch_dev', 'moe_net_debug_tap', 'moe_plan_create', 'moe_plan_destroy', 'moe_plan_info',
            'moe_plan_tiles', 'moe_plan_ramp', 'moe_plan_pool_elems', 'moe_plan_tile_offsets', 'moe_stitch', 'moe_run_plan',
            'moe_run_plan_ex', 'moe_run_plan_frames', 'moe_run_plan_tiles', 'moe_to_float', 'moe_to_output', 'moe_resize']

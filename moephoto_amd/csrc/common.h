@@ -140,7 +140,7 @@ struct TailAddArgs {
 };
 void launch_tailadd(const TailAddArgs& a, hipStream_t s);
 
-// One fused ARSB  y = x + conv_2(PReLU(conv_1(x)))  (arsb_fused.hip; conv_2's weights carry the ScaleLayer factor)
+// One fused ARSB  y = x + conv_2(PReLU(conv_1(x)))  (arsb32c.hip; conv_2's weights carry the ScaleLayer factor)
 struct ArsbArgs {
     const half_t* x_hi; const half_t* x_lo;   // stream in  [B][H][W][64] (x_lo: low part in units of 2^-11, or nullptr)
     half_t* y_hi; half_t* y_lo;               // stream out, NOT aliasing x (neighbouring patches read x's halo)
@@ -152,12 +152,8 @@ struct ArsbArgs {
     int cin;                                  // channels that carry data (0 = 64): arsb32c leaves the fourth k-slice out for the 48-channel nets
     unsigned long long* trace;                // -DARSB_TRACE builds only: s_memtime stamps [workgroup < 8][patch < 16][wave 4][slot 40]
 };
-bool launch_arsb_fused(ArsbArgs a, int max_groups, hipStream_t s);   // false: not applicable (caller runs the two convs)
-hipError_t arsb_fused_init();
-// second form (arsb32.hip): v_mfma_f32_32x32x16_f16, four waves in lock-step, both convs' weights resident; w1 / w2 in the conv3x3_sp fragment order (ConvLayer::w_hi)
-bool launch_arsb32(ArsbArgs a, int max_groups, hipStream_t s);
-hipError_t arsb32_init();
-// third form (arsb32c.hip): arsb32 with vertical continuation -- ten output rows per patch, the two last m rows of a patch stay in LDS for the patch below
+// arsb32c.hip: v_mfma_f32_32x32x16_f16, four waves in lock-step, both convs' weights resident (w1 / w2 in the pack_conv fragment order, ConvLayer::w_hi), ten output rows
+// per patch, the two last m rows of a patch stay in LDS for the patch below.  false: not applicable (the caller runs the two convs)
 bool launch_arsb32c(ArsbArgs a, int max_groups, hipStream_t s);
 hipError_t arsb32c_init();
 
@@ -190,12 +186,19 @@ hipError_t conv64_q8_init();
 // of the patches per plane P, so that the patch -> workgroup map (item % G with item = plane * P + k) -- and with it every slab's content and
 // summation order -- does not depend on how many planes share the launch.  (The SE / FRM gates feed fp16-rounded weights and multipliers: with
 // batch-dependent sums the last bit of a gate moved and SEDN's output with it by up to 5e-4; now a tile's result is independent of its launch set.)
+// P above max_groups with awkward factors (17 x 31 patches: largest divisor 31 of 256 CUs; a prime: 1) would collapse the launch onto a few CUs: pooled_groups_ok
+// tells the caller to leave the pooling to the separate pass (launch_pool_partial / sedn_xsum), which costs one read of the tensor instead of up to 10x the conv.
 inline int pooled_groups(long long P, long long items, int max_groups)
 {
     long long G = 1;
     if (P <= max_groups) G = P * (max_groups / P);
     else for (long long d = max_groups; d >= 1; --d) if (P % d == 0) { G = d; break; }
     return (int)(G < items ? G : items);
+}
+inline bool pooled_groups_ok(long long P, long long items, int max_groups)
+{
+    const long long full = items < max_groups ? items : max_groups;
+    return 2ll * pooled_groups(P, items, max_groups) >= full;      // at least half of the workgroups a plain launch would use
 }
 
 struct DirectConvArgs {

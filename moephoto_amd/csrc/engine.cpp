@@ -97,8 +97,8 @@ struct NetOptions {
     int x3_impl = 0;          // x3_impl     auto (0, default: q8 for the SR nets, x3 for the DN nets -- see forward) | x3 (1: conv64_x3.hip, three fp16 products) |
                               //             q8 (2: conv64_q8.hip, the two correction products on fp8 operands)
     int k48 = 1;              // k48         1 (default): kernels that can skip the zero k-slice of the 48-channel nets do | 0: they run all four (A/B)
-    int arsb_impl = 3;        // arsb_impl   v3 (3, default: arsb32c.hip, 32x32x16 MFMAs, waves in lock-step, vertical continuation: ten rows per patch, no recomputed
-                              //             m rows) | v2 (2: arsb32.hip, the same without continuation, eight rows per patch) | v1 (1: arsb_fused.hip, 16x16x32 MFMAs)
+                              // (arsb_impl: round 3 kept three generations of the one-launch ARSB side by side -- arsb_fused.hip, arsb32.hip, arsb32c.hip; only the last,
+                              // the default since, is built now: the earlier two are in the history at 689845f)
     bool fuse_tail = true;    // fuse_tail   last upsampler conv + 64->1 / 48->1 tail conv in one kernel
     bool sedn_fuse = true;    // sedn_fuse   SEDN's fused block tail
     bool pool_fuse = true;    // pool_fuse   SE / FRM channel sums out of the producing conv's epilogue
@@ -131,7 +131,7 @@ struct NetOptions {
         if (key == "lo8") { const int t = onoff(v); if (t < 0) return false; lo8 = t; return true; }
         if (key == "x3_impl") { const int t = tri(v, "auto", "x3", "q8", -1); if (t < 0) return false; x3_impl = t; return true; }
         if (key == "k48") { const int t = onoff(v); if (t < 0) return false; k48 = t; return true; }
-        if (key == "arsb_impl") { const int t = (v && !strcmp(v, "v3")) ? 3 : tri(v, nullptr, "v1", "v2", -1); if (t < 1) return false; arsb_impl = t; return true; }
+        if (key == "arsb_impl") return v && !strcmp(v, "v3");      // (accepted for old command lines: arsb32c.hip is the one form)
         if (key == "conv1x1") return flag(conv1x1);
         if (key == "x3_fuse") return flag(x3_fuse);
         if (key == "arsb_fuse") return flag(arsb_fuse);
@@ -147,11 +147,13 @@ struct NetOptions {
     void from_env()
     {
         static const char* const names[][2] = {{"MOE_CONV_IMPL", "conv_impl"}, {"MOE_SP_IMPL", "sp_impl"}, {"MOE_TAIL_SPLIT", "tail_split"}, {"MOE_TAIL_FORM", "tail_form"}, {"MOE_UP_IMPL", "up_impl"},
-                                               {"MOE_CONV1X1", "conv1x1"}, {"MOE_ARSB_IMPL", "arsb_impl"}, {"MOE_K48", "k48"}, {"MOE_X3_IMPL", "x3_impl"}, {"MOE_LO8", "lo8"}, {"MOE_X3_FUSE", "x3_fuse"}, {"MOE_ARSB_FUSE", "arsb_fuse"}, {"MOE_FUSE_TAIL", "fuse_tail"},
+                                               {"MOE_CONV1X1", "conv1x1"}, {"MOE_K48", "k48"}, {"MOE_X3_IMPL", "x3_impl"}, {"MOE_LO8", "lo8"}, {"MOE_X3_FUSE", "x3_fuse"}, {"MOE_ARSB_FUSE", "arsb_fuse"}, {"MOE_FUSE_TAIL", "fuse_tail"},
                                                {"MOE_SEDN_FUSE", "sedn_fuse"}, {"MOE_POOL_FUSE", "pool_fuse"}, {"MOE_DBG", "dbg"}, {"MOE_TRACE_KEY", "trace_key"},
                                                {"MOE_TILES_PER_BATCH", "tiles_per_batch"}, {"MOE_MAX_GROUPS", "max_groups"}};
         for (const auto& nv : names)
-            if (const char* e = getenv(nv[0])) (void)set(nv[1], e);
+            if (const char* e = getenv(nv[0]))
+                if (!set(nv[1], e)) fprintf(stderr, "moephoto_amd: %s=\"%s\" is not a value of option %s -- ignored\n", nv[0], e, nv[1]);      // (a typo in an A/B run must not pass silently)
+        if (getenv("MOE_ARSB_IMPL") && strcmp(getenv("MOE_ARSB_IMPL"), "v3")) fprintf(stderr, "moephoto_amd: MOE_ARSB_IMPL: only v3 (arsb32c.hip) is built since round 4 -- ignored\n");
         if (const char* e = getenv("MOE_EXACT_BLOCKS")) exact_blocks_env = atoi(e);
         arsb_trace = getenv("MOE_ARSB_TRACE") != nullptr;
     }
@@ -746,7 +748,7 @@ struct Fwd {
         a.tail_w = tail_w; a.tplanes = tplanes; a.tail_form = tplanes ? tail_form : 0;
         a.tail_split = (tplanes && mixed && tail_split_for(key)) ? 1 : 0;
         a.tail1_w = tail1_w; a.tail1_out = tail1_out;
-        if (pool_out && !x3 && L.r == 1 && L.nchunks == 1 && !res) {      // conv3x3_rw's pooled epilogue (SEDN rblock.2)
+        if (pool_out && !x3 && L.r == 1 && L.nchunks == 1 && !res && pooled_groups_ok((long long)a.px * a.py, items, n.max_groups)) {      // conv3x3_rw's pooled epilogue (SEDN rblock.2)
             a.pool = pool_out; a.pool_slabs = pool_slabs;
             a.G = pooled_groups((long long)a.px * a.py, items, n.max_groups);      // slab contents independent of the launch's plane count (common.h)
         }
@@ -834,7 +836,10 @@ struct Fwd {
                 q.res_hi = res ? res->hi : nullptr; q.res_lo = res ? res->lo : nullptr;
                 q.w_hi = blob<half_t>(L.w_arsb); q.w_lo = blob<half_t>(L.w_arsb_lo); q.zero = small<half_t>("zero");
                 q.slope = L.slope; q.B = B; q.H = H; q.W = W;
-                if (pool_out && !res && L.slope == 1.f) { q.pool = pool_out; q.pool_slabs = pool_slabs; }
+                if (pool_out && !res && L.slope == 1.f && pooled_groups_ok((long long)((W + kTileW - 1) / kTileW) * ((H + kTileH - 1) / kTileH),
+                                                                            (long long)B * ((W + kTileW - 1) / kTileW) * ((H + kTileH - 1) / kTileH), n.max_groups)) {
+                    q.pool = pool_out; q.pool_slabs = pool_slabs;      // (conv64_x3's patches are 8 x 32 outputs, as the launcher counts them)
+                }
                 const int rec = prof_begin(key, 3 * 2.0 * (double)B * H * W * L.cout * L.cin * L.taps);
                 bool ok = false;
                 // The two correction products on fp8 operands (conv64_q8.hip): 'mixed' only -- 'fp16x3' promises 2e-5, fp8 corrections deliver ~15 bits.
@@ -1017,7 +1022,7 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         f.tap("stem", A, h, w, 64, n.C);
         if (int rc = trunk_conv("input2", A, Bb, nullptr, mixed)) return rc;
         f.tap("input2", Bb, h, w, 64, n.C);
-        // single-pass ARSBs run as ONE kernel (arsb_fused.hip: conv_1's output never leaves the CU) that streams cur -> oth;
+        // single-pass ARSBs run as ONE kernel (arsb32c.hip: conv_1's output never leaves the CU) that streams cur -> oth;
         // split-operand / debug blocks use the two-launch form, conv_1 into `oth`, conv_2 back onto `cur`
         const bool arsb_fuse = n.opt.arsb_fuse && !f.x3 && !f.direct && n.opt.conv_impl == 2;
         Act cur = Bb, oth = Cc;
@@ -1037,14 +1042,12 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
                     const size_t tb = 8 * 16 * 4 * 40 * 8;
                     if (trace && i == 3 && hipMalloc((void**)&q.trace, tb) == hipSuccess) (void)hipMemsetAsync(q.trace, 0, tb, s);
                     const int rec = f.prof_begin("arsb" + std::to_string(i), 2.0 * 2.0 * (double)B * h * w * L1.cout * L1.cin * 9);
-                    if (n.opt.arsb_impl >= 2) {
+                    {
                         ArsbArgs q2 = q;
                         q2.w1 = f.blob<half_t>(L1.w_hi); q2.w2 = f.blob<half_t>(L2.w_hi);      // (pack_conv order; conv_2's carry the ScaleLayer factor as well)
                         q2.cin = (L1.cin == 48 && L2.cin == 48 && n.opt.k48) ? 48 : 64;      // NetDN: channels 48..63 are zeros in activations and weights
-                        done = n.opt.arsb_impl == 3 ? launch_arsb32c(q2, n.max_groups, s) : false;
-                        if (!done) done = launch_arsb32(q2, n.max_groups, s);
+                        done = launch_arsb32c(q2, n.max_groups, s);      // (false: the shape does not fit its 32-bit offsets -- the two-launch form below)
                     }
-                    if (!done) done = launch_arsb_fused(q, n.max_groups, s);
                     f.prof_end(rec);
                     if (q.trace) {
                         std::vector<unsigned long long> host(tb / 8);
@@ -1531,9 +1534,29 @@ int moe_net_set_param(moe_net* n, const char* name, const float* data, const int
     return MOE_OK;
 }
 
+// MOE_PREC_AUTO: the arithmetic that holds the product's tolerance (1e-3 max-abs against the reference's fp32 CPU path, on natural images and on white
+// noise) for the family -- the per-family policy lives HERE, behind the C ABI, so that the one-line stub of INTEGRATION.md works for every plugin-table key
+static int resolve_precision(int arch, int precision)
+{
+    if (precision != MOE_PREC_AUTO) return precision;
+    switch (arch) {
+        case MOE_ARCH_SEDN: return MOE_PREC_FP16;       // l15 / l25 / l50: 4-6e-4 in plain fp16
+        case MOE_ARCH_LITE: return MOE_PREC_FP16X3;     // lite2 / 4 / 8: every conv but one would have to be split anyway
+        default: return MOE_PREC_MIXED;                 // Net2x / 3x / 4x, NetDN
+    }
+}
+
+int moe_net_resolved_precision(const moe_net* n, int precision)
+{
+    if (!n) return fail(MOE_EINVAL, "moe_net_resolved_precision: NULL net");
+    if (precision < MOE_PREC_FP16 || precision > MOE_PREC_AUTO) return fail(MOE_EINVAL, "moe_net_resolved_precision: unknown precision %d", precision);
+    return resolve_precision(n->arch, precision);
+}
+
 int moe_net_finalize(moe_net* n, int device, int precision)
 {
     if (!n) return fail(MOE_EINVAL, "moe_net_finalize: NULL net");
+    if (precision == MOE_PREC_AUTO) precision = resolve_precision(n->arch, precision);
     if (precision != MOE_PREC_FP16 && precision != MOE_PREC_FP16X3 && precision != MOE_PREC_DEBUG_DIRECT && precision != MOE_PREC_MIXED)
         return fail(MOE_EINVAL, "moe_net_finalize: unknown precision %d", precision);
     if (precision == MOE_PREC_MIXED && (n->arch == MOE_ARCH_SEDN || n->arch == MOE_ARCH_LITE))
@@ -1570,9 +1593,10 @@ int moe_net_forward(moe_net* n, const void* x, int x_dtype, int B, int h, int w,
     hipStream_t s = (hipStream_t)stream;
     long long* xo = nullptr;
     long long* yo = nullptr;
+    moe_net::OffSlot* slot = nullptr;
     if (x_off || y_off) {
         // The host tables ride to the device on the launch stream: a slot of a small ring (pinned host copy + device copy) per call,
-        // reused once the event recorded behind its copy has fired -- no hipMalloc, no blocking copy, no stream synchronisation.
+        // reused once the event recorded behind the forward that reads it has fired -- no hipMalloc, no blocking copy, no stream synchronisation.
         HIP_TRY(hipSetDevice(n->device >= 0 ? n->device : 0));
         moe_net::OffSlot& sl = n->off_ring[n->off_next];
         n->off_next = (n->off_next + 1) % 4;
@@ -1590,14 +1614,18 @@ int moe_net_forward(moe_net* n, const void* x, int x_dtype, int B, int h, int w,
         if (!sl.done) HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         for (int i = 0; i < B; ++i) { sl.host[i] = x_off ? x_off[i] : 0; sl.host[B + i] = y_off ? y_off[i] : 0; }
         HIP_TRY(hipMemcpyAsync(sl.dev, sl.host, need * 8, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipEventRecord(sl.done, s));
         sl.used = true;
+        slot = &sl;
         if (x_off) xo = sl.dev;
         if (y_off) yo = sl.dev + B;
     }
     bool mult8 = true;
     if (y_off) for (int i = 0; i < B; ++i) mult8 = mult8 && (y_off[i] % 8 == 0);
-    return forward_dev(*n, x, x_dtype, B, h, w, sB, sH, sW, xo, y, y_dtype, yo, s, mult8);
+    const int rc = forward_dev(*n, x, x_dtype, B, h, w, sB, sH, sW, xo, y, y_dtype, yo, s, mult8);
+    // the slot's event covers the copy AND every kernel of this forward that reads the tables: recorded behind them, on their stream, so that a later call on
+    // ANOTHER stream cannot overwrite the tables while this forward is still in flight (the host wait above is on this event)
+    if (slot && hipEventRecord(slot->done, s) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(s); }
+    return rc;
 }
 
 int moe_net_set_option(moe_net* n, const char* key, const char* value)

@@ -150,6 +150,9 @@ def broadcast_state_dict(sd, src=0, device=None, group=None):
     return out
 
 
+DIST_PLAN_CACHE = 8
+
+
 def _agreed_plan(opt, shape, group, device):
     """One tile plan for all ranks.  With an explicit cropsize the plan is a pure function of the shape; with cropsize
     'auto' it depends on free memory, which differs between ranks -- the MINIMUM over the ranks is used so that every rank
@@ -158,9 +161,14 @@ def _agreed_plan(opt, shape, group, device):
     from .imageProcess import EngineModule, prepare
     key = ('dist',) + tuple(int(v) for v in shape[-3:])
     plans = opt.__dict__.setdefault('_dist_plans', {})      # kept apart from doCrop's LRU of plans (imageProcess._plan_for): an evicted plan
-    plan = plans.get(key)                                   # on ONE rank would leave that rank alone in the collectives below
+    plan = plans.pop(key, None)                             # on ONE rank would leave that rank alone in the collectives below
     if plan is not None:
+        plans[key] = plan                                   # (re-inserted last = most recently used)
         return plan
+    # bounded like PLAN_CACHE: every rank runs the same sequence of shapes (SPMD), so every rank evicts the same entry at the same call and the
+    # re-planning collective below stays matched; a plan owns its device tables, varied frame shapes must not accumulate them
+    while len(plans) >= DIST_PLAN_CACHE:
+        plans.pop(next(iter(plans)))
     free = config.calcFreeMem()
     if dist.get_world_size(group) > 1:
         t = torch.tensor([float(free)], dtype=torch.float64, device=device if dist.get_backend(group) != 'gloo' else None)

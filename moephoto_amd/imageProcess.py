@@ -215,6 +215,13 @@ def _plan_for(opt, shape):
             return prepare(key, freeMem, opt, opt.padding, opt.scale, opt.align, opt.cropsize)
         try:
             it, padImage, unpad, outShape, bl = plan_with(False)
+            # 'auto' tile size: memory torch has reserved but not handed out is invisible to hipMemGetInfo and unusable by the engine (hipMalloc).  The
+            # reference counts it as free (python/config.py:61-71); here it is RELEASED when it is a large share of what is free -- otherwise the planner
+            # would silently settle for smaller tiles while gigabytes sit in torch's cache (once per re-plan, i.e. every 29 calls at most)
+            if opt.cropsize <= 0:
+                slack = torch.cuda.memory_reserved(config.deviceId) - torch.cuda.memory_allocated(config.deviceId)
+                if slack > (1 << 30) and slack > 0.1 * max(1, config.getFreeMem()):
+                    it, padImage, unpad, outShape, bl = plan_with(True)
         except MemoryError:          # the smallest tile did not fit: hand torch's cached blocks back to the driver and ask again, once
             it, padImage, unpad, outShape, bl = plan_with(True)
         ent = [it.plan, 0]

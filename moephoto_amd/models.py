@@ -159,10 +159,11 @@ class EngineModule(object):
         return self
 
     def resolved_precision(self):
-        if self.precision == 'auto':
-            return {_lib.ARCH_LITE: 'fp16x3', _lib.ARCH_SEDN: 'fp16'}.get(self.ARCH, 'mixed')
-        if self.precision == 'mixed' and self.ARCH in (_lib.ARCH_LITE, _lib.ARCH_SEDN):
-            return 'fp16x3' if self.ARCH == _lib.ARCH_LITE else 'fp16'       # 'mixed' is defined for the ARSB nets only
+        """The arithmetic 'auto' (or 'mixed' on a family without such a recipe) resolves to.  The per-family policy lives behind the C ABI
+        (MOE_PREC_AUTO, moe_net_resolved_precision): this is only its name."""
+        names = {v: k for k, v in _lib.PRECISIONS.items()}
+        if self.precision == 'auto' or (self.precision == 'mixed' and self.ARCH in (_lib.ARCH_LITE, _lib.ARCH_SEDN)):
+            return names[_lib.check(_lib.lib().moe_net_resolved_precision(self._h, _lib.PREC_AUTO))]
         return self.precision
 
     def max_tile_pixels(self):
@@ -185,7 +186,8 @@ class EngineModule(object):
         if self._finalized_key == key:
             return
         _lib.require_device()
-        _lib.check(_lib.lib().moe_net_finalize(self._h, self._device.index, _lib.PRECISIONS[self.resolved_precision()]))
+        prec = _lib.PREC_AUTO if self.precision == 'auto' else _lib.PRECISIONS[self.resolved_precision()]
+        _lib.check(_lib.lib().moe_net_finalize(self._h, self._device.index, prec))
         self._finalized_key = key
 
     # ---- forward -------------------------------------------------------------------------------------

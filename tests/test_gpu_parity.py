@@ -660,10 +660,9 @@ def test_rccl_path_world1(dev):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('impl', ['v1', 'v2', 'v3'])
-def test_fused_arsb_matches_two_launch_form(impl, dev):
-    """impl v1 = arsb_fused.hip (16x16x32 MFMAs, wave = 16 channels), v2 = arsb32.hip (32x32x16 MFMAs, waves in lock-step), v3 = arsb32c.hip (v2 with
-    vertical continuation: ten rows per patch, a workgroup walks a column of patches and keeps the last two m rows for the patch below).
+def test_fused_arsb_matches_two_launch_form(dev):
+    """arsb32c.hip (32x32x16 MFMAs, waves in lock-step, vertical continuation: ten rows per patch, a workgroup walks a column of patches and keeps the last
+    two m rows for the patch below; the earlier forms arsb_fused.hip / arsb32.hip were retired in round 4).
     The fused ARSB kernel (conv_1 -> PReLU -> conv_2 -> + x in one launch, weights in registers) against the two-launch form of
     the same arithmetic (option arsb_fuse = 0) and the oracle: ragged shapes (patches are 8 x 30 outputs), 48- and 64-channel nets,
     with and without the hi+lo stream."""
@@ -680,7 +679,6 @@ def test_fused_arsb_matches_two_launch_form(impl, dev):
                 for prec, nb in (('fp16', -1), ('mixed', 0), ('mixed', -1)):
                     m = module_for(key, prec).set_exact_blocks(nb)
                     touched.append(m)
-                    m.set_option('arsb_impl', impl)
                     y0 = m.set_option('arsb_fuse', 0)(xd)[-1].cpu().numpy()
                     y1 = m.set_option('arsb_fuse', 1)(xd)[-1].cpu().numpy()
                     m.set_exact_blocks(-1)
@@ -697,7 +695,7 @@ def test_fused_arsb_matches_two_launch_form(impl, dev):
                             assert np.abs(y - want).max() <= (1e-2 if prec == 'fp16' else 2e-3), (key, shape, prec, nb, float(np.abs(y - want).max()))
                     if prec == 'mixed' and nb == -1:
                         assert np.abs(y1 - want).max() <= TOL, (key, shape, kind, float(np.abs(y1 - want).max()))
-                    if arch == 'netdn' and impl == 'v3':      # the 48-channel nets leave the all-zero fourth k-slice out: not a bit may change
+                    if arch == 'netdn':      # the 48-channel nets leave the all-zero fourth k-slice out: not a bit may change
                         y3 = m.set_exact_blocks(nb).set_option('k48', 0)(xd)[-1].cpu().numpy()
                         m.set_option('k48', 1).set_exact_blocks(-1)
                         assert np.array_equal(y3, y1), (key, shape, prec, nb, float(np.abs(y3 - y1).max()))
@@ -709,7 +707,7 @@ def test_fused_arsb_matches_two_launch_form(impl, dev):
                         assert np.array_equal(y2, y1), (key, shape, prec, nb, float(np.abs(y2 - y1).max()))
     finally:
         for m in touched:
-            m.set_option('arsb_fuse', 1).set_option('arsb_impl', 'v3').set_option('max_groups', 0).set_option('k48', 1).set_exact_blocks(-1)
+            m.set_option('arsb_fuse', 1).set_option('max_groups', 0).set_option('k48', 1).set_exact_blocks(-1)
 
 
 @pytest.mark.parametrize('key', ['a2', 'a4', 'dn_lite5'])
@@ -866,11 +864,13 @@ def test_kernel_forms_agree(dev):
         want = onets.forward(arch, sd, x).numpy()
         xd = torch.from_numpy(x).to(dev)
         m = module_for(key, prec)
-        ys = {impl: with_opt(m, 'sp_impl', impl, 'auto') for impl in ('auto', 'sp', 'rw')}
-        # the fused tail's two output forms: nine tap planes per phase (conv3x3_sp + tapsum2/3) vs phase-class sums + aprons (conv3x3_rw + tapsum4, x2 stages)
+        ys = {'ps4': m.set_option('up_impl', 'ps4')(xd)[-1].cpu().numpy()}      # the default: conv3x3_ps4.hip for every x2 upsampler stage (x3 nets: the forms below)
+        m.set_option('up_impl', 'rw')                                           # ... and round 3's per-phase kernels behind it
+        ys.update({impl: with_opt(m, 'sp_impl', impl, 'auto') for impl in ('auto', 'sp', 'rw')})
+        # the fused tail's per-phase output forms: nine tap planes per phase (conv3x3_sp + tapsum2/3) vs phase-class sums + aprons (conv3x3_rw + tapsum4, x2 stages)
         ys['planes'] = with_opt(m, 'tail_form', 'planes', 'sums')
         ys['planes+sp'] = with_opt(m.set_option('tail_form', 'planes'), 'sp_impl', 'sp', 'auto')
-        m.set_option('tail_form', 'sums')
+        m.set_option('tail_form', 'sums').set_option('up_impl', 'ps4')
         for impl, y in ys.items():
             assert np.abs(y - ys['sp']).max() <= 2.5e-4, (key, shape, prec, impl, float(np.abs(y - ys['sp']).max()))
             if prec == 'mixed':
@@ -986,3 +986,34 @@ def test_upconv_all_phases_in_one_workgroup_vs_per_phase_form(key, dev):
         assert np.abs(y16 - y32).max() <= HALF_OUT * max(1.0, float(np.abs(y32).max()) / 2), (key, float(np.abs(y16 - y32).max()))
     finally:
         m.set_option('up_impl', 'ps4').set_option('max_groups', 0)
+
+
+def test_integration_md_stub_drives_every_family(dev):
+    """INTEGRATION.md section 1 is the binding a MoePhoto maintainer would add (a ctypes stub over include/moephoto_amd.h).  This test EXECUTES that text --
+    the first python block of the file, with the library path filled in -- and drives one SR key, one NetDN key, one SEDN key and one lite key through the
+    reference's initModel sequence (python/imageProcess.py:319-334: ctor(); load_state_dict; requires_grad_; eval; .to(dtype, device)) and Option.__call__
+    against the reference-generated goldens.  The stub passes MOE_PREC_AUTO: the per-family precision policy is the library's, not the caller's."""
+    import re
+    from moephoto_amd import _lib
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'INTEGRATION.md')).read()
+    code = re.search(r'```python\n(.*?)```', text, re.S).group(1)
+    assert 'moe_net_finalize' in code and 'class SEDN' in code
+    code = code.replace("'libmoephoto_amd.so'", repr(_lib.LIB_PATH))
+    ns = {}
+    exec(compile(code, 'INTEGRATION.md', 'exec'), ns)
+    cases = [('a2', lambda: ns['Net2x']()), ('dn_lite5', lambda: ns['NetDN']()), ('l25', lambda: ns['SEDN']()), ('lite2', lambda: ns['Net'](2))]
+    for key, ctor in cases:
+        z = np.load(os.path.join(G, 'nets', key + '.npz'))
+        h, w = [int(v) for v in z['hw']]
+        seed = int(z['seed'])
+        m = ctor()
+        m.load_state_dict({n: torch.from_numpy(v) for n, v in gd.state_dict_for(key, load_state_dict_file).items()})
+        for p in m.parameters():
+            p.requires_grad_(False)
+        m.eval()
+        m = m.to(dtype=torch.float32, device=dev)
+        for kind in ('natural', 'noise'):
+            x = gd.natural_image(seed, (3, h, w))[:, None] if kind == 'natural' else gd.noise_image(seed, (3, 1, h, w))
+            y = m(torch.from_numpy(x).to(dev))[-1].float().cpu().numpy()
+            err = np.abs(y - z['y_' + kind]).max()
+            assert err <= TOL, '{} {} through the INTEGRATION.md stub: {:.3e}'.format(key, kind, err)
