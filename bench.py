@@ -61,8 +61,8 @@ MFLOP_PER_PX_PLANE = 3.9456          # Net4x conv FLOPs per LR pixel per plane (
 PARITY_TOL = 1e-3
 # bracketed layer groups: (profile substring, label, algorithmic FLOPs per LR pixel and plane)
 GROUPS = [
-    ('convt_R1.up1', 'R-branch 3x3 64->256 @2x res (+bias +PixelShuffle(2) +PReLU, fused 64->1 tail as phase-class sums, split activations: conv3x3_rw EPI 7)', 4 * 2 * 256 * 64 * 9),
-    ('u.up1', 'U-branch 3x3 64->256 @2x res (+bias +PixelShuffle(2) +PReLU, fused 64->1 tail as phase-class sums: conv3x3_rw EPI 3)', 4 * 2 * 256 * 64 * 9),
+    ('convt_R1.up1', 'R-branch 3x3 64->256 @2x res (+bias +PixelShuffle(2) +PReLU, fused 64->1 tail with split activations; conv3x3_ps4_kernel<2>: four phases per workgroup, rows streamed down a column, one fp32 plane + column aprons out)', 4 * 2 * 256 * 64 * 9),
+    ('u.up1', 'U-branch 3x3 64->256 @2x res (+bias +PixelShuffle(2) +PReLU, fused 64->1 tail; conv3x3_ps4_kernel<1>)', 4 * 2 * 256 * 64 * 9),
     ('arsb', 'arsb32c_kernel (one ARSB per launch: two 3x3 64->64 convs @1x res + PReLU + hi/lo residual stream, 32x32x16 MFMAs, conv_1 rows kept in LDS down a patch column; 5 of 6 ARSBs)', 5 * 2 * 2 * 64 * 64 * 9),
 ]
 
@@ -98,7 +98,11 @@ def main():
     ap.add_argument('--cpu-tiles', type=int, default=9, help='tiles of the headline frame run through the CPU oracle (parity + baseline)')
     ap.add_argument('--no-noise-input', action='store_true', help='skip the second (uniform uint8 noise) input')
     ap.add_argument('--no-dropin-loop', action='store_true', help='skip the per-tile drop-in loop leg')
+    ap.add_argument('--config', type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json's configs[N-1]: 2 = the headline (default), 3 = 4K l25 -> a2 chain, "
+                    '4 = batch of 64 1080p frames, 5 = one 8K frame -> 32K with 512-px tiles (bench_extra.py)')
+    ap.add_argument('--no-extras', action='store_true', help='config 2: skip the roofline objects of the HBM-bound members and the I/O edges')
     args = ap.parse_args()
+    args.steps_given = any(a == '--steps' or a.startswith('--steps=') for a in sys.argv[1:])
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # started plainly: become the launcher (one rank per GPU, rendezvous on the loopback address); the ranks re-enter main()
@@ -106,6 +110,10 @@ def main():
                '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
         sys.stdout.flush()
         os.execv(sys.executable, cmd)
+
+    if args.config != 2:
+        import bench_extra
+        return bench_extra.run_config(args.config, args)
 
     import numpy as np
     import torch
@@ -194,7 +202,7 @@ def main():
     in_mp = nframes * FRAME[1] * FRAME[2] / 1e6
     for _ in range(args.warmup):
         step(frames)
-    model.set_profile(','.join([g[0] for g in GROUPS] + HBM_KEYS))      # hipEvent pairs on the launch stream around the launches of each group
+    model.set_profile(','.join([g[0] for g in GROUPS] + HBM_KEYS + ['tailadd']))      # hipEvent pairs on the launch stream around the launches of each group
     dt = timed(frames, args.steps)
     profs = model.get_profile(all_keys=True)
     model.set_profile(None)
@@ -266,6 +274,14 @@ def main():
             k['traffic_note'] = t.get('note', '')
             k['achieved_measured_bytes'] = round(t['hbm_bytes_per_frame'] * frames_timed / secs / 1e9, 1)      # the PMC passes' bytes over this run's time
         res['roofline_hbm'] = k
+
+    # ---- the HBM-bound members of the path and the I/O edges the headline excludes (bench_extra.py) --------------------------------------
+    if world == 1 and not args.no_extras:
+        import bench_extra
+        tp = profs[len(GROUPS) + len(HBM_KEYS)] if len(profs) > len(GROUPS) + len(HBM_KEYS) else None
+        res['roofline_hbm_kernels'] = bench_extra.hbm_members(torch, _lib, ip, gd, dev, opt, model, plan, frames[0], tp, frames_timed, args.tiles_per_batch, load_state_dict_file)
+        res['io_edges'] = bench_extra.io_edges(torch, _lib, dev)
+        config.crop_sr = CROP
 
     # ---- sustained leg (power-capped part: a 0.5 s burst flatters the clock), with the clock / power sampled beside it ------------
     if args.sustain > 0:

@@ -298,6 +298,49 @@ def test_config5_full_size_8k_to_32k(dev):
     assert rep['stitch_algorithmic_gb_per_s'] >= 3500, rep      # 5.1 TB/s measured (profiles/r03); VERDICT r02 asked for >= 4 TB/s, the margin is for slower boxes
 
 
+def test_config4_full_size_64_frames_over_8_owners(dev):
+    """BASELINE config 4 AS WRITTEN: a batch of 64 1080p frames, a4, 256-px tiles = 2560 (frame, tile) pairs dealt round-robin to 8 owners exactly as on
+    8 GPUs (moe_run_plan_frames: each owner computes its 320 tiles with cross-frame batching).  Two tiles of two different frames are held against the
+    ORACLE; every stitched frame must equal the frame-by-frame doCrop bit for bit (the reference runs the frames one after the other,
+    python/video.py:349-360: same arithmetic per tile, whatever shares its launch)."""
+    from moephoto_amd import _lib, imageProcess as ip
+    opt = _opt_sr('a', 4, 256, fp16_io=True)
+    NF = 64
+    base = [torch.from_numpy(gd.natural_image(80 + f, (3, 1080, 1920))) if f % 2 == 0 else torch.from_numpy(_frames('noise_u8', f, (3, 1080, 1920))) for f in range(8)]
+    frames = torch.stack([base[f % 8] for f in range(NF)]).to(dev).half()          # 64 frames resident in HBM: four natural, four uint8-noise images
+    plan = ip._plan_for(opt, frames[0].shape)
+    assert plan.n_tiles == 40
+    L, model = _lib.lib(), opt.modelCached
+    stream = torch.cuda.current_stream().cuda_stream
+    pe = plan.pool_elems(3)
+    sC, sH, sW = frames[0].stride()
+    pools = torch.zeros((NF, pe), dtype=torch.float32, device=dev)                  # 27 GB of fp32 tile results
+    t0 = time.perf_counter()
+    for i in range(8):
+        _lib.check(L.moe_run_plan_frames(model._h, plan._h, frames.data_ptr(), _lib.F16, frames.stride(0), sC, sH, sW, NF,
+                                         ctypes.c_void_p(pools.data_ptr()), pe, i, 8, 0, stream))
+    torch.cuda.synchronize()
+    t_owners = time.perf_counter() - t0
+    sd = gd.state_dict_for('a4', load_state_dict_file)
+    off = plan.tile_offsets(3)
+    worst = 0.0
+    for f, k in ((5, 9), (62, 39)):              # an interior tile of a noise frame, the ragged corner of a natural one
+        top, bottom, left, right = plan.tiles[k][:4]
+        x16 = frames[f].float().cpu().numpy()
+        want = onets.forward('net4x', sd, np.ascontiguousarray(x16[:, None, top:bottom, left:right])).numpy()[:, 0]
+        got = pools[f][off[k]:off[k] + want.size].view(want.shape).cpu().numpy()
+        err = float(np.abs(got - want).max())
+        worst = max(worst, err)
+        assert err <= TOL, (f, k, err)
+    y = torch.empty((3, plan.outH, plan.outW), dtype=torch.float16, device=dev)
+    for f in range(NF):
+        _lib.check(L.moe_stitch(plan._h, 0, pools[f].data_ptr(), None, 3, y.data_ptr(), _lib.F16, stream))
+        torch.cuda.synchronize()
+        assert torch.equal(y, ip.doCrop(opt, frames[f])), f
+    _report('config4_64_frames_8_owners', {'oracle_tiles_worst_max_abs': float('{:.3e}'.format(worst)), 'eight_owner_passes_s': round(t_owners, 3),
+                                           'input_mp_per_s_one_gpu_doing_all_owners': round(NF * 2.0736 / t_owners, 2)})
+
+
 # ---- multi-GPU path with real engine calls, ranks sharing this GPU -------------------------------------------------------------------
 def _free_port():
     s = socket.socket()
