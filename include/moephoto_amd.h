@@ -153,6 +153,9 @@ int moe_plan_info(const moe_plan* plan, int64_t info[12]);
 int moe_plan_tiles(const moe_plan* plan, int32_t* tiles);
 /* blend ramp b[k] = sigmoid(9*(k/padSc - .5)), k < padSc, fp32 */
 int moe_plan_ramp(const moe_plan* plan, float* ramp);
+/* per tile row i (moe_plan_info: step_h of them) four ints: first output row the tile row writes, first un-blended row S(i) ("solid"), output row of the
+ * tiles' own row 0, height of the tiles' output extent -- what the stitch kernel folds with (python/imageProcess.py:120-131,167-170) */
+int moe_plan_rows(const moe_plan* plan, int32_t* rows);
 
 /* ---- device-side stitch / whole-image run ------------------------------------------------------ */
 /* Fold the per-tile results into the canvas exactly as doCrop's sequential blend does.
@@ -166,6 +169,13 @@ int moe_stitch(const moe_plan* plan, int device, const float* tiles_dev, const i
  * moephoto_amd/dist.py keeps one device table per frame it stitches. */
 int moe_stitch_dev(const moe_plan* plan, int device, const float* tiles_dev, const int64_t* tile_off_dev, int C,
                    void* out, int out_dtype, void* stream);
+/* One ROW BAND of the canvas: the output rows [S(row0), S(row1)) (S(i) = first un-blended row of tile row i, moe_plan_rows; S(step_h) = out_h) folded
+ * from tile rows row0 .. row1 into out = (C, S(row1) - S(row0), out_w).  The band ends with the blend band of tile row row1 (when row1 < step_h);
+ * strip != 0: the entries of tile_off_dev for that tile row point at STRIPS -- the pad_sc rows [first, solid) of each plane, C planes of pad_sc x width --
+ * instead of whole tiles.  Lets the ranks of a single-frame job each fold their own band of the canvas (moephoto_amd/dist.py: band-sharded stitch;
+ * only those strips cross between neighbouring bands), bit-identical to the rows of moe_stitch's canvas. */
+int moe_stitch_band(const moe_plan* plan, int device, const float* tiles_dev, const int64_t* tile_off_dev, int C,
+                    void* out, int out_dtype, int row0, int row1, int strip, void* stream);
 /* doCrop on device: img = (C, Hp, Wp) planes (already padded per moe_plan_info's pad_*_to, see
  * python wrapper), element (c,i,j) at img + c*sC + i*sH + j*sW; out as in moe_stitch.
  * max_tiles_per_batch <= 0 picks a default. */

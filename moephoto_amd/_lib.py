@@ -59,12 +59,14 @@ def lib():
         'moe_net_set_option': (c_int, [c_vp, ctypes.c_char_p, ctypes.c_char_p]),
         'moe_device_info': (c_int, [c_int, P(c_i64)]),
         'moe_stitch_dev': (c_int, [c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_vp]),
+        'moe_stitch_band': (c_int, [c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp]),
         'moe_net_debug_tap': (c_i64, [c_vp, ctypes.c_char_p, c_vp, c_i64, P(c_i64), c_vp]),
         'moe_plan_create': (c_int, [P(c_i64), c_dbl, c_dbl, c_int, c_int, c_int, c_int, P(c_vp)]),
         'moe_plan_destroy': (None, [c_vp]),
         'moe_plan_info': (c_int, [c_vp, P(c_i64)]),
         'moe_plan_tiles': (c_int, [c_vp, P(ctypes.c_int32)]),
         'moe_plan_ramp': (c_int, [c_vp, P(ctypes.c_float)]),
+        'moe_plan_rows': (c_int, [c_vp, P(ctypes.c_int32)]),
         'moe_plan_pool_elems': (c_i64, [c_vp, c_int]),
         'moe_plan_tile_offsets': (c_int, [c_vp, c_int, P(c_i64)]),
         'moe_stitch': (c_int, [c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_vp]),
@@ -87,8 +89,8 @@ def lib():
 
 EXPORTS = ['moe_last_error', 'moe_abi_version', 'moe_device_count', 'moe_net_create', 'moe_net_destroy', 'moe_net_scale',
            'moe_net_num_params', 'moe_net_param_info', 'moe_net_set_param', 'moe_net_finalize', 'moe_net_resolved_precision', 'moe_net_workspace_bytes',
-           'moe_net_max_tile_pixels', 'moe_net_forward', 'moe_net_set_profile', 'moe_net_get_profile', 'moe_net_get_profile_at', 'moe_net_set_exact_blocks', 'moe_net_set_debug', 'moe_net_set_option', 'moe_device_info', 'moe_stitch_dev', 'moe_net_debug_tap', 'moe_plan_create', 'moe_plan_destroy', 'moe_plan_info',
-           'moe_plan_tiles', 'moe_plan_ramp', 'moe_plan_pool_elems', 'moe_plan_tile_offsets', 'moe_stitch', 'moe_run_plan',
+           'moe_net_max_tile_pixels', 'moe_net_forward', 'moe_net_set_profile', 'moe_net_get_profile', 'moe_net_get_profile_at', 'moe_net_set_exact_blocks', 'moe_net_set_debug', 'moe_net_set_option', 'moe_device_info', 'moe_stitch_dev', 'moe_stitch_band', 'moe_net_debug_tap', 'moe_plan_create', 'moe_plan_destroy', 'moe_plan_info',
+           'moe_plan_tiles', 'moe_plan_ramp', 'moe_plan_rows', 'moe_plan_pool_elems', 'moe_plan_tile_offsets', 'moe_stitch', 'moe_run_plan',
            'moe_run_plan_ex', 'moe_run_plan_frames', 'moe_run_plan_tiles', 'moe_to_float', 'moe_to_output', 'moe_resize']
 
 

@@ -309,6 +309,8 @@ struct StitchArgs {
     const float* ramp;                               // device [pad_sc]
     void* out; int out_dtype;
     int C, out_h, out_w, step_w;
+    int row_lo;                                      // first tile row the fold visits (0; a band: its first tile row)
+    int y0, rows;                                    // the canvas rows [y0, y0 + rows) are folded into `out` = (C, rows, out_w): the whole canvas (0, out_h) or a band (moe_stitch_band)
 };
 void launch_stitch(const StitchArgs& a, hipStream_t s);
 

@@ -1389,6 +1389,7 @@ static int plan_device_tables(const Plan& p, int device, int C, int64_t sC, int6
     }
     if (p.dev.size() >= 16) {   // bounded: drop the oldest layout
         if (p.dev.front()->blob) (void)hipFree(p.dev.front()->blob);
+        for (auto& e : p.dev.front()->strip_tabs) (void)hipFree(e.second);
         p.dev.erase(p.dev.begin());
     }
     p.dev.push_back(std::make_unique<PlanDeviceCache>());
@@ -1442,6 +1443,7 @@ static void fill_stitch(const Plan& p, const PlanDeviceCache& d, StitchArgs& a, 
     a.row_first = d.row_first; a.row_cnt = d.row_cnt; a.col_first = d.col_first; a.col_cnt = d.col_cnt;
     a.row_tab = d.row_tab; a.col_tab = d.col_tab; a.ramp = d.ramp;
     a.out = out; a.out_dtype = out_dtype; a.C = C; a.out_h = p.out_h; a.out_w = p.out_w; a.step_w = p.aw.step;
+    a.y0 = 0; a.rows = p.out_h; a.row_lo = 0;
 }
 
 // =====================================================================================================
@@ -1741,7 +1743,7 @@ int moe_plan_create(const int64_t shape[3], double ram, double ram_coef, int pad
 void moe_plan_destroy(moe_plan* p)
 {
     if (!p) return;
-    for (auto& d : p->p.dev) if (d->blob) (void)hipFree(d->blob);
+    for (auto& d : p->p.dev) { if (d->blob) (void)hipFree(d->blob); for (auto& e : d->strip_tabs) (void)hipFree(e.second); }
     for (auto& d : p->p.fdev) if (d->blob) (void)hipFree(d->blob);
     for (auto& c : p->p.custom_off) if (c.dev) (void)hipFree(c.dev);
     if (p->p.pool) (void)hipFree(p->p.pool);
@@ -1755,6 +1757,13 @@ int moe_plan_info(const moe_plan* p, int64_t info[12])
     const int64_t v[12] = {(int64_t)q.tiles.size(), q.ah.step, q.aw.step, q.out_h, q.out_w, q.pad_h_to, q.pad_w_to, q.pad_sc,
                            q.tile_h, q.tile_w, q.ah.clip, q.aw.clip};
     memcpy(info, v, sizeof v);
+    return MOE_OK;
+}
+
+int moe_plan_rows(const moe_plan* p, int32_t* rows)
+{
+    if (!p || !rows) return fail(MOE_EINVAL, "moe_plan_rows: NULL argument");
+    memcpy(rows, p->p.row_tab.data(), p->p.row_tab.size() * 4);
     return MOE_OK;
 }
 
@@ -1830,6 +1839,43 @@ int moe_stitch_dev(const moe_plan* p, int device, const float* tiles_dev, const 
     if (rc) return rc;
     StitchArgs a{};
     fill_stitch(p->p, *d, a, tiles_dev, (const long long*)tile_off_dev, C, out, out_dtype);
+    launch_stitch(a, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MOE_EHIP, "stitch launch failed: %s", hipGetErrorString(e));
+    return MOE_OK;
+}
+
+int moe_stitch_band(const moe_plan* p, int device, const float* tiles_dev, const int64_t* tile_off_dev, int C, void* out, int out_dtype,
+                    int row0, int row1, int strip, void* stream)
+{
+    if (!p || !tiles_dev || !tile_off_dev || !out || C < 1) return fail(MOE_EINVAL, "moe_stitch_band: bad argument");
+    const Plan& q = p->p;
+    const int nrow = q.ah.step;
+    if (row0 < 0 || row1 <= row0 || row1 > nrow) return fail(MOE_EINVAL, "moe_stitch_band: tile rows [%d, %d) of %d", row0, row1, nrow);
+    HIP_TRY(hipSetDevice(device));
+    PlanDeviceCache* d = nullptr;
+    int rc = plan_device_tables(q, device, C, 0, 0, 0, 0, 1, &d);
+    if (rc) return rc;
+    StitchArgs a{};
+    fill_stitch(q, *d, a, tiles_dev, (const long long*)tile_off_dev, C, out, out_dtype);
+    a.row_lo = row0;
+    a.y0 = q.row_tab[row0 * 4 + 1];                                  // S(row0): first un-blended row of the band's first tile row (0 for row 0)
+    a.rows = (row1 < nrow ? q.row_tab[row1 * 4 + 1] : q.out_h) - a.y0;
+    if (strip && row1 < nrow) {
+        // the band ends with the blend band of tile row row1, rows [first, solid): its tiles are present as STRIPS of exactly those pad_sc rows (C planes of
+        // pad_sc x width each): a row table in which that tile row starts at `first` and is pad_sc high addresses them
+        int* tab = nullptr;
+        for (auto& e : d->strip_tabs) if (e.first == row1) tab = e.second;
+        if (!tab) {
+            std::vector<int> rt(q.row_tab);
+            rt[row1 * 4 + 2] = rt[row1 * 4 + 0];
+            rt[row1 * 4 + 3] = rt[row1 * 4 + 1] - rt[row1 * 4 + 0];
+            HIP_TRY(hipMalloc((void**)&tab, rt.size() * 4));
+            HIP_TRY(hipMemcpy(tab, rt.data(), rt.size() * 4, hipMemcpyHostToDevice));
+            d->strip_tabs.push_back({row1, tab});
+        }
+        a.row_tab = tab;
+    }
     launch_stitch(a, (hipStream_t)stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MOE_EHIP, "stitch launch failed: %s", hipGetErrorString(e));

@@ -4,6 +4,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/moephoto_amd.h"
@@ -34,6 +35,7 @@ struct PlanDeviceCache {       // device-side tables of a plan for one (layout, 
     long long* tile_off = nullptr; // [n_tiles] raster order
     int *row_first = nullptr, *row_cnt = nullptr, *col_first = nullptr, *col_cnt = nullptr, *row_tab = nullptr, *col_tab = nullptr;
     float* ramp = nullptr;
+    std::vector<std::pair<int, int*>> strip_tabs;   // moe_stitch_band: row tables in which one tile row is present as the strip of its blend band
 };
 
 struct FramesDeviceCache {     // offset tables of one multi-frame sharded run (moe_run_plan_tiles), cached per layout

@@ -819,7 +819,7 @@ __device__ __forceinline__ float stitch_pixel(const StitchArgs& a, int X, int Y,
     const int i0 = a.row_first[Y], ni = a.row_cnt[Y];
     const int j0 = a.col_first[X], nj = a.col_cnt[X];
     float cur = 0.f;
-    for (int i = i0; i < i0 + ni; ++i) {
+    for (int i = max(i0, a.row_lo); i < i0 + ni; ++i) {      // (row_lo: a band starts at the solid part of its first tile row, which overwrites whatever the rows above wrote)
         const int fy = a.row_tab[i * 4 + 0], sy = a.row_tab[i * 4 + 1], oy = a.row_tab[i * 4 + 2], eh = a.row_tab[i * 4 + 3];
         for (int j = j0; j < j0 + nj; ++j) {
             const int fx = a.col_tab[j * 4 + 0], sx = a.col_tab[j * 4 + 1], ox = a.col_tab[j * 4 + 2], ew = a.col_tab[j * 4 + 3];
@@ -837,10 +837,10 @@ __device__ __forceinline__ float stitch_pixel(const StitchArgs& a, int X, int Y,
 __global__ __launch_bounds__(256) void stitch_kernel(StitchArgs a)
 {
     const int X = blockIdx.x * 256 + threadIdx.x;
-    const int Y = blockIdx.y, c = blockIdx.z;
+    const int Y = blockIdx.y + a.y0, c = blockIdx.z;
     if (X >= a.out_w) return;
     const float cur = stitch_pixel(a, X, Y, c);
-    const long long o = ((long long)c * a.out_h + Y) * a.out_w + X;
+    const long long o = ((long long)c * a.rows + (Y - a.y0)) * a.out_w + X;
     if (a.out_dtype == MOE_F16) ((half_t*)a.out)[o] = (half_t)cur;
     else ((float*)a.out)[o] = cur;
 }
@@ -851,7 +851,7 @@ __global__ __launch_bounds__(256) void stitch_kernel(StitchArgs a)
 __global__ __launch_bounds__(256) void stitch4_kernel(StitchArgs a)
 {
     const int X0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    const int Y = blockIdx.y, c = blockIdx.z;
+    const int Y = blockIdx.y + a.y0, c = blockIdx.z;
     if (X0 >= a.out_w) return;
     float v[4];
     const int i0 = a.row_first[Y], j0 = a.col_first[X0];
@@ -870,7 +870,7 @@ __global__ __launch_bounds__(256) void stitch4_kernel(StitchArgs a)
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = stitch_pixel(a, X0 + e, Y, c);
     }
-    const long long o = ((long long)c * a.out_h + Y) * a.out_w + X0;
+    const long long o = ((long long)c * a.rows + (Y - a.y0)) * a.out_w + X0;
     if (a.out_dtype == MOE_F16) {
         half4_t h;
 #pragma unroll
@@ -898,7 +898,8 @@ __global__ __launch_bounds__(256) void stitch8r_kernel(StitchArgs a)
     __shared__ int s_col[64 * 4];
     __shared__ int s_seam[256];
     __shared__ int s_nseam;
-    const int Y0 = blockIdx.y * R, c = blockIdx.z;
+    const int Y0 = blockIdx.y * R + a.y0, c = blockIdx.z;
+    const int yend = a.y0 + a.rows;                       // (a band of the canvas: moe_stitch_band; the whole canvas: y0 = 0, rows = out_h)
     const int nsw = a.step_w;
     for (int t = threadIdx.x; t < nsw * 4; t += 256) s_col[t] = a.col_tab[t];
     if (threadIdx.x == 0) s_nseam = 0;
@@ -914,10 +915,10 @@ __global__ __launch_bounds__(256) void stitch8r_kernel(StitchArgs a)
             float v[R][8];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const int Y = min(Y0 + r, a.out_h - 1);            // (rows past the canvas repeat the last one and are not stored)
+                const int Y = min(Y0 + r, yend - 1);               // (rows past the band repeat the last one and are not stored)
                 const int i0 = a.row_first[Y], ni = a.row_cnt[Y];  // block-uniform
                 float cur[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                for (int i = i0; i < i0 + ni; ++i) {
+                for (int i = max(i0, a.row_lo); i < i0 + ni; ++i) {
                     const int fy = a.row_tab[i * 4 + 0], sy = a.row_tab[i * 4 + 1], oy = a.row_tab[i * 4 + 2], eh = a.row_tab[i * 4 + 3];
                     const long long o = a.tile_off[i * nsw + j0] + ((long long)c * eh + (Y - oy)) * ew + (X0 - ox);
                     float q[8];
@@ -942,8 +943,8 @@ __global__ __launch_bounds__(256) void stitch8r_kernel(StitchArgs a)
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                if (Y0 + r >= a.out_h) break;
-                const long long o = ((long long)c * a.out_h + Y0 + r) * a.out_w + X0;
+                if (Y0 + r >= yend) break;
+                const long long o = ((long long)c * a.rows + (Y0 + r - a.y0)) * a.out_w + X0;
                 if (a.out_dtype == MOE_F16) {
                     half8_t h;
 #pragma unroll
@@ -964,9 +965,9 @@ __global__ __launch_bounds__(256) void stitch8r_kernel(StitchArgs a)
         const int gidx = t / (8 * R), rem = t - gidx * 8 * R;
         const int r = rem >> 3, e = rem & 7;
         const int X = (blockIdx.x * 256 + s_seam[gidx]) * 8 + e, Y = Y0 + r;
-        if (Y >= a.out_h) continue;
+        if (Y >= yend) continue;
         const float cur = stitch_pixel(a, X, Y, c);
-        const long long o = ((long long)c * a.out_h + Y) * a.out_w + X;
+        const long long o = ((long long)c * a.rows + (Y - a.y0)) * a.out_w + X;
         if (a.out_dtype == MOE_F16) ((half_t*)a.out)[o] = (half_t)cur;
         else ((float*)a.out)[o] = cur;
     }
@@ -1091,9 +1092,10 @@ void launch_frm(const FrmArgs& a, hipStream_t s)
 
 void launch_stitch(const StitchArgs& a, hipStream_t s)
 {
-    if (a.out_w % 8 == 0 && a.step_w <= 64 && ((uintptr_t)a.out & 15) == 0) hipLaunchKernelGGL(stitch8r_kernel<4>, dim3((a.out_w / 8 + 255) / 256, (a.out_h + 3) / 4, a.C), dim3(256), 0, s, a);
-    else if (a.out_w % 4 == 0 && ((uintptr_t)a.out & 15) == 0) hipLaunchKernelGGL(stitch4_kernel, dim3((a.out_w / 4 + 255) / 256, a.out_h, a.C), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(stitch_kernel, dim3((a.out_w + 255) / 256, a.out_h, a.C), dim3(256), 0, s, a);
+    if (a.rows <= 0) return;
+    if (a.out_w % 8 == 0 && a.step_w <= 64 && ((uintptr_t)a.out & 15) == 0) hipLaunchKernelGGL(stitch8r_kernel<4>, dim3((a.out_w / 8 + 255) / 256, (a.rows + 3) / 4, a.C), dim3(256), 0, s, a);
+    else if (a.out_w % 4 == 0 && ((uintptr_t)a.out & 15) == 0) hipLaunchKernelGGL(stitch4_kernel, dim3((a.out_w / 4 + 255) / 256, a.rows, a.C), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(stitch_kernel, dim3((a.out_w + 255) / 256, a.rows, a.C), dim3(256), 0, s, a);
 }
 
 void launch_to_float(const void* src, int src_dtype, float d, bool divide, int H, int W, int C, void* dst, int dst_dtype, hipStream_t s)

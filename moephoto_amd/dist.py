@@ -13,7 +13,13 @@ embarrassingly parallel decomposition with ONE exchange step:
               collective would be bound by one link)
   weights     broadcast once from rank 0 (flattened state dict)
 
-Nothing is copied around the collective.  `TileExchange` lays ONE device buffer out once per plan,
+  bands       fewer frames than ranks (config 5: ONE 8K frame, a 3.19-GB canvas): stitcher(f) = f % world would funnel every tile into one rank and
+              leave the others idle.  Then each frame's canvas is cut into `world` ROW BANDS along tile-row boundaries (band r = tile rows
+              [r n / world, (r+1) n / world), output rows [S(first), S(last + 1)) with S(i) = first un-blended row of tile row i): a tile goes to the rank
+              of its tile row, and only the pad_sc rows of the NEXT band's first tile row that are blended into this band's last rows travel twice
+              (as strips: ~1 % of the bytes).  Every rank folds its own band (moe_stitch_band) and keeps it: the canvas stays sharded.
+
+Nothing is copied around the collective (band mode: but the strips).  `TileExchange` lays ONE device buffer out once per plan,
 
     [ own | recv from rank 0 | recv from rank 1 | ... | send to rank 0 | send to rank 1 | ... ]
 
@@ -39,10 +45,16 @@ class TileExchange(object):
 
     tile_elems[k] = fp32 elements of tile k's result (all C planes)."""
 
-    def __init__(self, tile_elems, n_frames, rank, world, group=None):
+    def __init__(self, tile_elems, n_frames, rank, world, group=None, bands=None):
+        """bands: None (frame mode) or (step_w, rows, tile_dims, pad_sc) -- tile columns per tile row, the plan's row table (TilePlan.rows), per tile its
+        (C, height, width) in output pixels, the blend length -- for the band-sharded layout."""
         self.sizes = [int(v) for v in tile_elems]
         self.n_tiles, self.n_frames = len(self.sizes), int(n_frames)
         self.rank, self.world, self.group = int(rank), int(world), group
+        self.bands = bands is not None
+        if self.bands:
+            self._init_bands(*bands)
+            return
         r, W, nt = self.rank, self.world, self.n_tiles
         self.mine = [f for f in range(self.n_frames) if self.stitcher(f) == r]
         # where this rank WRITES its tiles (engine table) and where it READS the tiles of the frames it stitches
@@ -79,6 +91,98 @@ class TileExchange(object):
         self._stitch_c = {f: (ctypes.c_int64 * nt)(*v.tolist()) for f, v in self.stitch_off.items()}
         self._stitch_dev = None        # one device blob [len(mine)][n_tiles] of the tables above, uploaded on first use (stitch_tables)
 
+    # ---- band mode -------------------------------------------------------------------------------------
+    def band_rows(self, rank):
+        """tile rows [i0, i1) of rank's band"""
+        return (rank * self.step_h) // self.world, ((rank + 1) * self.step_h) // self.world
+
+    def _init_bands(self, step_w, rows, tile_dims, pad_sc):
+        r, W, nt = self.rank, self.world, self.n_tiles
+        self.step_w, self.step_h, self.rows_tab, self.pad_sc = int(step_w), nt // int(step_w), [tuple(int(v) for v in t) for t in rows], int(pad_sc)
+        self.dims = [tuple(int(v) for v in d) for d in tile_dims]
+        strip_elems = [d[0] * self.pad_sc * d[2] for d in self.dims]
+        i0, i1 = self.band_rows(r)
+        self.my_rows = (i0, i1)
+        self.mine = list(range(self.n_frames)) if i1 > i0 else []       # every rank with a non-empty band folds that band of EVERY frame
+
+        def wants(dst):
+            """(tile, is_strip) pairs of one frame that rank dst folds, in wire order"""
+            a, b = self.band_rows(dst)
+            if b <= a:
+                return []
+            out = [(k, False) for k in range(a * self.step_w, b * self.step_w)]
+            if b < self.step_h:
+                out += [(k, True) for k in range(b * self.step_w, (b + 1) * self.step_w)]
+            return out
+        self._wants = wants
+        whole_dst = lambda k: next(d for d in range(W) if self.band_rows(d)[0] <= k // self.step_w < self.band_rows(d)[1])
+        self.tile_dst = np.full((self.n_frames, nt), -1, np.int64)
+        self.stitch_off = {f: np.full(nt, 0, np.int64) for f in self.mine}      # (entries of tile rows outside the band are never read: moe_stitch_band)
+        self.strip_copies = []               # (src offset, C, th, tw, first row of the strip inside the tile, dst offset): done between compute and exchange
+        pos = 0
+        strip_row0 = lambda k: self.rows_tab[k // self.step_w][0] - self.rows_tab[k // self.step_w][2]       # first written row - row of the tile's row 0
+        # own region: tiles computed here and folded here (whole), then strips computed here and folded here
+        for f in range(self.n_frames):
+            for k, is_strip in wants(r):
+                if self.owner(f, k) != r:
+                    continue
+                if not is_strip:
+                    self.tile_dst[f, k] = self.stitch_off[f][k] = pos
+                    pos += self.sizes[k]
+        own_strips = []
+        for f in range(self.n_frames):
+            for k, is_strip in wants(r):
+                if is_strip and self.owner(f, k) == r:
+                    self.stitch_off[f][k] = pos
+                    own_strips.append((f, k, pos))
+                    pos += strip_elems[k]
+        self.own_elems = pos
+        self.recv_split = []
+        for src in range(W):
+            n0 = pos
+            if src != r:
+                for f in range(self.n_frames):
+                    for k, is_strip in wants(r):
+                        if self.owner(f, k) == src:
+                            self.stitch_off[f][k] = pos
+                            pos += strip_elems[k] if is_strip else self.sizes[k]
+            self.recv_split.append(pos - n0)
+        self.recv_elems = pos - self.own_elems
+        self.send_split = []
+        send_strips = []
+        for dst in range(W):
+            n0 = pos
+            if dst != r:
+                for f in range(self.n_frames):
+                    for k, is_strip in wants(dst):
+                        if self.owner(f, k) != r:
+                            continue
+                        if is_strip:
+                            send_strips.append((f, k, pos))
+                            pos += strip_elems[k]
+                        else:
+                            self.tile_dst[f, k] = pos
+                            pos += self.sizes[k]
+            self.send_split.append(pos - n0)
+        self.send_elems = pos - self.own_elems - self.recv_elems
+        # a tile this rank computed whose WHOLE destination is nobody's band cannot exist (every tile row belongs to one band); one whose whole copy
+        # goes elsewhere but whose strip is wanted: its whole copy sits in the send region, the strip is cut from there
+        for f, k, at in own_strips + send_strips:
+            src = int(self.tile_dst[f, k])
+            assert src >= 0
+            C, th, tw = self.dims[k]
+            self.strip_copies.append((src, C, th, tw, strip_row0(k), at))
+        self.total_elems = pos
+        assert all(self.tile_dst[f, k] >= 0 for f in range(self.n_frames) for k in range(nt) if self.owner(f, k) == r)
+        self._tile_dst_c = (ctypes.c_int64 * self.tile_dst.size)(*self.tile_dst.reshape(-1).tolist())
+        self._stitch_c = {f: (ctypes.c_int64 * nt)(*v.tolist()) for f, v in self.stitch_off.items()}
+        self._stitch_dev = None
+
+    def cut_strips(self, buf):
+        """band mode, between compute and exchange: the pad_sc rows of a tile that the band above blends into its last rows, copied next to the whole tile"""
+        for src, C, th, tw, r0, at in self.strip_copies:
+            buf[at:at + C * self.pad_sc * tw].view(C, self.pad_sc, tw).copy_(buf[src:src + C * th * tw].view(C, th, tw)[:, r0:r0 + self.pad_sc])
+
     def stitch_tables(self, device):
         """{frame: device pointer of its n_tiles int64 stitch offsets}: ONE upload per layout, whatever the number of frames
         this rank stitches (moe_stitch_dev reads the table in place)."""
@@ -104,7 +208,7 @@ class TileExchange(object):
     def signature(self):
         """Order-sensitive digest of everything the ranks must agree on (checked once per layout in run_frames)."""
         h = 1469598103934665603
-        for v in [self.n_tiles, self.n_frames, self.world] + self.sizes:
+        for v in [self.n_tiles, self.n_frames, self.world, int(self.bands)] + self.sizes:
             h = ((h ^ int(v)) * 1099511628211) % (1 << 61)
         return h
 
@@ -112,6 +216,8 @@ class TileExchange(object):
     def exchange(self, buf):
         """buf: 1-D fp32 tensor of total_elems holding this rank's tiles at tile_dst.  After the call the `own` + `recv`
         regions hold every tile of the frames this rank stitches (read them through stitch_off)."""
+        if self.bands:
+            self.cut_strips(buf)
         if self.world == 1 and not FORCE_COLLECTIVE:
             return self.mine
         a, b = self.own_elems, self.own_elems + self.recv_elems
@@ -182,10 +288,11 @@ def _agreed_plan(opt, shape, group, device):
     return it.plan
 
 
-def run_frames(opt, frames, group=None, out_dtype=None, max_tiles_per_batch=0):
+def run_frames(opt, frames, group=None, out_dtype=None, max_tiles_per_batch=0, bands=None):
     """Tile-parallel doCrop over a list of equally-shaped (C,H,W) frames that every rank holds
     (broadcast them first).  Returns {frame index: stitched (C, sc*H, sc*W) tensor} for the frames
-    this rank stitches."""
+    this rank stitches -- or, in band mode (bands=True; default when there are fewer frames than ranks), {frame index: (first output row, band tensor
+    (C, rows, sc*W))} for every frame: this rank's row band of the canvas, which stays sharded over the ranks (gather_bands concatenates them)."""
     from .imageProcess import _DT
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     model = opt.modelCached
@@ -193,14 +300,21 @@ def run_frames(opt, frames, group=None, out_dtype=None, max_tiles_per_batch=0):
     dev = x0.device
     plan = _agreed_plan(opt, x0.shape, group, dev)
     C = x0.shape[0]
+    if bands is None:
+        bands = world > 1 and len(frames) < world
+    bands = bool(bands) and plan.stepH >= 1
     cache = opt.__dict__.setdefault('_exchanges', {})
-    ck = (tuple(int(v) for v in x0.shape[-3:]), len(frames), rank, world, C)
+    ck = (tuple(int(v) for v in x0.shape[-3:]), len(frames), rank, world, C, bands)
     ent = cache.get(ck)
     if ent is not None and ent[0] is not plan:               # the entry owns its plan: a layout is only ever used with the plan it was built from
         ent = None
     if ent is None:
         off = plan.tile_offsets(C) + [plan.pool_elems(C)]
-        ex = TileExchange([off[k + 1] - off[k] for k in range(plan.n_tiles)], len(frames), rank, world, group)
+        bspec = None
+        if bands:
+            dims = [(C, (t[1] - t[0]) * plan.sc, (t[3] - t[2]) * plan.sc) for t in plan.tiles]
+            bspec = (plan.stepW, plan.rows, dims, plan.padSc)
+        ex = TileExchange([off[k + 1] - off[k] for k in range(plan.n_tiles)], len(frames), rank, world, group, bands=bspec)
         if world > 1:       # every rank must have derived the same layout
             sig = torch.tensor([ex.signature()], dtype=torch.int64, device=dev if dist.get_backend(group) != 'gloo' else None)
             lo, hi = sig.clone(), sig.clone()
@@ -235,8 +349,40 @@ def run_frames(opt, frames, group=None, out_dtype=None, max_tiles_per_batch=0):
     out = {}
     odt = out_dtype if out_dtype is not None else x0.dtype
     tables = ex.stitch_tables(dev)
+    if ex.bands:
+        i0, i1 = ex.my_rows
+        y0 = plan.rows[i0][1] if i1 > i0 else 0
+        y1 = (plan.rows[i1][1] if i1 < plan.stepH else plan.outH) if i1 > i0 else 0
+        for f in mine:
+            y = torch.empty((C, y1 - y0, plan.outW), dtype=odt, device=dev)
+            _lib.check(L.moe_stitch_band(plan._h, dev.index or 0, buf.data_ptr(), ctypes.c_void_p(tables[f]), C, y.data_ptr(), _DT[odt], i0, i1, 1, stream))
+            out[f] = (y0, y)
+        return out
     for f in mine:
         y = torch.empty((C, plan.outH, plan.outW), dtype=odt, device=dev)
         _lib.check(L.moe_stitch_dev(plan._h, dev.index or 0, buf.data_ptr(), ctypes.c_void_p(tables[f]), C, y.data_ptr(), _DT[odt], stream))
         out[f] = y
     return out
+
+
+def gather_bands(band, group=None):
+    """(first row, band tensor) of every rank -> the whole canvas on every rank (tests, or a caller that wants the image in one place after all;
+    the sharded bands are the product: a 32K canvas is 3.19 GB)."""
+    world = dist.get_world_size(group)
+    y0, y = band if band is not None else (0, None)
+    metas = [None] * world
+    dist.all_gather_object(metas, None if y is None else (int(y0), tuple(y.shape), str(y.dtype)), group=group)
+    parts = []
+    for r, m in enumerate(metas):
+        if m is None:
+            continue
+        t = y if r == dist.get_rank(group) else torch.empty(m[1], dtype=getattr(torch, m[2].split('.')[-1]), device=y.device if y is not None else None)
+        if dist.get_backend(group) == 'gloo' and t.is_cuda:
+            h = t.cpu()
+            dist.broadcast(h, src=r, group=group)
+            t = h.to(t.device)
+        else:
+            dist.broadcast(t, src=r, group=group)
+        parts.append((m[0], t))
+    parts.sort(key=lambda p: p[0])
+    return torch.cat([p[1] for p in parts], dim=-2)

@@ -67,6 +67,9 @@ class TilePlan(object):
         r = (ctypes.c_float * max(1, self.padSc))()
         _lib.check(L.moe_plan_ramp(self._h, r))
         self.ramp = np.array(r[:self.padSc], np.float32)
+        rt = (ctypes.c_int32 * (4 * self.stepH))()
+        _lib.check(L.moe_plan_rows(self._h, rt))
+        self.rows = [tuple(rt[i * 4:(i + 1) * 4]) for i in range(self.stepH)]      # (first written row, first un-blended row, row of the tiles' row 0, tiles' height) per tile row
         self.sc, self.pad, self.align = int(sc), int(pad), int(align)
 
     def __del__(self):

@@ -36,5 +36,17 @@ out2 = run_frames(opt, list(allf.unbind(0)), out_dtype=torch.float16)
 torch.cuda.synchronize()
 for f, y in out2.items():
     assert torch.equal(y, out[f]), f
+# band-sharded stitch: ONE frame, every rank folds its row band of the canvas; concatenated, the bands are doCrop's canvas bit for bit
+from moephoto_amd.dist import gather_bands  # noqa: E402
+for fr in (frames[1], torch.from_numpy(gd.natural_image(77, (3, 264, 136))).cuda().half()):      # (7 and 6 tile rows at crop 64)
+    bands = run_frames(opt, [fr], out_dtype=torch.float16)            # fewer frames than ranks: band mode by default
+    torch.cuda.synchronize()
+    assert sorted(bands) == [0] and isinstance(bands[0], tuple), bands
+    whole = gather_bands(bands[0])
+    want = ip.doCrop(opt, fr)
+    assert whole.shape == want.shape, (whole.shape, want.shape)
+    assert torch.equal(whole, want), float((whole.float() - want.float()).abs().max())
+    y0, yb = bands[0]
+    assert torch.equal(yb, want[:, y0:y0 + yb.shape[1]])
 dist.barrier()
 os.write(1, 'RANK {} OK frames {}\n'.format(rank, sorted(out)).encode())      # (one write: the ranks share the pipe)

@@ -51,6 +51,55 @@ for rep in range(2):                         # the layout is reused every step
         assert not any(np.isnan(t).any() for t in tiles)
         want = ostitch.fold_stitch([tile_value(f, k) for k in range(nt)], pl, sc)
         assert np.array_equal(ostitch.fold_stitch(tiles, pl, sc), want)
+# ---- band-sharded stitch (fewer frames than ranks): every rank folds its own row band of the ONE canvas -------------------------------
+rows_o = ostitch.axis_cover(pl.anchors_h, sc, pl.pad_sc, pl.out_shape[-2])          # (first written, first un-blended, origin) per tile row
+ext = [ (pl.tiles[i * pl.step_w][1] - pl.tiles[i * pl.step_w][0]) * sc for i in range(len(rows_o)) ]
+rows_tab = [(r_[0], r_[1], r_[2], e) for r_, e in zip(rows_o, ext)]
+dims = [(C, (t[1] - t[0]) * sc, (t[3] - t[2]) * sc) for t in pl.tiles]
+for nf in (1, 2):
+    exb = TileExchange(sizes, nf, rank, world, bands=(pl.step_w, rows_tab, dims, pl.pad_sc))
+    sigs = [None] * world
+    dist.all_gather_object(sigs, exb.signature())
+    assert len(set(sigs)) == 1
+    assert exb.own_elems + exb.recv_elems + exb.send_elems == exb.total_elems
+    bufb = torch.full((exb.total_elems,), float('nan'))
+    for f in range(nf):                      # the engine writes every owned tile ONCE, at tile_dst
+        for k in exb.tiles_of(f, rank):
+            at = int(exb.tile_dst[f, k])
+            assert at >= 0
+            bufb[at:at + sizes[k]] = torch.from_numpy(tile_value(f, k).reshape(-1))
+    mine = exb.exchange(bufb)
+    i0, i1 = exb.my_rows
+    nrow = len(rows_tab)
+    assert (i0, i1) == ((rank * nrow) // world, ((rank + 1) * nrow) // world)
+    if i1 <= i0:
+        assert mine == []
+    else:
+        assert mine == list(range(nf))
+        y0, y1 = rows_tab[i0][1], (rows_tab[i1][1] if i1 < nrow else pl.out_shape[-2])
+        for f in mine:                       # what moe_stitch_band does: whole tiles of the band's tile rows, the strip of the next tile row, nothing else
+            tiles = []
+            for k in range(nt):
+                i = k // pl.step_w
+                Cc, th, tw = dims[k]
+                t = np.full((Cc, th, tw), np.nan, np.float32)
+                at = int(exb.stitch_off[f][k])
+                if i0 <= i < i1:
+                    t = bufb[at:at + sizes[k]].numpy().reshape(Cc, th, tw)
+                    assert np.array_equal(t, tile_value(f, k))
+                elif i == i1:
+                    r0 = rows_tab[i][0] - rows_tab[i][2]
+                    strip = bufb[at:at + Cc * pl.pad_sc * tw].numpy().reshape(Cc, pl.pad_sc, tw)
+                    assert np.array_equal(strip, tile_value(f, k)[:, r0:r0 + pl.pad_sc])
+                    t[:, r0:r0 + pl.pad_sc] = strip
+                tiles.append(t)
+            want = ostitch.fold_stitch([tile_value(f, k) for k in range(nt)], pl, sc)
+            with np.errstate(invalid='ignore'):
+                got = ostitch.fold_stitch(tiles, pl, sc)
+            assert np.array_equal(got[:, y0:y1], want[:, y0:y1]), (rank, f, y0, y1)      # the band's rows need nothing but its own tiles and that strip
+    total = [None] * world
+    dist.all_gather_object(total, (i0, i1))
+    assert sorted(set(v for a, b in total for v in range(a, b))) == list(range(nrow))  # the bands tile the canvas
 sd = OrderedDict([('a.weight', torch.arange(12.).reshape(3, 4)), ('b', torch.tensor([2.5]))]) if rank == 0 else None
 out = broadcast_state_dict(sd, src=0)
 assert list(out.keys()) == ['a.weight', 'b'] and out['a.weight'].shape == (3, 4) and float(out['b']) == 2.5

@@ -1017,3 +1017,48 @@ def test_integration_md_stub_drives_every_family(dev):
             y = m(torch.from_numpy(x).to(dev))[-1].float().cpu().numpy()
             err = np.abs(y - z['y_' + kind]).max()
             assert err <= TOL, '{} {} through the INTEGRATION.md stub: {:.3e}'.format(key, kind, err)
+
+
+def test_stitch_band_equals_rows_of_the_canvas(dev):
+    """moe_stitch_band: the canvas in row bands along tile-row boundaries (dist.py's band-sharded stitch for jobs with fewer frames than ranks).  Every band,
+    from whole tiles (strip = 0) and with the next tile row present only as the strips of its blend band (strip = 1: C planes of pad_sc rows, cut here the way
+    dist.TileExchange.cut_strips does), must equal the same rows of moe_stitch's canvas bit for bit -- including the re-anchored last tile row."""
+    import ctypes
+    from moephoto_amd import _lib, imageProcess as ip
+    for (H, W, crop, scale, model) in ((150, 200, 64, 4, 'a'), (293, 120, 96, 2, 'a')):
+        opt = _opt_sr(model, scale, crop, fp16_io=True)
+        xd = torch.from_numpy(gd.natural_image(3, (3, H, W))).to(dev).half()
+        plan = ip._plan_for(opt, xd.shape)
+        L = _lib.lib()
+        stream = torch.cuda.current_stream().cuda_stream
+        pool = torch.empty(plan.pool_elems(3), dtype=torch.float32, device=dev)
+        canvas = torch.empty((3, plan.outH, plan.outW), dtype=torch.float16, device=dev)
+        sC, sH, sW = xd.stride()
+        _lib.check(L.moe_run_plan_ex(opt.modelCached._h, plan._h, xd.data_ptr(), _lib.F16, sC, sH, sW, canvas.data_ptr(), _lib.F16, 0, ctypes.c_void_p(pool.data_ptr()), 0, 1, 1, stream))
+        off = plan.tile_offsets(3)
+        nrow = plan.stepH
+        assert nrow >= 3 and len(plan.rows) == nrow
+        S = [r[1] for r in plan.rows] + [plan.outH]
+        assert S[0] == 0
+        for cuts in ([0, 1, nrow], [0, nrow // 2, nrow - 1, nrow], list(range(nrow + 1))):
+            for i0, i1 in zip(cuts, cuts[1:]):
+                for strip in (0, 1):
+                    offs = list(off)
+                    buf = pool
+                    if strip and i1 < nrow:        # tile row i1 as strips, appended behind the pool
+                        extra = []
+                        base = pool.numel()
+                        for j in range(plan.stepW):
+                            k = i1 * plan.stepW + j
+                            t = plan.tiles[k]
+                            th, tw = (t[1] - t[0]) * scale, (t[3] - t[2]) * scale
+                            r0 = plan.rows[i1][0] - plan.rows[i1][2]
+                            extra.append(pool[off[k]:off[k] + 3 * th * tw].view(3, th, tw)[:, r0:r0 + plan.padSc].reshape(-1))
+                            offs[k] = base
+                            base += extra[-1].numel()
+                        buf = torch.cat([pool] + extra)
+                    tab = torch.tensor(offs, dtype=torch.int64, device=dev)
+                    y = torch.full((3, S[i1] - S[i0], plan.outW), float('nan'), dtype=torch.float16, device=dev)
+                    _lib.check(L.moe_stitch_band(plan._h, 0, buf.data_ptr(), ctypes.c_void_p(tab.data_ptr()), 3, y.data_ptr(), _lib.F16, i0, i1, strip, stream))
+                    torch.cuda.synchronize()
+                    assert torch.equal(y, canvas[:, S[i0]:S[i1]]), (H, W, i0, i1, strip)
