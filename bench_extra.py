@@ -324,9 +324,10 @@ def _config4(ns, args):
             for f in frames:                  # the reference runs a batch's frames one after the other (python/video.py:349-360)
                 ip.doCrop(opt, f)
             return
-        # round-robin (frame, tile) ownership over the ranks; 8 frames per exchange keeps the buffers of 64 8K frames out of memory
-        for g in range(0, NF, 8):
-            _run_frames(ns, opt, frames[g:g + 8], args)
+        # round-robin (frame, tile) ownership over the ranks, in groups of N frames: every rank computes one frame's worth of tiles per group and stitches one
+        # frame of it; the all-to-all of a group runs behind the next group's convolutions (dist.run_frames_overlapped)
+        from moephoto_amd.dist import run_frames_overlapped
+        run_frames_overlapped(opt, frames, out_dtype=torch.float16, max_tiles_per_batch=args.tiles_per_batch)
     step()
     steps = args.steps if args.steps_given else 3
     model = opt.modelCached
@@ -338,7 +339,7 @@ def _config4(ns, args):
     in_mp = NF * shape[1] * shape[2] / 1e6
     res, peak = _base(ns, args, 'megapixels/sec (input), batch of 64 1080p frames, 4x SR (a4), 256-px tiles', in_mp / (ms / 1e3), ms, steps, 'strong', 'fp16',
                       'BASELINE configs[3]: 64 frames 1920x1080 RGB -> 7680x4320 per step, model a4 (synthetic weights), 2560 tiles per step'
-                      + (' dealt round-robin over {} GPUs ((frame, tile) -> rank, 8 frames per exchange)'.format(world) if world > 1 else ', one GPU, frame after frame'),
+                      + (' dealt round-robin over {} GPUs ((frame, tile) -> rank; groups of {} frames, the exchange of a group behind the next group\'s convolutions)'.format(world, world) if world > 1 else ', one GPU, frame after frame'),
                       {'frames_per_step': NF, 'tiles_per_step': 40 * NF, 'ms_per_frame': round(ms / NF, 3),
                        'tflops_algorithmic': round(in_mp * 1e6 * 3 * 3.9456e6 / (ms / 1e3) / 1e12, 2)})
     ks = []

@@ -213,13 +213,15 @@ class TileExchange(object):
         return h
 
     # ---- the collective --------------------------------------------------------------------------------
-    def exchange(self, buf):
+    def exchange(self, buf, async_op=False):
         """buf: 1-D fp32 tensor of total_elems holding this rank's tiles at tile_dst.  After the call the `own` + `recv`
-        regions hold every tile of the frames this rank stitches (read them through stitch_off)."""
+        regions hold every tile of the frames this rank stitches (read them through stitch_off).
+        async_op: returns a handle whose wait() makes the CURRENT stream wait for the collective -- the all-to-all then runs on the backend's own
+        stream behind the work enqueued so far, and kernels enqueued before wait() (the next group's convolutions) overlap it."""
         if self.bands:
             self.cut_strips(buf)
         if self.world == 1 and not FORCE_COLLECTIVE:
-            return self.mine
+            return _Done() if async_op else self.mine
         a, b = self.own_elems, self.own_elems + self.recv_elems
         recv, send = buf[a:b], buf[b:b + self.send_elems]
         if send.is_cuda and dist.get_backend(self.group) == 'gloo':
@@ -227,9 +229,14 @@ class TileExchange(object):
             recv_h = torch.empty(self.recv_elems, dtype=send.dtype)
             dist.all_to_all_single(recv_h, send.cpu(), self.recv_split, self.send_split, group=self.group)
             recv.copy_(recv_h)
-        else:
-            dist.all_to_all_single(recv, send, self.recv_split, self.send_split, group=self.group)
-        return self.mine
+            return _Done() if async_op else self.mine
+        work = dist.all_to_all_single(recv, send, self.recv_split, self.send_split, group=self.group, async_op=async_op)
+        return work if async_op else self.mine
+
+
+class _Done(object):
+    def wait(self):
+        return True
 
 
 FORCE_COLLECTIVE = False      # tests: issue the all-to-all even on a world of one rank (exercises the RCCL path on a 1-GPU box)
@@ -288,21 +295,55 @@ def _agreed_plan(opt, shape, group, device):
     return it.plan
 
 
-def run_frames(opt, frames, group=None, out_dtype=None, max_tiles_per_batch=0, bands=None):
-    """Tile-parallel doCrop over a list of equally-shaped (C,H,W) frames that every rank holds
-    (broadcast them first).  Returns {frame index: stitched (C, sc*H, sc*W) tensor} for the frames
-    this rank stitches -- or, in band mode (bands=True; default when there are fewer frames than ranks), {frame index: (first output row, band tensor
-    (C, rows, sc*W))} for every frame: this rank's row band of the canvas, which stays sharded over the ranks (gather_bands concatenates them)."""
+def run_frames_overlapped(opt, frames, group=None, out_dtype=None, max_tiles_per_batch=0):
+    """run_frames for a BATCH of frames (config 4: 64 of them), in groups of `world` frames with the exchange of a group overlapping the convolutions of the
+    next: per group every rank computes its share of the group's tiles into one of TWO exchange buffers, starts the all-to-all asynchronously (it runs on
+    the backend's stream), enqueues the next group's convolutions, and only then lets its stream wait for the previous group's exchange and folds the frame
+    it stitches.  The result is the same dict as run_frames(opt, frames): same layout, same arithmetic per group."""
     from .imageProcess import _DT
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if len(frames) <= world:
+        return run_frames(opt, frames, group, out_dtype, max_tiles_per_batch, bands=False)
     model = opt.modelCached
     x0 = frames[0]
     dev = x0.device
-    plan = _agreed_plan(opt, x0.shape, group, dev)
     C = x0.shape[0]
-    if bands is None:
-        bands = world > 1 and len(frames) < world
-    bands = bool(bands) and plan.stepH >= 1
+    L = _lib.lib()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    odt = out_dtype if out_dtype is not None else x0.dtype
+    out = {}
+    pending = None           # (handle, ex, buf, first frame index of the group)
+
+    def finish(p):
+        work, ex, buf, f0 = p
+        work.wait()
+        tables = ex.stitch_tables(dev)
+        for f in ex.mine:
+            y = torch.empty((C, ex._plan.outH, ex._plan.outW), dtype=odt, device=dev)
+            _lib.check(L.moe_stitch_dev(ex._plan._h, dev.index or 0, buf.data_ptr(), ctypes.c_void_p(tables[f]), C, y.data_ptr(), _DT[odt], stream))
+            out[f0 + f] = y
+    for gi, f0 in enumerate(range(0, len(frames), world)):
+        grp = frames[f0:f0 + world]
+        plan, ex, bufs, padded, fstride = _layout(opt, grp, group, dev, rank, world, C, False, nbuf=2)
+        ex._plan = plan
+        buf = bufs[gi & 1]
+        sC, sH, sW = padded[0].stride()
+        _lib.check(L.moe_run_plan_tiles(model._h, plan._h, padded[0].data_ptr(), _DT[padded[0].dtype], int(fstride), sC, sH, sW,
+                                        len(grp), ctypes.c_void_p(buf.data_ptr()), ex._tile_dst_c, int(max_tiles_per_batch), stream))
+        for p_ in padded:
+            p_.record_stream(torch.cuda.current_stream(dev))
+        work = ex.exchange(buf, async_op=True)
+        if pending is not None:
+            finish(pending)      # (its buffer is the OTHER one; the convolutions above are already enqueued in front of this wait)
+        pending = (work, ex, buf, f0)
+    finish(pending)
+    return out
+
+
+def _layout(opt, frames, group, dev, rank, world, C, bands, nbuf=1):
+    """(plan, exchange layout, its buffer(s), the padded frames, their stride): cached on the Option per (shape, frame count, rank, world, C, mode)."""
+    x0 = frames[0]
+    plan = _agreed_plan(opt, x0.shape, group, dev)
     cache = opt.__dict__.setdefault('_exchanges', {})
     ck = (tuple(int(v) for v in x0.shape[-3:]), len(frames), rank, world, C, bands)
     ent = cache.get(ck)
@@ -322,13 +363,12 @@ def run_frames(opt, frames, group=None, out_dtype=None, max_tiles_per_batch=0, b
             dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
             if int(lo.item()) != int(hi.item()):
                 raise RuntimeError('run_frames: the ranks derived different tile plans (pass an explicit cropsize)')
-        buf = torch.empty(ex.total_elems, dtype=torch.float32, device=dev)
-        ent = cache[ck] = (plan, ex, buf)
+        ent = cache[ck] = (plan, ex, [])
         while len(cache) > 4:
             cache.pop(next(iter(cache)))
-    _, ex, buf = ent
-    L = _lib.lib()
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    _, ex, bufs = ent
+    while len(bufs) < nbuf:
+        bufs.append(torch.empty(ex.total_elems, dtype=torch.float32, device=dev))
     padded = [plan.padImage(x) for x in frames]
     # one launch set for ALL frames: same-shaped tiles of different frames share batches (a rank owns only n_tiles/world tiles
     # of each frame -- run frame by frame they would go out as many small, inefficient launches)
@@ -340,6 +380,27 @@ def run_frames(opt, frames, group=None, out_dtype=None, max_tiles_per_batch=0, b
         stacked = torch.stack(padded)            # frames are not slices of one tensor: gather them once
         padded = list(stacked.unbind(0))
         fstride = stacked.stride(0)
+    return plan, ex, bufs, padded, fstride
+
+
+def run_frames(opt, frames, group=None, out_dtype=None, max_tiles_per_batch=0, bands=None):
+    """Tile-parallel doCrop over a list of equally-shaped (C,H,W) frames that every rank holds
+    (broadcast them first).  Returns {frame index: stitched (C, sc*H, sc*W) tensor} for the frames
+    this rank stitches -- or, in band mode (bands=True; default when there are fewer frames than ranks), {frame index: (first output row, band tensor
+    (C, rows, sc*W))} for every frame: this rank's row band of the canvas, which stays sharded over the ranks (gather_bands concatenates them)."""
+    from .imageProcess import _DT
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    model = opt.modelCached
+    x0 = frames[0]
+    dev = x0.device
+    C = x0.shape[0]
+    if bands is None:
+        bands = world > 1 and len(frames) < world
+    bands = bool(bands)
+    plan, ex, bufs, padded, fstride = _layout(opt, frames, group, dev, rank, world, C, bands)
+    buf = bufs[0]
+    L = _lib.lib()
+    stream = torch.cuda.current_stream(dev).cuda_stream
     sC, sH, sW = padded[0].stride()
     _lib.check(L.moe_run_plan_tiles(model._h, plan._h, padded[0].data_ptr(), _DT[padded[0].dtype], int(fstride), sC, sH, sW,
                                     len(frames), ctypes.c_void_p(buf.data_ptr()), ex._tile_dst_c, int(max_tiles_per_batch), stream))

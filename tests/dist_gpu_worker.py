@@ -36,6 +36,14 @@ out2 = run_frames(opt, list(allf.unbind(0)), out_dtype=torch.float16)
 torch.cuda.synchronize()
 for f, y in out2.items():
     assert torch.equal(y, out[f]), f
+# a batch of frames in groups of `world` with the exchange of a group overlapping the next group's convolutions (two exchange buffers)
+from moephoto_amd.dist import run_frames_overlapped  # noqa: E402
+more = frames + [torch.from_numpy(gd.natural_image(60 + f, (3, 150, 200))).cuda().half() for f in range(4)]        # 7 frames: groups of `world`, a short last one
+out3 = run_frames_overlapped(opt, more, out_dtype=torch.float16)
+torch.cuda.synchronize()
+assert sorted(out3) == [f for f in range(len(more)) if (f % world) == rank], (sorted(out3), rank)
+for f, y in out3.items():
+    assert torch.equal(y, ip.doCrop(opt, more[f])), f
 # band-sharded stitch: ONE frame, every rank folds its row band of the canvas; concatenated, the bands are doCrop's canvas bit for bit
 from moephoto_amd.dist import gather_bands  # noqa: E402
 for fr in (frames[1], torch.from_numpy(gd.natural_image(77, (3, 264, 136))).cuda().half()):      # (7 and 6 tile rows at crop 64)

@@ -655,6 +655,12 @@ def test_rccl_path_world1(dev):
             assert sorted(out) == [0, 1, 2]
             for f, y in out.items():
                 assert torch.equal(y, ip.doCrop(opt, frames[f])), (rep, f)
+        # the grouped form with ASYNCHRONOUS all-to-alls on RCCL's stream (groups of one frame here), two exchange buffers
+        out = mdist.run_frames_overlapped(opt, frames, out_dtype=torch.float16)
+        torch.cuda.synchronize()
+        assert sorted(out) == [0, 1, 2]
+        for f, y in out.items():
+            assert torch.equal(y, ip.doCrop(opt, frames[f])), f
     finally:
         mdist.FORCE_COLLECTIVE = False
         dist.destroy_process_group()
