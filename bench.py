@@ -249,6 +249,8 @@ def main():
                 k['mfma_busy_pmc'] = t['mfma_busy']
         else:
             k['traffic'] = None
+            if getattr(_pmc_table, 'stale', None):
+                k['traffic_note'] = _pmc_table.stale
         kernels.append(k)
     kernels.sort(key=lambda k: -k['ms_per_frame'])
     if kernels:
@@ -528,7 +530,12 @@ def _pmc_table():
     """{layer key: {'hbm_bytes_per_frame', 'launches_per_frame', ...}} from the committed rocprofv3 PMC passes of THIS command
     (tools/pmc_bench.sh -> tools/pmc_collect.py -> profiles/pmc_bench.json), or {} when absent."""
     try:
-        return json.load(open(os.path.join(ROOT, 'profiles', 'pmc_bench.json'))).get('groups', {})
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_bench.json')))
+        from moephoto_amd.build import source_digest
+        if d.get('source_sha256') != source_digest():      # counters of ANOTHER tree: no traffic figure rather than a stale one
+            _pmc_table.stale = 'profiles/pmc_bench.json was collected on other sources (digest {} != {}): rerun tools/pmc_bench.sh'.format(str(d.get('source_sha256'))[:12], source_digest()[:12])
+            return {}
+        return d.get('groups', {})
     except Exception:
         return {}
 

@@ -27,6 +27,18 @@ def hipcc():
     return 'hipcc'
 
 
+def source_digest():
+    """sha256 over the kernel / engine sources and headers (sorted by name): names the binary a set of profiles belongs to -- the GPU box has no .git, and
+    bench.py must not pair the PMC bytes of one tree with the timings of another (profiles/pmc_bench.json carries this digest)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(SOURCES + ['common.h', 'engine.h', 'rowtile.h'])
+    for f in files + [os.path.join('..', '..', 'include', 'moephoto_amd.h')]:
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), 'rb').read())
+    return h.hexdigest()
+
+
 def stale():
     if not os.path.exists(LIB):
         return True

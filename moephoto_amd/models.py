@@ -175,6 +175,36 @@ class EngineModule(object):
         _lib.check(_lib.lib().moe_net_set_exact_blocks(self._h, int(blocks)))
         return self
 
+    def calibrate(self, target=8e-4, tile=(3, 192, 192), seeds=(0, 1)):
+        """Pick the number of split-operand ARSBs for THESE weights: the per-architecture defaults (Net2x 4, Net3x 2, Net4x 1, NetDN 1) were chosen on the zoo's
+        weights with ~2e-4 of the 1e-3 budget to spare on uint8 noise; a checkpoint whose trunk swings wider spends more (tools/margin_sweep.py: the same a2
+        with its trunk weights x 1.15 needs more blocks).  Runs uniform uint8-noise tiles through the default arithmetic with n = default .. 6 blocks against
+        this engine's exact mode ('fp16x3', pinned to the oracle at 2e-5 by the tests) and keeps the smallest n whose worst max-abs difference is <= target.
+        A host-side convenience on top of moe_net_set_exact_blocks (no reference counterpart); returns (n, worst error at n).  Only for precision 'auto' /
+        'mixed' on the ARSB nets; the module must be on its device."""
+        import numpy as np
+        if self._device is None:
+            raise _lib.EngineError('calibrate: move the module to its device first')
+        if self.resolved_precision() != 'mixed':
+            return None
+        prec = self.precision
+        xs = [torch.from_numpy(np.random.default_rng(s).integers(0, 256, tile, dtype=np.uint8).astype(np.float32) / np.float32(255)).to(self._device)[:, None] for s in seeds]
+        try:
+            self.set_precision('fp16x3')
+            want = [self(x)[-1].clone() for x in xs]
+            self.set_precision(prec)
+            n0 = {_lib.ARCH_NET2X: 4, _lib.ARCH_NET3X: 2, _lib.ARCH_NET4X: 1, _lib.ARCH_NETDN: 1}.get(self.ARCH, 1)
+            best = None
+            for n in range(n0, 7):
+                self.set_exact_blocks(n)
+                err = max(float((self(x)[-1] - w).abs().amax()) for x, w in zip(xs, want))
+                best = (n, err)
+                if err <= target:
+                    break
+            return best
+        finally:
+            self.set_precision(prec)
+
     def set_option(self, key, value):
         """A kernel-form switch of this net (moe_net_set_option): e.g. ('sp_impl', 'rw'), ('arsb_fuse', 0).  Takes effect at the next forward."""
         v = value if isinstance(value, str) else str(int(value))

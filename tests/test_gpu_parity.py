@@ -1068,3 +1068,27 @@ def test_stitch_band_equals_rows_of_the_canvas(dev):
                     _lib.check(L.moe_stitch_band(plan._h, 0, buf.data_ptr(), ctypes.c_void_p(tab.data_ptr()), 3, y.data_ptr(), _lib.F16, i0, i1, strip, stream))
                     torch.cuda.synchronize()
                     assert torch.equal(y, canvas[:, S[i0]:S[i1]]), (H, W, i0, i1, strip)
+
+
+def test_calibrate_exact_blocks_for_other_weights(dev):
+    """EngineModule.calibrate: the per-architecture number of split-operand blocks was chosen on the zoo's weights; a checkpoint whose trunk swings wider
+    needs more (tools/margin_sweep.py).  On a2 as shipped the default (4) holds the target and is kept; on a2 with its trunk weights x 1.15 the default spends
+    more than the target on uint8 noise, and calibrate() moves to more blocks with a smaller error."""
+    from moephoto_amd import models
+    sd = gd.state_dict_for('a2', load_state_dict_file)
+
+    def build(scale):
+        v = {k: (a * np.float32(scale) if (k.startswith('conv_input2') or (k.startswith('convt_F') and a.ndim == 4)) else a) for k, a in sd.items()}
+        m = models.Net2x()
+        m.load_state_dict({n: torch.from_numpy(np.ascontiguousarray(a, np.float32)) for n, a in v.items()})
+        return m.eval().to(dtype=torch.float32, device=dev)
+    m = build(1.0)
+    n, err = m.calibrate()
+    assert n == 4 and err <= 8e-4, (n, err)
+    m = build(1.15)
+    m.set_exact_blocks(4)
+    x = torch.from_numpy(gd.noise_u8(0, (3, 192, 192)).astype(np.float32) / np.float32(255)).to(dev)[:, None]
+    e4 = float((m(x)[-1] - m.set_precision('fp16x3')(x)[-1]).abs().amax())
+    m.set_precision('auto')
+    n, err = m.calibrate()
+    assert n > 4 and err < e4, (n, err, e4)

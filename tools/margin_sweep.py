@@ -1,0 +1,63 @@
+#!/usr/bin/env python
+"""How much of the 1e-3 budget the default arithmetic ('mixed': n split-operand blocks, fp8 corrections, fp8 low parts) keeps when the WEIGHTS change (the
+defaults were tuned on a2's real weights, a4-synth and a few uint8-noise frames).  The engine's own exact mode ('fp16x3', pinned to the oracle at 2e-5) is the
+transfer standard, as in tests/test_gpu_fullsize.py.  Variants: the 3x3 64->64 trunk weights (conv_input2, every ARSB) scaled by s -- activations and the
+residual stream swing s^k times wider -- and an independent Gaussian perturbation of every conv weight by 10 % of its tensor's rms.
+    python tools/margin_sweep.py [a4 a2]        -> worst tile (max-abs vs exact mode) per variant, uint8-noise and natural 256^2 tiles
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'tests')):
+    sys.path.insert(0, p)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import golden_defs as gd  # noqa: E402
+from moephoto_amd import models  # noqa: E402
+from moephoto_amd.weights import load_state_dict_file  # noqa: E402
+
+
+def variants(sd):
+    trunk = [k for k in sd if k.startswith('conv_input2') or (k.startswith('convt_F') and k.endswith('weight') and sd[k].ndim == 4)]
+    yield 'as shipped', dict(sd)
+    for s in (0.85, 1.15, 1.3):
+        v = dict(sd)
+        for k in trunk:
+            v[k] = (sd[k] * np.float32(s)).astype(np.float32)
+        yield 'trunk weights x %.2f' % s, v
+    for seed in (1, 2):
+        rng = np.random.default_rng(seed)
+        v = dict(sd)
+        for k in sd:
+            if sd[k].ndim == 4:
+                v[k] = (sd[k] + rng.standard_normal(sd[k].shape).astype(np.float32) * np.float32(0.1 * np.sqrt(np.mean(sd[k] ** 2)))).astype(np.float32)
+        yield 'every conv weight + N(0, (0.1 rms)^2), seed %d' % seed, v
+
+
+def main():
+    keys = sys.argv[1:] or ['a4', 'a2']
+    for key in keys:
+        arch = gd.MODELS[key][0]
+        sd0 = gd.state_dict_for(key, load_state_dict_file)
+        ctor = {'net2x': models.Net2x, 'net4x': models.Net4x}[arch]
+        for name, sd in variants(sd0):
+            m = ctor()
+            m.load_state_dict({n: torch.from_numpy(np.ascontiguousarray(v)) for n, v in sd.items()})
+            m = m.eval().to(dtype=torch.float32, device='cuda:0')
+            worst = {}
+            for kind in ('noise_u8', 'natural'):
+                w = 0.0
+                for seed in range(4):
+                    x = (gd.noise_u8(seed, (12, 256, 256)).astype(np.float32) / np.float32(255)) if kind == 'noise_u8' else gd.natural_image(200 + seed, (12, 256, 256))
+                    xd = torch.from_numpy(x[:, None]).cuda().half().float()
+                    y = m.set_precision('auto')(xd)[-1]
+                    want = m.set_precision('fp16x3')(xd)[-1]
+                    w = max(w, float((y - want).abs().amax()))
+                    rng_out = float(want.abs().amax())
+                worst[kind] = (w, rng_out)
+            print('%-3s %-52s noise_u8 %.3e (|y| <= %.2f)   natural %.3e' % (key, name, worst['noise_u8'][0], worst['noise_u8'][1], worst['natural'][0]), flush=True)
+
+
+if __name__ == '__main__':
+    main()

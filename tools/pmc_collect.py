@@ -79,7 +79,9 @@ for key, rx in GROUP_KERNELS.items():
     if ck:
         g['clock_ghz_profiled'] = round(sum(ck) / len(ck), 3)
     groups[key] = g
-json.dump({'frames_profiled': frames, 'kernels': kernels, 'groups': groups}, open(os.path.join(out, 'pmc_bench.json'), 'w'), indent=1)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from moephoto_amd.build import source_digest  # noqa: E402
+json.dump({'frames_profiled': frames, 'source_sha256': source_digest(), 'kernels': kernels, 'groups': groups}, open(os.path.join(out, 'pmc_bench.json'), 'w'), indent=1)
 print('%-44s %6s %10s %10s %8s %8s %8s %8s' % ('kernel', 'n/frm', 'fetch MB', 'write MB', 'MFMA', 'waitI', 'GHz', 'ms/frm'))
 for k, e in kernels.items():
     print('%-44s %6.1f %10.1f %10.1f %8s %8s %8s %8s' % (k[:44], e['dispatches_per_frame'], e.get('fetch_bytes_per_frame', 0) / 1e6, e.get('write_bytes_per_frame', 0) / 1e6,
