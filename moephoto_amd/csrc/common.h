@@ -155,6 +155,9 @@ struct ArsbArgs {
 // arsb32c.hip: v_mfma_f32_32x32x16_f16, four waves in lock-step, both convs' weights resident (w1 / w2 in the pack_conv fragment order, ConvLayer::w_hi), ten output rows
 // per patch, the two last m rows of a patch stay in LDS for the patch below.  false: not applicable (the caller runs the two convs)
 bool launch_arsb32c(ArsbArgs a, int max_groups, hipStream_t s);
+// arsb_s.hip: the same ARSB streamed down 30-pixel columns (two waves per workgroup, two workgroups per CU, every row step 72 MFMAs), bit-identical results
+bool launch_arsb_s(ArsbArgs a, int max_groups, hipStream_t s);
+hipError_t arsb_s_init();
 hipError_t arsb32c_init();
 
 // One 3x3 64->64 conv with split operands, three products in one launch (conv64_x3.hip); weights in the fused-ARSB order

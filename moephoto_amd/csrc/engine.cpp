@@ -97,6 +97,9 @@ struct NetOptions {
     int x3_impl = 0;          // x3_impl     auto (0, default: q8 for the SR nets, x3 for the DN nets -- see forward) | x3 (1: conv64_x3.hip, three fp16 products) |
                               //             q8 (2: conv64_q8.hip, the two correction products on fp8 operands)
     int k48 = 1;              // k48         1 (default): kernels that can skip the zero k-slice of the 48-channel nets do | 0: they run all four (A/B)
+    int arsb_impl = 3;        // arsb_impl   v3 (3, default: arsb32c.hip, ten-row patches) | s (4: arsb_s.hip, rows streamed down 30-pixel columns by two-wave workgroups:
+                              //             bit-identical, measured 7 % SLOWER -- both forms sit at the package power cap with the same MFMA rate (busy x clock 0.73 x 1.65
+                              //             vs 0.69 x 1.74 GHz) and the streamed one issues 9 % more MFMAs on rows it recomputes at range starts; kept as the A/B)
                               // (arsb_impl: round 3 kept three generations of the one-launch ARSB side by side -- arsb_fused.hip, arsb32.hip, arsb32c.hip; only the last,
                               // the default since, is built now: the earlier two are in the history at 689845f)
     bool fuse_tail = true;    // fuse_tail   last upsampler conv + 64->1 / 48->1 tail conv in one kernel
@@ -131,7 +134,7 @@ struct NetOptions {
         if (key == "lo8") { const int t = onoff(v); if (t < 0) return false; lo8 = t; return true; }
         if (key == "x3_impl") { const int t = tri(v, "auto", "x3", "q8", -1); if (t < 0) return false; x3_impl = t; return true; }
         if (key == "k48") { const int t = onoff(v); if (t < 0) return false; k48 = t; return true; }
-        if (key == "arsb_impl") return v && !strcmp(v, "v3");      // (accepted for old command lines: arsb32c.hip is the one form)
+        if (key == "arsb_impl") { if (v && !strcmp(v, "s")) arsb_impl = 4; else if (v && !strcmp(v, "v3")) arsb_impl = 3; else return false; return true; }
         if (key == "conv1x1") return flag(conv1x1);
         if (key == "x3_fuse") return flag(x3_fuse);
         if (key == "arsb_fuse") return flag(arsb_fuse);
@@ -147,13 +150,13 @@ struct NetOptions {
     void from_env()
     {
         static const char* const names[][2] = {{"MOE_CONV_IMPL", "conv_impl"}, {"MOE_SP_IMPL", "sp_impl"}, {"MOE_TAIL_SPLIT", "tail_split"}, {"MOE_TAIL_FORM", "tail_form"}, {"MOE_UP_IMPL", "up_impl"},
-                                               {"MOE_CONV1X1", "conv1x1"}, {"MOE_K48", "k48"}, {"MOE_X3_IMPL", "x3_impl"}, {"MOE_LO8", "lo8"}, {"MOE_X3_FUSE", "x3_fuse"}, {"MOE_ARSB_FUSE", "arsb_fuse"}, {"MOE_FUSE_TAIL", "fuse_tail"},
+                                               {"MOE_CONV1X1", "conv1x1"}, {"MOE_ARSB_IMPL", "arsb_impl"}, {"MOE_K48", "k48"}, {"MOE_X3_IMPL", "x3_impl"}, {"MOE_LO8", "lo8"}, {"MOE_X3_FUSE", "x3_fuse"}, {"MOE_ARSB_FUSE", "arsb_fuse"}, {"MOE_FUSE_TAIL", "fuse_tail"},
                                                {"MOE_SEDN_FUSE", "sedn_fuse"}, {"MOE_POOL_FUSE", "pool_fuse"}, {"MOE_DBG", "dbg"}, {"MOE_TRACE_KEY", "trace_key"},
                                                {"MOE_TILES_PER_BATCH", "tiles_per_batch"}, {"MOE_MAX_GROUPS", "max_groups"}};
         for (const auto& nv : names)
             if (const char* e = getenv(nv[0]))
                 if (!set(nv[1], e)) fprintf(stderr, "moephoto_amd: %s=\"%s\" is not a value of option %s -- ignored\n", nv[0], e, nv[1]);      // (a typo in an A/B run must not pass silently)
-        if (getenv("MOE_ARSB_IMPL") && strcmp(getenv("MOE_ARSB_IMPL"), "v3")) fprintf(stderr, "moephoto_amd: MOE_ARSB_IMPL: only v3 (arsb32c.hip) is built since round 4 -- ignored\n");
+
         if (const char* e = getenv("MOE_EXACT_BLOCKS")) exact_blocks_env = atoi(e);
         arsb_trace = getenv("MOE_ARSB_TRACE") != nullptr;
     }
@@ -1046,7 +1049,8 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
                         ArsbArgs q2 = q;
                         q2.w1 = f.blob<half_t>(L1.w_hi); q2.w2 = f.blob<half_t>(L2.w_hi);      // (pack_conv order; conv_2's carry the ScaleLayer factor as well)
                         q2.cin = (L1.cin == 48 && L2.cin == 48 && n.opt.k48) ? 48 : 64;      // NetDN: channels 48..63 are zeros in activations and weights
-                        done = launch_arsb32c(q2, n.max_groups, s);      // (false: the shape does not fit its 32-bit offsets -- the two-launch form below)
+                        if (n.opt.arsb_impl == 4) done = launch_arsb_s(q2, n.max_groups, s);
+                        if (!done) done = launch_arsb32c(q2, n.max_groups, s);      // (false: the shape does not fit its 32-bit offsets -- the two-launch form below)
                     }
                     f.prof_end(rec);
                     if (q.trace) {

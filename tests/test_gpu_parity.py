@@ -1092,3 +1092,26 @@ def test_calibrate_exact_blocks_for_other_weights(dev):
     m.set_precision('auto')
     n, err = m.calibrate()
     assert n > 4 and err < e4, (n, err, e4)
+
+
+def test_streamed_arsb_is_bit_identical_to_the_patch_form(dev):
+    """Option arsb_impl = s (arsb_s.hip: the ARSB streamed down 30-pixel columns by two-wave workgroups, conv_2 four rows behind conv_1 through an m ring in LDS,
+    the rows a range needs from its neighbours recomputed) against the default arsb32c.hip: the same MFMAs in the same order and the same epilogue arithmetic
+    -- not a bit may differ, on ragged shapes, 48- and 64-channel nets, with and without the hi + lo stream, and however the ranges are cut."""
+    touched = []
+    try:
+        for key, prec in (('a2', 'auto'), ('a2', 'fp16'), ('dn_lite5', 'auto'), ('dn_lite5', 'fp16'), ('a4', 'auto')):
+            m = module_for(key, prec)
+            touched.append(m)
+            for shape in ((3, 8, 16), (3, 24, 40), (2, 40, 264), (3, 16, 35), (5, 88, 64), (2, 128, 61)):
+                x = gd.noise_image(17, shape)[:, None]
+                xd = torch.from_numpy(x).to(dev)
+                y3 = m.set_option('arsb_impl', 'v3')(xd)[-1]
+                ys = m.set_option('arsb_impl', 's')(xd)[-1]
+                yg = m.set_option('max_groups', 5)(xd)[-1]
+                m.set_option('max_groups', 0)
+                assert torch.equal(y3, ys), (key, prec, shape, float((y3 - ys).abs().max()))
+                assert torch.equal(ys, yg), (key, prec, shape)
+    finally:
+        for m in touched:
+            m.set_option('arsb_impl', 'v3').set_option('max_groups', 0)
