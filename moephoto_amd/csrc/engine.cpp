@@ -770,8 +770,11 @@ struct Fwd {
                 return;
             }
             if (fast && n.opt.up_impl == 1 && !ca.tplanes && !ca.pool && ca.r == 2 && ca.nchunks == 4 && ca.in_cs == 64 && ca.acc_mode == 0 && !ca.res && !ca.out_lo && ca.scale == 1.f &&
-                !ca.dbg && L.has_bias) {
-                Ps4Args q{};      // the x2 upsampler stages that store their tensor: all four phases in one workgroup (conv3x3_ps4.hip, store form)
+                !ca.dbg && L.has_bias && (long long)ca.B * ((ca.W + kTileW - 1) / kTileW) * (ca.H / 4) >= 32ll * n.max_groups) {
+                // The x2 upsampler stages that store their tensor: all four phases in one workgroup (conv3x3_ps4.hip, store form) -- when a workgroup gets at least
+                // 32 four-row blocks: a range recomputes two blocks at its ends, and a launch of three planes of 256 x 256 (the reference's own per-tile loop) would
+                // give each of the 256 workgroups six.  conv3x3_rw<1> below produces the same bits (same MFMAs in the same order), so the choice is invisible.
+                Ps4Args q{};
                 q.in = ca.in; q.wpk = ca.wpk; q.bias = ca.bias; q.out = ca.out; q.slope = ca.slope; q.B = ca.B; q.H = ca.H; q.W = ca.W;
                 if (launch_conv3x3_ps4(q, n.max_groups, s)) return;
             }
