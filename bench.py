@@ -253,6 +253,14 @@ def main():
                 k['traffic_note'] = _pmc_table.stale
         kernels.append(k)
     kernels.sort(key=lambda k: -k['ms_per_frame'])
+    # what the package power cap lets the matrix pipe deliver on operands whose bits toggle: a loop of nothing but v_mfma_f32_32x32x16_f16 on uniform random
+    # fp16 data (tools/micro/mfma_power.hip), measured here on this box -- the practical ceiling beside the nominal peak every `frac` is quoted against
+    power = _power_roofline() if rank == 0 else None
+    if power:
+        res['power_roofline'] = power
+        for k in kernels:
+            k['frac_of_power_roofline'] = round(k['achieved'] / power['uniform_random_tflops'], 4)
+            k['frac_executed_of_power_roofline'] = round(k['achieved_executed'] / power['uniform_random_tflops'], 4)
     if kernels:
         res['roofline'] = dict(kernels[0])
         res['roofline_kernels'] = kernels
@@ -524,6 +532,27 @@ def _one_socket_cores():
     except Exception:
         pass
     return n, n
+
+
+def _power_roofline():
+    exe = os.path.join(ROOT, 'tools', 'micro', '_build', 'mfma_power')
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe, '60000'], capture_output=True, text=True, timeout=120).stdout
+        import re
+        v = {}
+        for kind, key in (('zeros', 'zeros_tflops'), ('uniform random', 'uniform_random_tflops'), ('random signs', 'random_signs_tflops'), ('random, B per 8 MFMAs', 'uniform_random_shared_b_tflops')):
+            m = re.search(re.escape(kind) + r'\s+idle states 0:\s+([0-9.]+) TFLOP/s', out)
+            if m:
+                v[key] = float(m.group(1))
+        if 'uniform_random_tflops' not in v:
+            return None
+        v['what'] = ('back-to-back v_mfma_f32_32x32x16_f16 from registers (no LDS, no memory), one 4-wave workgroup per CU, ~25 ms per variant: the rate the package power cap '
+                     'sustains; zeros = operands that do not toggle')
+        return v
+    except Exception:
+        return None
 
 
 def _pmc_table():

@@ -82,5 +82,18 @@ def build_lib(force=False, verbose=False):
     return LIB
 
 
+def build_probes():
+    """tools/micro/mfma_power (measurement infrastructure, not product): the matrix pipe's rate under the package power cap; bench.py runs it for the
+    `power_roofline` object.  Built next to the library so that it travels to the GPU box with the working tree."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, 'tools', 'micro', 'mfma_power.hip')
+    out = os.path.join(root, 'tools', 'micro', '_build', 'mfma_power')
+    if os.path.exists(src) and (not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src)):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.check_call([hipcc(), '--offload-arch=' + ARCH, '-O3', src, '-o', out])
+    return out
+
+
 if __name__ == '__main__':
+    build_probes()
     print(build_lib(force='--force' in sys.argv, verbose=True))
