@@ -535,7 +535,7 @@ def _one_socket_cores():
 
 
 def _power_roofline():
-    exe = os.path.join(ROOT, 'tools', 'micro', '_build', 'mfma_power')
+    exe = os.path.join(ROOT, 'tools', 'micro', 'bin', 'mfma_power')
     if not os.path.exists(exe):
         return None
     try:

@@ -87,7 +87,7 @@ def build_probes():
     `power_roofline` object.  Built next to the library so that it travels to the GPU box with the working tree."""
     root = os.path.dirname(HERE)
     src = os.path.join(root, 'tools', 'micro', 'mfma_power.hip')
-    out = os.path.join(root, 'tools', 'micro', '_build', 'mfma_power')
+    out = os.path.join(root, 'tools', 'micro', 'bin', 'mfma_power')
     if os.path.exists(src) and (not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src)):
         os.makedirs(os.path.dirname(out), exist_ok=True)
         subprocess.check_call([hipcc(), '--offload-arch=' + ARCH, '-O3', src, '-o', out])

@@ -7,6 +7,7 @@ kernels do, so `F.conv2d` on rounded operands models them up to summation order.
 
   python tests/emu_precision.py layers a2      per-layer contribution of weight / activation rounding
   python tests/emu_precision.py budget         max-abs error of fp16 / mixed(n) on noise and natural tiles, all ARSB nets
+  python tests/emu_precision.py wino a4        the upsampler convs as Winograd F(2x2, 3x3) with fp16 transformed operands, per branch (round 4 study)
 
 Used by tests/test_precision_budget.py (CPU suite) to pin the defaults of `exact_blocks_of` in engine.cpp.
 """
@@ -270,6 +271,24 @@ def main(argv):
     cmd = argv[1] if len(argv) > 1 else 'budget'
     if cmd == 'lite':
         lite_budget(tuple(argv[2:]) or ('lite2', 'lite4', 'lite8'))
+        return
+    if cmd == 'wino':       # the upsampler convs as Winograd F(2x2, 3x3) with fp16 U and V (2.25x fewer MFMAs): what would it cost in precision, per branch?
+        for key in (argv[2:] or ['a4']):
+            arch, sd = gd.MODELS[key][0], _load(key)
+            ups = [l for l in layer_names(arch) if '.up' in l]
+            for kind, shape, seed in (('noise-u8', (3, 256, 256), 0), ('noise-u8', (3, 256, 256), 1), ('noise-u8', (3, 256, 256), 2), ('natural', (3, 40, 264), 5)):
+                x = gd.natural_image(seed, shape) if kind == 'natural' else gd.noise_u8(seed, shape).astype(np.float32) / 255.0
+                x = x[:, None]
+                with torch.no_grad():
+                    want = forward(arch, sd, x)
+                    for n in (DEFAULT_EXACT[arch], DEFAULT_EXACT[arch] + 2):
+                        ex = ['input2'] + ['c%d_%d' % (j, i) for i in range(1, n + 1) for j in (1, 2)]
+                        w16, a16, s16 = mode_sets(arch, 'mixed', n)
+                        line = '%-4s %-8s seed %d n=%d: direct %.3e' % (key, kind, seed, n, float((forward(arch, sd, x, w16, a16, s16, corr8=ex, lo8=True) - want).abs().max()))
+                        for tag, ws in (('R branch', [u for u in ups if u.startswith('r.')]), ('U branch', [u for u in ups if u.startswith('u.')]), ('both', ups)):
+                            e = float((forward(arch, sd, x, w16, a16, s16, corr8=ex, lo8=True, wino=ws) - want).abs().max())
+                            line += ' | Winograd on the %s %.3e' % (tag, e)
+                        print(line, flush=True)
         return
     if cmd == 'corr6':      # the correction products on block-scaled fp6 instead of fp8 (4x instead of 2x the fp16 MFMA rate): does the budget hold?
         for key in (argv[2:] or ['a2', 'a3', 'a4', 'dn_lite5']):
