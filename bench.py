@@ -255,7 +255,7 @@ def main():
     kernels.sort(key=lambda k: -k['ms_per_frame'])
     # what the package power cap lets the matrix pipe deliver on operands whose bits toggle: a loop of nothing but v_mfma_f32_32x32x16_f16 on uniform random
     # fp16 data (tools/micro/mfma_power.hip), measured here on this box -- the practical ceiling beside the nominal peak every `frac` is quoted against
-    power = _power_roofline() if rank == 0 else None
+    power = _power_roofline() if (rank == 0 and world == 1) else None      # (single-GPU runs only: a second process on the device has no place in a scaling run)
     if power:
         res['power_roofline'] = power
         for k in kernels:
