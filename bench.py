@@ -100,6 +100,7 @@ def main():
     ap.add_argument('--no-dropin-loop', action='store_true', help='skip the per-tile drop-in loop leg')
     ap.add_argument('--config', type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json's configs[N-1]: 2 = the headline (default), 3 = 4K l25 -> a2 chain, "
                     '4 = batch of 64 1080p frames, 5 = one 8K frame -> 32K with 512-px tiles (bench_extra.py)')
+    ap.add_argument('--wire', default='f32', choices=['f32', 'f16s'], help='configs 3-5 under --gpus N: tile results between ranks as fp32, or as fp16 + fp32 seams (dist.py)')
     ap.add_argument('--no-extras', action='store_true', help='config 2: skip the roofline objects of the HBM-bound members and the I/O edges')
     args = ap.parse_args()
     args.steps_given = any(a == '--steps' or a.startswith('--steps=') for a in sys.argv[1:])

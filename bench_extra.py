@@ -201,6 +201,8 @@ def _pool_of(ns, opt, plan, xd, stitch_to=None):
 def _base(ns, args, metric, value, ms_per_step, steps, scaling, dtype, workload, extra_cfg):
     res = {'metric': metric, 'value': round(value, 3), 'unit': 'MP/s', 'n_gpus': ns['world'], 'steps': steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
            'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic', 'config': dict({'workload': workload}, **extra_cfg)}
+    if ns['world'] > 1:
+        res['config']['wire'] = args.wire
     d = ns['_lib'].device_info(ns['local'])
     peak = d['compute_units'] * 4 * 1024 * d['clock_khz'] * 1e3 / 1e12
     res['device'] = {'compute_units': d['compute_units'], 'max_clock_ghz': round(d['clock_khz'] / 1e6, 3), 'peak_fp16_mfma_tflops': round(peak, 1)}
@@ -236,7 +238,7 @@ def run_config(cfg, args):
 
 def _run_frames(ns, opt, frames, args):
     from moephoto_amd.dist import run_frames
-    return run_frames(opt, frames, out_dtype=ns['torch'].float16, max_tiles_per_batch=args.tiles_per_batch)
+    return run_frames(opt, frames, out_dtype=ns['torch'].float16, max_tiles_per_batch=args.tiles_per_batch, wire=args.wire)
 
 
 def _config3(ns, args):
@@ -327,7 +329,7 @@ def _config4(ns, args):
         # round-robin (frame, tile) ownership over the ranks, in groups of N frames: every rank computes one frame's worth of tiles per group and stitches one
         # frame of it; the all-to-all of a group runs behind the next group's convolutions (dist.run_frames_overlapped)
         from moephoto_amd.dist import run_frames_overlapped
-        run_frames_overlapped(opt, frames, out_dtype=torch.float16, max_tiles_per_batch=args.tiles_per_batch)
+        run_frames_overlapped(opt, frames, out_dtype=torch.float16, max_tiles_per_batch=args.tiles_per_batch, wire=args.wire)
     step()
     steps = args.steps if args.steps_given else 3
     model = opt.modelCached

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MOE_ABI_VERSION 2      /* 2: MOE_PREC_AUTO, moe_net_resolved_precision (round 4); 1 also lacked a bump for moe_net_set_option / moe_device_info / moe_stitch_dev */
+#define MOE_ABI_VERSION 2      /* 2: MOE_PREC_AUTO, moe_net_resolved_precision, moe_plan_rows / moe_stitch_band, moe_plan_seams / moe_wire_* (round 4); 1 also lacked a bump for moe_net_set_option / moe_device_info / moe_stitch_dev */
 
 /* error codes */
 #define MOE_OK 0
@@ -176,6 +176,27 @@ int moe_stitch_dev(const moe_plan* plan, int device, const float* tiles_dev, con
  * only those strips cross between neighbouring bands), bit-identical to the rows of moe_stitch's canvas. */
 int moe_stitch_band(const moe_plan* plan, int device, const float* tiles_dev, const int64_t* tile_off_dev, int C,
                     void* out, int out_dtype, int row0, int row1, int strip, void* stream);
+/* ---- wire format of tile results between ranks (moephoto_amd/dist.py, wire = 'f16s') ------------------------------------------------
+ * The reference has no multi-device code; this belongs to the tile-parallel layer around doCrop (python/imageProcess.py:120-172).  A tile's fp32
+ * value is needed exactly only where a blend reads it: in the tile's own blend band and under the blend bands of later tiles (imageProcess.py:
+ * 120-131); elsewhere it is rounded to the canvas dtype or overwritten.  moe_plan_seams gives those rows / columns per tile (8 ints: two row ranges,
+ * two column ranges, tile-local, half-open); a record then travels as [fp16 image of all values | fp32 seam rows | fp32 seam columns]
+ * (moe_wire_words 4-byte words; a record whose seam rows cover it -- a band-mode strip -- is its fp32 values alone).  Unpacked tiles hold the exact
+ * fp32 value in the seams and float(half(v)) elsewhere: an fp16 canvas folded from them is bit-identical to the fp32-wire one. */
+typedef struct moe_wire_rec {
+    int64_t tile_off;                /* fp32 elements into the tile buffer */
+    int64_t wire_off;                /* 4-byte words into the wire buffer */
+    int32_t C, th, tw;               /* planes, rows, columns of the tile (or strip) */
+    int32_t ra0, ra1, rb0, rb1;      /* seam rows [ra0, ra1) and [rb0, rb1), ra1 <= rb0 */
+    int32_t ca0, ca1, cb0, cb1;      /* seam columns likewise */
+    int32_t reserved;
+} moe_wire_rec;
+int moe_plan_seams(const moe_plan* plan, int32_t* seams /* n_tiles x 8 */);
+int64_t moe_wire_words(const moe_wire_rec* rec);
+/* recs_dev: n records on the device; max_elems: the largest C*th*tw among them (sizes the launch). */
+int moe_wire_pack(const float* tiles_dev, void* wire_dev, const moe_wire_rec* recs_dev, int n, int64_t max_elems, void* stream);
+int moe_wire_unpack(float* tiles_dev, const void* wire_dev, const moe_wire_rec* recs_dev, int n, int64_t max_elems, void* stream);
+
 /* doCrop on device: img = (C, Hp, Wp) planes (already padded per moe_plan_info's pad_*_to, see
  * python wrapper), element (c,i,j) at img + c*sC + i*sH + j*sW; out as in moe_stitch.
  * max_tiles_per_batch <= 0 picks a default. */

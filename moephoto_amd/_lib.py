@@ -67,6 +67,10 @@ def lib():
         'moe_plan_tiles': (c_int, [c_vp, P(ctypes.c_int32)]),
         'moe_plan_ramp': (c_int, [c_vp, P(ctypes.c_float)]),
         'moe_plan_rows': (c_int, [c_vp, P(ctypes.c_int32)]),
+        'moe_plan_seams': (c_int, [c_vp, P(ctypes.c_int32)]),
+        'moe_wire_words': (c_i64, [c_vp]),
+        'moe_wire_pack': (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_vp]),
+        'moe_wire_unpack': (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_vp]),
         'moe_plan_pool_elems': (c_i64, [c_vp, c_int]),
         'moe_plan_tile_offsets': (c_int, [c_vp, c_int, P(c_i64)]),
         'moe_stitch': (c_int, [c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_vp]),
@@ -90,7 +94,7 @@ def lib():
 EXPORTS = ['moe_last_error', 'moe_abi_version', 'moe_device_count', 'moe_net_create', 'moe_net_destroy', 'moe_net_scale',
            'moe_net_num_params', 'moe_net_param_info', 'moe_net_set_param', 'moe_net_finalize', 'moe_net_resolved_precision', 'moe_net_workspace_bytes',
            'moe_net_max_tile_pixels', 'moe_net_forward', 'moe_net_set_profile', 'moe_net_get_profile', 'moe_net_get_profile_at', 'moe_net_set_exact_blocks', 'moe_net_set_debug', 'moe_net_set_option', 'moe_device_info', 'moe_stitch_dev', 'moe_stitch_band', 'moe_net_debug_tap', 'moe_plan_create', 'moe_plan_destroy', 'moe_plan_info',
-           'moe_plan_tiles', 'moe_plan_ramp', 'moe_plan_rows', 'moe_plan_pool_elems', 'moe_plan_tile_offsets', 'moe_stitch', 'moe_run_plan',
+           'moe_plan_tiles', 'moe_plan_ramp', 'moe_plan_rows', 'moe_plan_seams', 'moe_wire_words', 'moe_wire_pack', 'moe_wire_unpack', 'moe_plan_pool_elems', 'moe_plan_tile_offsets', 'moe_stitch', 'moe_run_plan',
            'moe_run_plan_ex', 'moe_run_plan_frames', 'moe_run_plan_tiles', 'moe_to_float', 'moe_to_output', 'moe_resize']
 
 

@@ -317,6 +317,18 @@ struct StitchArgs {
 };
 void launch_stitch(const StitchArgs& a, hipStream_t s);
 
+// One record of the inter-rank wire format (moe_wire_pack / moe_wire_unpack; the public moe_wire_rec has the same layout): a tile (or strip) of C planes of
+// th x tw fp32 values <-> [fp16 image of all values | fp32 seam rows | fp32 seam columns], offsets in 4-byte words.
+struct WireRec {
+    long long tile_off, wire_off;
+    int C, th, tw;
+    int ra0, ra1, rb0, rb1;          // seam rows [ra0, ra1) and [rb0, rb1), tile-local, ra1 <= rb0
+    int ca0, ca1, cb0, cb1;          // seam columns likewise
+    int pad_;
+};
+long long wire_rec_words(const WireRec& r);
+void launch_wire(bool pack, float* tiles, unsigned* wire, const WireRec* recs, int n, long long max_elems, hipStream_t s);
+
 void launch_to_float(const void* src, int src_dtype, float inv_or_div, bool divide, int H, int W, int C, void* dst, int dst_dtype, hipStream_t s);
 void launch_to_output(const void* src, int src_dtype, int H, int W, int C, float quant, void* dst, int dst_dtype, hipStream_t s);
 // (C, H, W) -> (C, h, w); mode 0 nearest, 1 bilinear, 2 bicubic (torch F.interpolate semantics, align_corners = False)

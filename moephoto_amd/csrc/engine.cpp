@@ -1774,6 +1774,74 @@ int moe_plan_rows(const moe_plan* p, int32_t* rows)
     return MOE_OK;
 }
 
+// Seam rows / columns of every tile for the wire format (misc_kernels.hip: wire_kernel): per tile 8 ints (ra0, ra1, rb0, rb1, ca0, ca1, cb0, cb1), tile-local.
+// A tile's value is read at full precision inside its OWN blend band and wherever a LATER tile along the axis blends over it; the union of those bands,
+// clipped to the tile, is covered with at most two ranges per axis (more than two are merged into the hull of the second and the rest: a superset is safe).
+static void axis_seams(const std::vector<int>& tab, int i, int out[4])
+{
+    const int n = (int)tab.size() / 4;
+    const int o = tab[i * 4 + 2], ext = tab[i * 4 + 3];
+    std::vector<std::pair<int, int>> iv;
+    for (int k = 0; k < n; ++k) {                      // (earlier tiles' bands lie before the tile; they are taken along for the clipped last tile: a superset is safe)
+        const int a = std::max(tab[k * 4 + 0] - o, 0), b = std::min(tab[k * 4 + 1] - o, ext);
+        if (b > a) iv.push_back({a, b});
+    }
+    std::sort(iv.begin(), iv.end());
+    std::vector<std::pair<int, int>> m;
+    for (auto& v : iv) {
+        if (!m.empty() && v.first <= m.back().second) m.back().second = std::max(m.back().second, v.second);
+        else m.push_back(v);
+    }
+    while (m.size() > 2) { m[1].second = m.back().second; m.pop_back(); }
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (m.size() >= 1) { out[0] = m[0].first; out[1] = m[0].second; out[2] = out[3] = m[0].second; }
+    if (m.size() == 2) { out[2] = m[1].first; out[3] = m[1].second; }
+}
+
+int moe_plan_seams(const moe_plan* p, int32_t* seams)
+{
+    if (!p || !seams) return fail(MOE_EINVAL, "moe_plan_seams: NULL argument");
+    const Plan& q = p->p;
+    for (int i = 0; i < q.ah.step; ++i)
+        for (int j = 0; j < q.aw.step; ++j) {
+            int r[4], c[4];
+            axis_seams(q.row_tab, i, r);
+            axis_seams(q.col_tab, j, c);
+            int32_t* o = seams + ((size_t)i * q.aw.step + j) * 8;
+            for (int e = 0; e < 4; ++e) { o[e] = r[e]; o[4 + e] = c[e]; }
+        }
+    return MOE_OK;
+}
+
+static_assert(sizeof(moe_wire_rec) == sizeof(WireRec) && sizeof(WireRec) == 64, "moe_wire_rec layout");
+
+int64_t moe_wire_words(const moe_wire_rec* rec)
+{
+    if (!rec) return -1;
+    WireRec r;
+    memcpy(&r, rec, sizeof r);
+    return wire_rec_words(r);
+}
+
+static int wire_call(bool pack, float* tiles, void* wire, const moe_wire_rec* recs_dev, int n, int64_t max_elems, void* stream)
+{
+    if (n < 0 || (n > 0 && (!tiles || !wire || !recs_dev))) return fail(MOE_EINVAL, "moe_wire_%s: bad argument", pack ? "pack" : "unpack");
+    launch_wire(pack, tiles, (unsigned*)wire, (const WireRec*)recs_dev, n, max_elems, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MOE_EHIP, "wire kernel launch failed: %s", hipGetErrorString(e));
+    return MOE_OK;
+}
+
+int moe_wire_pack(const float* tiles_dev, void* wire_dev, const moe_wire_rec* recs_dev, int n, int64_t max_elems, void* stream)
+{
+    return wire_call(true, (float*)tiles_dev, wire_dev, recs_dev, n, max_elems, stream);
+}
+
+int moe_wire_unpack(float* tiles_dev, const void* wire_dev, const moe_wire_rec* recs_dev, int n, int64_t max_elems, void* stream)
+{
+    return wire_call(false, tiles_dev, (void*)wire_dev, recs_dev, n, max_elems, stream);
+}
+
 int moe_plan_tiles(const moe_plan* p, int32_t* tiles)
 {
     if (!p || !tiles) return fail(MOE_EINVAL, "moe_plan_tiles: NULL argument");

@@ -2,6 +2,7 @@
 // squeeze-excite pooling / gates, tile stitch, and the uint8/uint16 <-> float image edges.
 // All of them stream NHWC fp16 activations with 16-byte accesses (8 lanes = one 128-B pixel line).
 #include "common.h"
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include "../../include/moephoto_amd.h"
@@ -1096,6 +1097,71 @@ void launch_stitch(const StitchArgs& a, hipStream_t s)
     if (a.out_w % 8 == 0 && a.step_w <= 64 && ((uintptr_t)a.out & 15) == 0) hipLaunchKernelGGL(stitch8r_kernel<4>, dim3((a.out_w / 8 + 255) / 256, (a.rows + 3) / 4, a.C), dim3(256), 0, s, a);
     else if (a.out_w % 4 == 0 && ((uintptr_t)a.out & 15) == 0) hipLaunchKernelGGL(stitch4_kernel, dim3((a.out_w / 4 + 255) / 256, a.rows, a.C), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(stitch_kernel, dim3((a.out_w + 255) / 256, a.rows, a.C), dim3(256), 0, s, a);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Wire format of tile results between ranks (moephoto_amd/dist.py, wire = 'f16s').  The stitch reads a tile's value at full precision only where
+// a blend happens (the tile's own blend band, and the rows / columns a LATER tile blends over: python/imageProcess.py:120-131); everywhere else the
+// value either is the canvas pixel (then it is rounded to the canvas dtype) or is overwritten.  So a tile travels as the fp16 image of all its
+// values plus the fp32 values of its seam rows and seam columns, and unpacking gives back fp32 tiles whose seams are exact and whose interior is
+// float(half(v)): an fp16 canvas folded from them is bit-identical to the one folded from the fp32 tiles, at 0.5 + 0.5 x (seam share) of the bytes.
+// A record whose seam rows cover the tile (a band-mode strip) is just its fp32 values.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wire_slot(int v, int a0, int a1, int b0, int b1)
+{
+    return (v >= a0 && v < a1) ? v - a0 : (v >= b0 && v < b1) ? (a1 - a0) + v - b0 : -1;
+}
+
+template <bool PACK>
+__global__ __launch_bounds__(256) void wire_kernel(float* __restrict__ tiles, unsigned* __restrict__ wire, const WireRec* __restrict__ recs)
+{
+    const WireRec r = recs[blockIdx.y];
+    const int nR = (r.ra1 - r.ra0) + (r.rb1 - r.rb0), nC = (r.ca1 - r.ca0) + (r.cb1 - r.cb0);
+    const bool raw = nR >= r.th;
+    const long long plane = (long long)r.th * r.tw, n = plane * r.C;
+    float* t = tiles + r.tile_off;
+    unsigned* w = wire + r.wire_off;
+    const long long hw = raw ? 0 : (n + 1) / 2;                      // words of the fp16 image
+    half_t* h16 = (half_t*)w;
+    float* rows = (float*)(w + hw);
+    float* cols = rows + (long long)r.C * nR * r.tw;
+    // two consecutive values per thread and step (one 4-byte word of the fp16 image)
+    for (long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 2; e < n; e += (long long)gridDim.x * 512) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long long q = e + u;
+            if (q >= n) break;
+            const int c = (int)(q / plane);
+            const int rem = (int)(q - c * plane);
+            const int y = rem / r.tw, x = rem - y * r.tw;
+            const int ry = wire_slot(y, r.ra0, r.ra1, r.rb0, r.rb1);
+            const int cx = ry >= 0 ? -1 : wire_slot(x, r.ca0, r.ca1, r.cb0, r.cb1);
+            if (PACK) {
+                const float v = t[q];
+                if (!raw) h16[q] = (half_t)v;
+                if (ry >= 0) rows[((long long)c * nR + ry) * r.tw + x] = v;
+                else if (cx >= 0) cols[((long long)c * r.th + y) * nC + cx] = v;
+            } else {
+                t[q] = ry >= 0 ? rows[((long long)c * nR + ry) * r.tw + x] : cx >= 0 ? cols[((long long)c * r.th + y) * nC + cx] : (float)h16[q];
+            }
+        }
+    }
+}
+
+long long wire_rec_words(const WireRec& r)
+{
+    const long long nR = (r.ra1 - r.ra0) + (r.rb1 - r.rb0), nC = (r.ca1 - r.ca0) + (r.cb1 - r.cb0);
+    const long long n = (long long)r.C * r.th * r.tw;
+    if (nR >= r.th) return n;
+    return (n + 1) / 2 + (long long)r.C * nR * r.tw + (long long)r.C * r.th * nC;
+}
+
+void launch_wire(bool pack, float* tiles, unsigned* wire, const WireRec* recs, int n, long long max_elems, hipStream_t s)
+{
+    if (n <= 0) return;
+    const unsigned gx = (unsigned)std::min<long long>(std::max<long long>((max_elems + 2047) / 2048, 1), 4096);     // four steps per thread at most on the largest record
+    if (pack) hipLaunchKernelGGL(wire_kernel<true>, dim3(gx, n), dim3(256), 0, s, tiles, wire, recs);
+    else hipLaunchKernelGGL(wire_kernel<false>, dim3(gx, n), dim3(256), 0, s, tiles, wire, recs);
 }
 
 void launch_to_float(const void* src, int src_dtype, float d, bool divide, int H, int W, int C, void* dst, int dst_dtype, hipStream_t s)

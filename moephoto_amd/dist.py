@@ -19,7 +19,11 @@ embarrassingly parallel decomposition with ONE exchange step:
               of its tile row, and only the pad_sc rows of the NEXT band's first tile row that are blended into this band's last rows travel twice
               (as strips: ~1 % of the bytes).  Every rank folds its own band (moe_stitch_band) and keeps it: the canvas stays sharded.
 
-Nothing is copied around the collective (band mode: but the strips).  `TileExchange` lays ONE device buffer out once per plan,
+  wire        the tiles cross as fp32 (default), or -- wire='f16s' -- as [fp16 image | fp32 seam rows | fp32 seam columns] records (moe_wire_pack /
+              moe_wire_unpack, include/moephoto_amd.h): the fold needs a tile's exact value only where a blend reads it, so an fp16 canvas comes out
+              bit-identical at 0.5 + 0.5 x (seam share) of the bytes on the links.  Pack and unpack are one HBM pass each around the collective.
+
+Nothing is copied around the collective (band mode: but the strips; wire='f16s': the pack / unpack passes).  `TileExchange` lays ONE device buffer out once per plan,
 
     [ own | recv from rank 0 | recv from rank 1 | ... | send to rank 0 | send to rank 1 | ... ]
 
@@ -45,16 +49,24 @@ class TileExchange(object):
 
     tile_elems[k] = fp32 elements of tile k's result (all C planes)."""
 
-    def __init__(self, tile_elems, n_frames, rank, world, group=None, bands=None):
+    def __init__(self, tile_elems, n_frames, rank, world, group=None, bands=None, wire=None):
         """bands: None (frame mode) or (step_w, rows, tile_dims, pad_sc) -- tile columns per tile row, the plan's row table (TilePlan.rows), per tile its
-        (C, height, width) in output pixels, the blend length -- for the band-sharded layout."""
+        (C, height, width) in output pixels, the blend length -- for the band-sharded layout.
+        wire: None (fp32 tiles on the links) or (tile_dims, seams, pad_sc) -- per tile (C, height, width) and TilePlan.seams() -- for the 'f16s' records."""
         self.sizes = [int(v) for v in tile_elems]
         self.n_tiles, self.n_frames = len(self.sizes), int(n_frames)
         self.rank, self.world, self.group = int(rank), int(world), group
         self.bands = bands is not None
+        self.wire = wire is not None
+        self._send_items, self._recv_items = [], []      # (peer, offset in the buffer, tile, is_strip) in wire order
         if self.bands:
             self._init_bands(*bands)
-            return
+        else:
+            self._init_frames()
+        if self.wire:
+            self._init_wire(*wire)
+
+    def _init_frames(self):
         r, W, nt = self.rank, self.world, self.n_tiles
         self.mine = [f for f in range(self.n_frames) if self.stitcher(f) == r]
         # where this rank WRITES its tiles (engine table) and where it READS the tiles of the frames it stitches
@@ -72,6 +84,7 @@ class TileExchange(object):
             if src != r:
                 for f, k in self._segments(src, r):
                     self.stitch_off[f][k] = pos
+                    self._recv_items.append((src, pos, k, False))
                     pos += self.sizes[k]
             self.recv_split.append(pos - n0)
         self.recv_elems = pos - self.own_elems
@@ -81,6 +94,7 @@ class TileExchange(object):
             if dst != r:
                 for f, k in self._segments(r, dst):
                     self.tile_dst[f, k] = pos
+                    self._send_items.append((dst, pos, k, False))
                     pos += self.sizes[k]
             self.send_split.append(pos - n0)
         self.send_elems = pos - self.own_elems - self.recv_elems
@@ -145,6 +159,7 @@ class TileExchange(object):
                     for k, is_strip in wants(r):
                         if self.owner(f, k) == src:
                             self.stitch_off[f][k] = pos
+                            self._recv_items.append((src, pos, k, is_strip))
                             pos += strip_elems[k] if is_strip else self.sizes[k]
             self.recv_split.append(pos - n0)
         self.recv_elems = pos - self.own_elems
@@ -157,6 +172,7 @@ class TileExchange(object):
                     for k, is_strip in wants(dst):
                         if self.owner(f, k) != r:
                             continue
+                        self._send_items.append((dst, pos, k, is_strip))
                         if is_strip:
                             send_strips.append((f, k, pos))
                             pos += strip_elems[k]
@@ -183,6 +199,52 @@ class TileExchange(object):
         for src, C, th, tw, r0, at in self.strip_copies:
             buf[at:at + C * self.pad_sc * tw].view(C, self.pad_sc, tw).copy_(buf[src:src + C * th * tw].view(C, th, tw)[:, r0:r0 + self.pad_sc])
 
+    # ---- wire format -----------------------------------------------------------------------------------
+    def _init_wire(self, tile_dims, seams, pad_sc):
+        """records (moe_wire_rec) of everything this rank sends and receives, and the split sizes of the collective in 4-byte words"""
+        dims = [tuple(int(v) for v in d) for d in tile_dims]
+
+        def table(items):
+            recs = np.zeros(len(items), WIRE_REC)
+            split, pos = [0] * self.world, 0
+            for n, (peer, off, k, is_strip) in enumerate(items):
+                C, th, tw = dims[k]
+                if is_strip:
+                    r = (off, pos, C, int(pad_sc), tw, 0, int(pad_sc), int(pad_sc), int(pad_sc), 0, 0, 0, 0, 0)
+                else:
+                    r = (off, pos, C, th, tw) + tuple(int(v) for v in seams[k]) + (0,)
+                recs[n] = r
+                w = wire_words(r)
+                pos += w
+                split[peer] += w
+            return recs, split, pos
+        self.send_recs, self.wire_send_split, self.wire_send_words = table(self._send_items)
+        self.recv_recs, self.wire_recv_split, self.wire_recv_words = table(self._recv_items)
+        self._wire_dev = {}          # exchange buffer -> (send words, recv words, send records, recv records) on its device
+
+    def _wire_state(self, buf):
+        key = (buf.data_ptr(), str(buf.device))
+        st = self._wire_dev.get(key)
+        if st is None:
+            dev = buf.device
+            up = lambda recs: torch.from_numpy(recs.view(np.uint8).reshape(-1).copy() if len(recs) else np.zeros(0, np.uint8)).to(dev)
+            st = self._wire_dev[key] = (torch.empty(self.wire_send_words, dtype=torch.int32, device=dev), torch.empty(self.wire_recv_words, dtype=torch.int32, device=dev),
+                                        up(self.send_recs), up(self.recv_recs))
+        return st
+
+    def _codec(self, pack, buf, words, recs_np, recs_dev):
+        if not len(recs_np):
+            return
+        if not buf.is_cuda:
+            if CPU_CODEC is None:
+                raise _lib.EngineError('the wire format packs on the GPU (moe_wire_pack); CPU tensors only under the tests\' codec')
+            return CPU_CODEC(pack, buf, words, recs_np)
+        L = _lib.lib()
+        big = int(max(int(r['C']) * int(r['th']) * int(r['tw']) for r in recs_np))
+        stream = torch.cuda.current_stream(buf.device).cuda_stream
+        fn = L.moe_wire_pack if pack else L.moe_wire_unpack
+        _lib.check(fn(buf.data_ptr(), words.data_ptr(), recs_dev.data_ptr(), len(recs_np), big, stream))
+
     def stitch_tables(self, device):
         """{frame: device pointer of its n_tiles int64 stitch offsets}: ONE upload per layout, whatever the number of frames
         this rank stitches (moe_stitch_dev reads the table in place)."""
@@ -208,7 +270,7 @@ class TileExchange(object):
     def signature(self):
         """Order-sensitive digest of everything the ranks must agree on (checked once per layout in run_frames)."""
         h = 1469598103934665603
-        for v in [self.n_tiles, self.n_frames, self.world, int(self.bands)] + self.sizes:
+        for v in [self.n_tiles, self.n_frames, self.world, int(self.bands) + 2 * int(self.wire)] + self.sizes:
             h = ((h ^ int(v)) * 1099511628211) % (1 << 61)
         return h
 
@@ -224,19 +286,55 @@ class TileExchange(object):
             return _Done() if async_op else self.mine
         a, b = self.own_elems, self.own_elems + self.recv_elems
         recv, send = buf[a:b], buf[b:b + self.send_elems]
+        rsplit, ssplit = self.recv_split, self.send_split
+        after = None
+        if self.wire:
+            wsend, wrecv, srecs, rrecs = self._wire_state(buf)
+            self._codec(True, buf, wsend, self.send_recs, srecs)
+            recv, send, rsplit, ssplit = wrecv, wsend, self.wire_recv_split, self.wire_send_split
+            after = lambda: self._codec(False, buf, wrecv, self.recv_recs, rrecs)
         if send.is_cuda and dist.get_backend(self.group) == 'gloo':
             # test mode (several ranks sharing one GPU, MOE_DIST_BACKEND=gloo): stage through the host
-            recv_h = torch.empty(self.recv_elems, dtype=send.dtype)
-            dist.all_to_all_single(recv_h, send.cpu(), self.recv_split, self.send_split, group=self.group)
+            recv_h = torch.empty(recv.numel(), dtype=send.dtype)
+            dist.all_to_all_single(recv_h, send.cpu(), rsplit, ssplit, group=self.group)
             recv.copy_(recv_h)
+            if after:
+                after()
             return _Done() if async_op else self.mine
-        work = dist.all_to_all_single(recv, send, self.recv_split, self.send_split, group=self.group, async_op=async_op)
-        return work if async_op else self.mine
+        work = dist.all_to_all_single(recv, send, rsplit, ssplit, group=self.group, async_op=async_op)
+        if async_op:
+            return _Then(work, after) if after else work
+        if after:
+            after()
+        return self.mine
+
+
+class _Then(object):
+    """an asynchronous collective followed by work on the waiting stream (the unpack pass of the wire format)"""
+    def __init__(self, work, after):
+        self.work, self.after = work, after
+
+    def wait(self):
+        r = self.work.wait()
+        self.after()
+        return r
 
 
 class _Done(object):
     def wait(self):
         return True
+
+
+CPU_CODEC = None             # tests: codec(pack, buf, words, records) on CPU tensors (tests/wire_codec.py); the product packs with moe_wire_pack on the GPU
+WIRE_REC = np.dtype([('tile_off', '<i8'), ('wire_off', '<i8'), ('C', '<i4'), ('th', '<i4'), ('tw', '<i4'), ('ra0', '<i4'), ('ra1', '<i4'), ('rb0', '<i4'), ('rb1', '<i4'),
+                     ('ca0', '<i4'), ('ca1', '<i4'), ('cb0', '<i4'), ('cb1', '<i4'), ('reserved', '<i4')])       # = moe_wire_rec (include/moephoto_amd.h)
+
+
+def wire_words(rec):
+    """4-byte words of one record (= moe_wire_words): fp16 image of all values + fp32 seam rows + fp32 seam columns; a record that is all seam rows is fp32 alone"""
+    _, _, C, th, tw, ra0, ra1, rb0, rb1, ca0, ca1, cb0, cb1 = [int(v) for v in tuple(rec)[:13]]
+    nR, nC, n = (ra1 - ra0) + (rb1 - rb0), (ca1 - ca0) + (cb1 - cb0), C * th * tw
+    return n if nR >= th else (n + 1) // 2 + C * nR * tw + C * th * nC
 
 
 FORCE_COLLECTIVE = False      # tests: issue the all-to-all even on a world of one rank (exercises the RCCL path on a 1-GPU box)
@@ -295,7 +393,7 @@ def _agreed_plan(opt, shape, group, device):
     return it.plan
 
 
-def run_frames_overlapped(opt, frames, group=None, out_dtype=None, max_tiles_per_batch=0):
+def run_frames_overlapped(opt, frames, group=None, out_dtype=None, max_tiles_per_batch=0, wire=None):
     """run_frames for a BATCH of frames (config 4: 64 of them), in groups of `world` frames with the exchange of a group overlapping the convolutions of the
     next: per group every rank computes its share of the group's tiles into one of TWO exchange buffers, starts the all-to-all asynchronously (it runs on
     the backend's stream), enqueues the next group's convolutions, and only then lets its stream wait for the previous group's exchange and folds the frame
@@ -303,7 +401,7 @@ def run_frames_overlapped(opt, frames, group=None, out_dtype=None, max_tiles_per
     from .imageProcess import _DT
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     if len(frames) <= world:
-        return run_frames(opt, frames, group, out_dtype, max_tiles_per_batch, bands=False)
+        return run_frames(opt, frames, group, out_dtype, max_tiles_per_batch, bands=False, wire=wire)
     model = opt.modelCached
     x0 = frames[0]
     dev = x0.device
@@ -324,7 +422,7 @@ def run_frames_overlapped(opt, frames, group=None, out_dtype=None, max_tiles_per
             out[f0 + f] = y
     for gi, f0 in enumerate(range(0, len(frames), world)):
         grp = frames[f0:f0 + world]
-        plan, ex, bufs, padded, fstride = _layout(opt, grp, group, dev, rank, world, C, False, nbuf=2)
+        plan, ex, bufs, padded, fstride = _layout(opt, grp, group, dev, rank, world, C, False, nbuf=2, wire=wire)
         ex._plan = plan
         buf = bufs[gi & 1]
         sC, sH, sW = padded[0].stride()
@@ -340,22 +438,24 @@ def run_frames_overlapped(opt, frames, group=None, out_dtype=None, max_tiles_per
     return out
 
 
-def _layout(opt, frames, group, dev, rank, world, C, bands, nbuf=1):
+def _layout(opt, frames, group, dev, rank, world, C, bands, nbuf=1, wire=None):
     """(plan, exchange layout, its buffer(s), the padded frames, their stride): cached on the Option per (shape, frame count, rank, world, C, mode)."""
     x0 = frames[0]
     plan = _agreed_plan(opt, x0.shape, group, dev)
     cache = opt.__dict__.setdefault('_exchanges', {})
-    ck = (tuple(int(v) for v in x0.shape[-3:]), len(frames), rank, world, C, bands)
+    if wire not in (None, 'f32', 'f16s'):
+        raise ValueError("wire: None | 'f32' | 'f16s'")
+    wire = wire == 'f16s'
+    ck = (tuple(int(v) for v in x0.shape[-3:]), len(frames), rank, world, C, bands, wire)
     ent = cache.get(ck)
     if ent is not None and ent[0] is not plan:               # the entry owns its plan: a layout is only ever used with the plan it was built from
         ent = None
     if ent is None:
         off = plan.tile_offsets(C) + [plan.pool_elems(C)]
-        bspec = None
-        if bands:
-            dims = [(C, (t[1] - t[0]) * plan.sc, (t[3] - t[2]) * plan.sc) for t in plan.tiles]
-            bspec = (plan.stepW, plan.rows, dims, plan.padSc)
-        ex = TileExchange([off[k + 1] - off[k] for k in range(plan.n_tiles)], len(frames), rank, world, group, bands=bspec)
+        dims = [(C, (t[1] - t[0]) * plan.sc, (t[3] - t[2]) * plan.sc) for t in plan.tiles]
+        bspec = (plan.stepW, plan.rows, dims, plan.padSc) if bands else None
+        wspec = (dims, plan.seams(), plan.padSc) if wire else None
+        ex = TileExchange([off[k + 1] - off[k] for k in range(plan.n_tiles)], len(frames), rank, world, group, bands=bspec, wire=wspec)
         if world > 1:       # every rank must have derived the same layout
             sig = torch.tensor([ex.signature()], dtype=torch.int64, device=dev if dist.get_backend(group) != 'gloo' else None)
             lo, hi = sig.clone(), sig.clone()
@@ -383,11 +483,13 @@ def _layout(opt, frames, group, dev, rank, world, C, bands, nbuf=1):
     return plan, ex, bufs, padded, fstride
 
 
-def run_frames(opt, frames, group=None, out_dtype=None, max_tiles_per_batch=0, bands=None):
+def run_frames(opt, frames, group=None, out_dtype=None, max_tiles_per_batch=0, bands=None, wire=None):
     """Tile-parallel doCrop over a list of equally-shaped (C,H,W) frames that every rank holds
     (broadcast them first).  Returns {frame index: stitched (C, sc*H, sc*W) tensor} for the frames
     this rank stitches -- or, in band mode (bands=True; default when there are fewer frames than ranks), {frame index: (first output row, band tensor
-    (C, rows, sc*W))} for every frame: this rank's row band of the canvas, which stays sharded over the ranks (gather_bands concatenates them)."""
+    (C, rows, sc*W))} for every frame: this rank's row band of the canvas, which stays sharded over the ranks (gather_bands concatenates them).
+    wire: None / 'f32' -- fp32 tiles on the links; 'f16s' -- fp16 + fp32 seams (module docstring): for fp16 (or narrower) canvases, where the result is
+    bit-identical; an fp32 canvas would carry fp16-rounded values outside the seams."""
     from .imageProcess import _DT
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     model = opt.modelCached
@@ -397,7 +499,7 @@ def run_frames(opt, frames, group=None, out_dtype=None, max_tiles_per_batch=0, b
     if bands is None:
         bands = world > 1 and len(frames) < world
     bands = bool(bands)
-    plan, ex, bufs, padded, fstride = _layout(opt, frames, group, dev, rank, world, C, bands)
+    plan, ex, bufs, padded, fstride = _layout(opt, frames, group, dev, rank, world, C, bands, wire=wire)
     buf = bufs[0]
     L = _lib.lib()
     stream = torch.cuda.current_stream(dev).cuda_stream

@@ -88,6 +88,12 @@ class TilePlan(object):
         _lib.check(_lib.lib().moe_plan_tile_offsets(self._h, int(C), off))
         return list(off)
 
+    def seams(self):
+        """per tile (ra0, ra1, rb0, rb1, ca0, ca1, cb0, cb1): the rows / columns of the tile a blend reads (moe_plan_seams; the wire format of dist.py)"""
+        t = (ctypes.c_int32 * (8 * self.n_tiles))()
+        _lib.check(_lib.lib().moe_plan_seams(self._h, t))
+        return [tuple(t[k * 8:(k + 1) * 8]) for k in range(self.n_tiles)]
+
     def padImage(self, x):
         """getPad (python/imageProcess.py:47-56) restricted to the region a single-tile axis reads:
         reflect (edge not repeated) up to len-1, then zeros."""

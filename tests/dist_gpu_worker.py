@@ -56,5 +56,23 @@ for fr in (frames[1], torch.from_numpy(gd.natural_image(77, (3, 264, 136))).cuda
     assert torch.equal(whole, want), float((whole.float() - want.float()).abs().max())
     y0, yb = bands[0]
     assert torch.equal(yb, want[:, y0:y0 + yb.shape[1]])
+# wire = 'f16s': fp16 values + fp32 seam rows / columns on the links (moe_wire_pack / moe_wire_unpack around the collective): the fp16 canvases are the same bits,
+# in the frame layout, the overlapped groups and the band layout
+out4 = run_frames(opt, frames, out_dtype=torch.float16, wire='f16s')
+torch.cuda.synchronize()
+assert sorted(out4) == sorted(out)
+for f, y in out4.items():
+    assert torch.equal(y, out[f]), ('wire frames', f, float((y.float() - out[f].float()).abs().max()))
+out5 = run_frames_overlapped(opt, more, out_dtype=torch.float16, wire='f16s')
+torch.cuda.synchronize()
+for f, y in out5.items():
+    assert torch.equal(y, out3[f]), ('wire overlapped', f)
+fr = torch.from_numpy(gd.natural_image(77, (3, 264, 136))).cuda().half()
+whole = gather_bands(run_frames(opt, [fr], out_dtype=torch.float16, wire='f16s')[0])
+torch.cuda.synchronize()
+assert torch.equal(whole, ip.doCrop(opt, fr)), 'wire bands'
+ex = [e for k, e in opt._exchanges.items() if k[-1]][0][1]
+if world > 1:
+    assert 0 < ex.wire_send_words < ex.send_elems, (ex.wire_send_words, ex.send_elems)
 dist.barrier()
 os.write(1, 'RANK {} OK frames {}\n'.format(rank, sorted(out)).encode())      # (one write: the ranks share the pipe)

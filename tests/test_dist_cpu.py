@@ -51,13 +51,38 @@ for rep in range(2):                         # the layout is reused every step
         assert not any(np.isnan(t).any() for t in tiles)
         want = ostitch.fold_stitch([tile_value(f, k) for k in range(nt)], pl, sc)
         assert np.array_equal(ostitch.fold_stitch(tiles, pl, sc), want)
+# ---- wire format 'f16s' (fp16 values + fp32 seam rows / columns on the links): same layout, fp16 canvases bit-identical ---------------------------
+import wire_codec
+from moephoto_amd import dist as mdist
+from moephoto_amd.imageProcess import TilePlan
+mdist.CPU_CODEC = wire_codec.codec           # (the product packs with moe_wire_pack on the GPU; tests/test_gpu_parity.py holds that kernel against this codec)
+seams = TilePlan(shape, 1 << 40, 1e-3, pad, sc, 8, crop).seams()
+dims = [(C, (t[1] - t[0]) * sc, (t[3] - t[2]) * sc) for t in pl.tiles]
+wspec = (dims, seams, pl.pad_sc)
+exw = TileExchange(sizes, frames, rank, world, wire=wspec)
+assert np.array_equal(exw.tile_dst, ex.tile_dst) and exw.total_elems == ex.total_elems and exw.signature() != ex.signature()
+assert sum(exw.wire_send_split) == exw.wire_send_words and sum(exw.wire_recv_split) == exw.wire_recv_words
+if exw.send_elems:
+    assert exw.wire_send_words < 0.9 * exw.send_elems, (exw.wire_send_words, exw.send_elems)
+bufw = torch.full((exw.total_elems,), float('nan'))
+for f in range(frames):
+    for k in exw.tiles_of(f, rank):
+        at = int(exw.tile_dst[f, k])
+        bufw[at:at + sizes[k]] = torch.from_numpy(tile_value(f, k).reshape(-1))
+rounded = 0
+for f in exw.exchange(bufw):
+    tiles = [bufw[int(exw.stitch_off[f][k]):int(exw.stitch_off[f][k]) + sizes[k]].numpy().reshape(dims[k]) for k in range(nt)]
+    rounded += sum(not np.array_equal(t, tile_value(f, k)) for k, t in enumerate(tiles))
+    want = ostitch.fold_stitch([tile_value(f, k) for k in range(nt)], pl, sc)
+    assert np.array_equal(ostitch.fold_stitch(tiles, pl, sc).astype(np.float16), want.astype(np.float16))
+assert rounded > 0 or world == 1             # (the tiles that crossed really were fp16 outside their seams)
 # ---- band-sharded stitch (fewer frames than ranks): every rank folds its own row band of the ONE canvas -------------------------------
 rows_o = ostitch.axis_cover(pl.anchors_h, sc, pl.pad_sc, pl.out_shape[-2])          # (first written, first un-blended, origin) per tile row
 ext = [ (pl.tiles[i * pl.step_w][1] - pl.tiles[i * pl.step_w][0]) * sc for i in range(len(rows_o)) ]
 rows_tab = [(r_[0], r_[1], r_[2], e) for r_, e in zip(rows_o, ext)]
-dims = [(C, (t[1] - t[0]) * sc, (t[3] - t[2]) * sc) for t in pl.tiles]
-for nf in (1, 2):
-    exb = TileExchange(sizes, nf, rank, world, bands=(pl.step_w, rows_tab, dims, pl.pad_sc))
+for nf, wire in ((1, None), (2, None), (1, wspec), (2, wspec)):
+    exb = TileExchange(sizes, nf, rank, world, bands=(pl.step_w, rows_tab, dims, pl.pad_sc), wire=wire)
+    same = (lambda a, b: np.array_equal(a, b)) if wire is None else (lambda a, b: np.array_equal(a.astype(np.float16), b.astype(np.float16)))
     sigs = [None] * world
     dist.all_gather_object(sigs, exb.signature())
     assert len(set(sigs)) == 1
@@ -86,7 +111,7 @@ for nf in (1, 2):
                 at = int(exb.stitch_off[f][k])
                 if i0 <= i < i1:
                     t = bufb[at:at + sizes[k]].numpy().reshape(Cc, th, tw)
-                    assert np.array_equal(t, tile_value(f, k))
+                    assert same(t, tile_value(f, k))
                 elif i == i1:
                     r0 = rows_tab[i][0] - rows_tab[i][2]
                     strip = bufb[at:at + Cc * pl.pad_sc * tw].numpy().reshape(Cc, pl.pad_sc, tw)
@@ -96,7 +121,7 @@ for nf in (1, 2):
             want = ostitch.fold_stitch([tile_value(f, k) for k in range(nt)], pl, sc)
             with np.errstate(invalid='ignore'):
                 got = ostitch.fold_stitch(tiles, pl, sc)
-            assert np.array_equal(got[:, y0:y1], want[:, y0:y1]), (rank, f, y0, y1)      # the band's rows need nothing but its own tiles and that strip
+            assert same(got[:, y0:y1], want[:, y0:y1]), (rank, f, y0, y1)      # the band's rows need nothing but its own tiles and that strip
     total = [None] * world
     dist.all_gather_object(total, (i0, i1))
     assert sorted(set(v for a, b in total for v in range(a, b))) == list(range(nrow))  # the bands tile the canvas

@@ -1115,3 +1115,74 @@ def test_streamed_arsb_is_bit_identical_to_the_patch_form(dev):
     finally:
         for m in touched:
             m.set_option('arsb_impl', 'v3').set_option('max_groups', 0)
+
+
+def test_wire_pack_unpack_kernels_vs_numpy_codec(dev):
+    """moe_wire_pack / moe_wire_unpack (the 'f16s' wire format of dist.py: fp16 image + fp32 seam rows + fp32 seam columns per tile, strips as plain fp32)
+    against tests/wire_codec.py, bit for bit, on the real seams of a plan plus synthetic records (odd sizes, empty ranges, one-range seams, a strip), and the
+    canvas folded from unpacked tiles against the one folded from the fp32 tiles (fp16: same bits)."""
+    import ctypes
+    import wire_codec
+    from moephoto_amd import _lib, dist as mdist, imageProcess as ip
+    L = _lib.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    opt = _opt_sr('a', 2, 64, fp16_io=True)
+    xd = torch.from_numpy(gd.natural_image(9, (3, 150, 200))).to(dev).half()
+    plan = ip._plan_for(opt, xd.shape)
+    seams = plan.seams()
+    dims = [(3, (t[1] - t[0]) * 2, (t[3] - t[2]) * 2) for t in plan.tiles]
+    items = [(d, s) for d, s in zip(dims, seams)]
+    items += [((1, 7, 13), (0, 2, 5, 7, 0, 0, 0, 0)), ((2, 5, 3), (0, 0, 0, 0, 1, 2, 2, 2)), ((3, 10, 24), (0, 10, 10, 10, 0, 0, 0, 0)), ((1, 1, 1), (0, 0, 0, 0, 0, 0, 0, 0)),
+              ((2, 9, 31), (3, 4, 4, 4, 0, 5, 30, 31))]
+    recs = np.zeros(len(items), mdist.WIRE_REC)
+    off = wpos = 0
+    for n, (d, s) in enumerate(items):
+        recs[n] = (off, wpos) + tuple(d) + tuple(s) + (0,)
+        assert mdist.wire_words(recs[n]) == L.moe_wire_words(recs[n:n + 1].ctypes.data)
+        off += d[0] * d[1] * d[2]
+        wpos += mdist.wire_words(recs[n])
+    rng = np.random.default_rng(5)
+    buf = (rng.standard_normal(off) * 0.8).astype(np.float32)
+    buf[::97] *= 1e5                                                       # (beyond fp16: inf in the fp16 image, exact in the seams)
+    want_wire = np.zeros(wpos, np.int32)
+    wire_codec.codec(True, buf, want_wire, recs)
+    want_back = np.full(off, np.nan, np.float32)
+    wire_codec.codec(False, want_back, want_wire, recs)
+    bd = torch.from_numpy(buf).to(dev)
+    rd = torch.from_numpy(recs.view(np.uint8).reshape(-1).copy()).to(dev)
+    wd = torch.zeros(wpos, dtype=torch.int32, device=dev)
+    big = max(d[0] * d[1] * d[2] for d, _ in items)
+    _lib.check(L.moe_wire_pack(bd.data_ptr(), wd.data_ptr(), rd.data_ptr(), len(items), big, stream))
+    # compare only the words the format defines (the column area's entries inside seam rows are never written)
+    back = torch.full((off,), float('nan'), dtype=torch.float32, device=dev)
+    _lib.check(L.moe_wire_unpack(back.data_ptr(), wd.data_ptr(), rd.data_ptr(), len(items), big, stream))
+    torch.cuda.synchronize()
+    got_back = back.cpu().numpy()
+    assert np.array_equal(got_back, want_back, equal_nan=True)
+    got_wire = wd.cpu().numpy()
+    chk = np.full(off, np.nan, np.float32)
+    wire_codec.codec(False, chk, got_wire, recs)                           # the device's wire decodes, with the CPU codec, to the same tiles
+    assert np.array_equal(chk, want_back, equal_nan=True)
+    # the fold of a real frame: fp32 tiles -> pack -> unpack -> stitch == stitch of the fp32 tiles, as fp16
+    pool = torch.empty(plan.pool_elems(3), dtype=torch.float32, device=dev)
+    canvas = torch.empty((3, plan.outH, plan.outW), dtype=torch.float16, device=dev)
+    sC, sH, sW = xd.stride()
+    _lib.check(L.moe_run_plan_ex(opt.modelCached._h, plan._h, xd.data_ptr(), _lib.F16, sC, sH, sW, canvas.data_ptr(), _lib.F16, 0, ctypes.c_void_p(pool.data_ptr()), 0, 1, 1, stream))
+    offs = plan.tile_offsets(3)
+    recs2 = np.zeros(plan.n_tiles, mdist.WIRE_REC)
+    wpos = 0
+    for k in range(plan.n_tiles):
+        recs2[k] = (offs[k], wpos) + dims[k] + tuple(seams[k]) + (0,)
+        wpos += mdist.wire_words(recs2[k])
+    assert wpos * 4 < 0.85 * pool.numel() * 4
+    rd2 = torch.from_numpy(recs2.view(np.uint8).reshape(-1).copy()).to(dev)
+    wd2 = torch.empty(wpos, dtype=torch.int32, device=dev)
+    pool2 = torch.full_like(pool, float('nan'))
+    big = max(d[0] * d[1] * d[2] for d in dims)
+    _lib.check(L.moe_wire_pack(pool.data_ptr(), wd2.data_ptr(), rd2.data_ptr(), plan.n_tiles, big, stream))
+    _lib.check(L.moe_wire_unpack(pool2.data_ptr(), wd2.data_ptr(), rd2.data_ptr(), plan.n_tiles, big, stream))
+    tab = torch.tensor(offs, dtype=torch.int64, device=dev)
+    canvas2 = torch.empty_like(canvas)
+    _lib.check(L.moe_stitch_dev(plan._h, 0, pool2.data_ptr(), ctypes.c_void_p(tab.data_ptr()), 3, canvas2.data_ptr(), _lib.F16, stream))
+    torch.cuda.synchronize()
+    assert not torch.equal(pool2, pool) and torch.equal(canvas2, canvas)

@@ -229,3 +229,50 @@ def test_video_buffer_edges_and_frame_loop():
     assert procedure.runFrames(process, io.BytesIO(raw).read, out.append, w, h, bitDepth=16, stop=0) == 1
     with pytest.raises(ValueError):
         procedure.runFrames(process, io.BytesIO(raw[:-5]).read, out.append, w, h, bitDepth=16)
+
+
+@pytest.mark.parametrize('case', [c for c in PLANNER['prepare'] if len(c['tiles']) > 1 and int(np.prod(c['out_shape'])) <= 3e7], ids=lambda c: 'x'.join(map(str, c['shape'])) + '_c{}'.format(c['cropsize']))
+def test_wire_format_seams_keep_fp16_canvases_bit_identical(case):
+    """The inter-rank wire format (include/moephoto_amd.h: moe_plan_seams / moe_wire_*; moephoto_amd/dist.py wire='f16s') sends fp16 values plus the fp32
+    values of the seam rows / columns.  Host-side proof on the planner's golden cases, with the numpy restatement of the pack / unpack passes and the
+    oracle's fold: a canvas folded from round-tripped tiles equals, after rounding to fp16, the canvas folded from the fp32 tiles -- and rounding the
+    WHOLE tile to fp16 does not (the seams are needed)."""
+    import wire_codec
+    from moephoto_amd import dist as mdist
+    from moephoto_amd.imageProcess import TilePlan
+    from oracle import planner as oplanner, stitch as ostitch
+    C, sc = case['shape'][0], case['sc']
+    pl = TilePlan(case['shape'], case['ram'], case['ram_coef'], case['pad'], sc, case['align'], case['cropsize'])
+    opl = oplanner.prepare(tuple(case['shape']), case['ram'], case['ram_coef'], case['pad'], sc, case['align'], case['cropsize'])
+    seams = pl.seams()
+    dims = [(C, (t[1] - t[0]) * sc, (t[3] - t[2]) * sc) for t in pl.tiles]
+    rng = np.random.default_rng(3)
+    tiles = [(rng.standard_normal(d) * 0.7 + 0.4).astype(np.float32) for d in dims]
+    recs = np.zeros(len(dims), mdist.WIRE_REC)
+    off = wpos = 0
+    for k, d in enumerate(dims):
+        recs[k] = (off, wpos) + d + tuple(seams[k]) + (0,)
+        words = mdist.wire_words(recs[k])
+        assert words == _lib.lib().moe_wire_words(recs[k:k + 1].ctypes.data)
+        s = seams[k]
+        assert 0 <= s[0] <= s[1] <= s[2] <= s[3] <= d[1] and 0 <= s[4] <= s[5] <= s[6] <= s[7] <= d[2]
+        off += d[0] * d[1] * d[2]
+        wpos += words
+    buf = np.concatenate([t.reshape(-1) for t in tiles])
+    wire = np.zeros(wpos, np.int32)
+    wire_codec.codec(True, buf, wire, recs)
+    back = np.full_like(buf, np.nan)
+    wire_codec.codec(False, back, wire, recs)
+    got = [back[int(r['tile_off']):int(r['tile_off']) + d[0] * d[1] * d[2]].reshape(d) for r, d in zip(recs, dims)]
+    for k, (t, g) in enumerate(zip(tiles, got)):
+        s = seams[k]
+        m = np.zeros(t.shape, bool)
+        m[:, s[0]:s[1]] = m[:, s[2]:s[3]] = True
+        m[:, :, s[4]:s[5]] = m[:, :, s[6]:s[7]] = True
+        assert np.array_equal(g[m], t[m]) and np.array_equal(g[~m], t.astype(np.float16).astype(np.float32)[~m])
+    want = ostitch.fold_stitch(tiles, opl, sc)
+    assert np.array_equal(ostitch.fold_stitch(got, opl, sc).astype(np.float16), want.astype(np.float16))
+    if case['pad'] > 0:
+        crude = ostitch.fold_stitch([t.astype(np.float16).astype(np.float32) for t in tiles], opl, sc)
+        assert not np.array_equal(crude.astype(np.float16), want.astype(np.float16))
+    assert wpos * 4 < 0.95 * buf.nbytes or min(d[1] for d in dims) < 6 * case['pad'] * sc
