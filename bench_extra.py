@@ -48,12 +48,12 @@ def io_edges(torch, _lib, dev):
     src = torch.randint(0, 256, (H, W, 3), dtype=torch.uint8, device=dev)
     dst = torch.empty((3, H, W), dtype=torch.float16, device=dev)
     ms = _events_ms(torch, lambda: _lib.check(L.moe_to_float(src.data_ptr(), _lib.U8, 8, H, W, 3, dst.data_ptr(), _lib.F16, dev.index or 0, stream)), 20)
-    out['u8_to_fp16_1080p'] = _hbm_obj('to_float_kernel<uint8, half>', '1920x1080x3 interleaved uint8 -> 3 planes fp16 (v / 255)', H * W * 3 * (1 + 2), ms)
+    out['u8_to_fp16_1080p'] = _hbm_obj('to_float3_kernel<uint8, half> (eight pixels per thread)', '1920x1080x3 interleaved uint8 -> 3 planes fp16 (v / 255)', H * W * 3 * (1 + 2), ms)
     H, W = 4320, 7680
     can = torch.rand((3, H, W), device=dev).half()
     o8 = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
     ms = _events_ms(torch, lambda: _lib.check(L.moe_to_output(can.data_ptr(), _lib.F16, H, W, 3, 8, o8.data_ptr(), _lib.U8, dev.index or 0, stream)), 10)
-    out['fp16_to_u8_8k'] = _hbm_obj('to_output_kernel<half, uint8>', '3 planes fp16 7680x4320 -> interleaved uint8 (x 256, clamp, truncate)', H * W * 3 * (2 + 1), ms)
+    out['fp16_to_u8_8k'] = _hbm_obj('to_output3_kernel<half, uint8> (eight pixels per thread)', '3 planes fp16 7680x4320 -> interleaved uint8 (x 256, clamp, truncate)', H * W * 3 * (2 + 1), ms)
     out['note'] = 'excluded from `value` (SURVEY 8(d)); beside a 24-ms frame the two passes add %.3f ms' % (out['u8_to_fp16_1080p']['ms'] + out['fp16_to_u8_8k']['ms'])
     return out
 

@@ -1005,6 +1005,49 @@ __global__ void to_output_kernel(const TS* src, TD* dst, int H, int W, int C, fl
     dst[idx] = (TD)(int)v;
 }
 
+// Three-channel images, eight pixels per thread (H * W % 8 == 0, aligned bases): the per-element kernels above move one 1..4-byte element per thread with a
+// stride of C elements on the interleaved side (1.3 TB/s on the 8K canvas); here a thread moves 8 x 3 interleaved elements as one contiguous run and 8
+// consecutive elements of each plane as one vector.  Same arithmetic per element.
+template <typename T, int N> struct alignas(sizeof(T) * 8 >= 16 ? 16 : 8) VecN { T e[N]; };      // (a run of 8 or 24 elements starting at a multiple of 8 elements)
+
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void to_float3_kernel(const TS* __restrict__ src, TD* __restrict__ dst, long long HW, float d, bool divide)
+{
+    const long long p0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (p0 >= HW) return;
+    const VecN<TS, 24> in = *(const VecN<TS, 24>*)(src + p0 * 3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        VecN<TD, 8> o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = (float)in.e[e * 3 + c];
+            o.e[e] = (TD)(divide ? v / d : v * d);
+        }
+        *(VecN<TD, 8>*)(dst + c * HW + p0) = o;
+    }
+}
+
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void to_output3_kernel(const TS* __restrict__ src, TD* __restrict__ dst, long long HW, float quant)
+{
+    const long long p0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (p0 >= HW) return;
+    VecN<TD, 24> o;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const VecN<TS, 8> in = *(const VecN<TS, 8>*)(src + c * HW + p0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = (float)in.e[e] * quant;
+            v = fminf(fmaxf(v, 0.f), quant - 1.f);
+            if (!(v == v)) v = 0.f;
+            o.e[e * 3 + c] = (TD)(int)v;
+        }
+    }
+    *(VecN<TD, 24>*)(dst + p0 * 3) = o;
+}
+
 __global__ void nhwc_to_nchw_kernel(const half_t* in, const half_t* in_lo, float* out, int B, int H, int W, int cs, int C)
 {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -1166,8 +1209,20 @@ void launch_wire(bool pack, float* tiles, unsigned* wire, const WireRec* recs, i
 
 void launch_to_float(const void* src, int src_dtype, float d, bool divide, int H, int W, int C, void* dst, int dst_dtype, hipStream_t s)
 {
-    const long long n = (long long)H * W * C;
-    const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+    const long long n = (long long)H * W * C, HW = (long long)H * W;
+    const dim3 blk(256);
+    if (C == 3 && HW % 8 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        const dim3 g3((unsigned)((HW / 8 + 255) / 256));
+        if (src_dtype == MOE_U8) {
+            if (dst_dtype == MOE_F16) hipLaunchKernelGGL((to_float3_kernel<uint8_t, half_t>), g3, blk, 0, s, (const uint8_t*)src, (half_t*)dst, HW, d, divide);
+            else hipLaunchKernelGGL((to_float3_kernel<uint8_t, float>), g3, blk, 0, s, (const uint8_t*)src, (float*)dst, HW, d, divide);
+        } else {
+            if (dst_dtype == MOE_F16) hipLaunchKernelGGL((to_float3_kernel<uint16_t, half_t>), g3, blk, 0, s, (const uint16_t*)src, (half_t*)dst, HW, d, divide);
+            else hipLaunchKernelGGL((to_float3_kernel<uint16_t, float>), g3, blk, 0, s, (const uint16_t*)src, (float*)dst, HW, d, divide);
+        }
+        return;
+    }
+    const dim3 grid((unsigned)((n + 255) / 256));
     if (src_dtype == MOE_U8) {
         if (dst_dtype == MOE_F16) hipLaunchKernelGGL((to_float_kernel<uint8_t, half_t>), grid, blk, 0, s, (const uint8_t*)src, (half_t*)dst, H, W, C, d, divide);
         else hipLaunchKernelGGL((to_float_kernel<uint8_t, float>), grid, blk, 0, s, (const uint8_t*)src, (float*)dst, H, W, C, d, divide);
@@ -1179,8 +1234,20 @@ void launch_to_float(const void* src, int src_dtype, float d, bool divide, int H
 
 void launch_to_output(const void* src, int src_dtype, int H, int W, int C, float quant, void* dst, int dst_dtype, hipStream_t s)
 {
-    const long long n = (long long)H * W * C;
-    const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+    const long long n = (long long)H * W * C, HW = (long long)H * W;
+    const dim3 blk(256);
+    if (C == 3 && HW % 8 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        const dim3 g3((unsigned)((HW / 8 + 255) / 256));
+        if (src_dtype == MOE_F16) {
+            if (dst_dtype == MOE_U8) hipLaunchKernelGGL((to_output3_kernel<half_t, uint8_t>), g3, blk, 0, s, (const half_t*)src, (uint8_t*)dst, HW, quant);
+            else hipLaunchKernelGGL((to_output3_kernel<half_t, uint16_t>), g3, blk, 0, s, (const half_t*)src, (uint16_t*)dst, HW, quant);
+        } else {
+            if (dst_dtype == MOE_U8) hipLaunchKernelGGL((to_output3_kernel<float, uint8_t>), g3, blk, 0, s, (const float*)src, (uint8_t*)dst, HW, quant);
+            else hipLaunchKernelGGL((to_output3_kernel<float, uint16_t>), g3, blk, 0, s, (const float*)src, (uint16_t*)dst, HW, quant);
+        }
+        return;
+    }
+    const dim3 grid((unsigned)((n + 255) / 256));
     if (src_dtype == MOE_F16) {
         if (dst_dtype == MOE_U8) hipLaunchKernelGGL((to_output_kernel<half_t, uint8_t>), grid, blk, 0, s, (const half_t*)src, (uint8_t*)dst, H, W, C, quant);
         else hipLaunchKernelGGL((to_output_kernel<half_t, uint16_t>), grid, blk, 0, s, (const half_t*)src, (uint16_t*)dst, H, W, C, quant);

@@ -1186,3 +1186,38 @@ def test_wire_pack_unpack_kernels_vs_numpy_codec(dev):
     _lib.check(L.moe_stitch_dev(plan._h, 0, pool2.data_ptr(), ctypes.c_void_p(tab.data_ptr()), 3, canvas2.data_ptr(), _lib.F16, stream))
     torch.cuda.synchronize()
     assert not torch.equal(pool2, pool) and torch.equal(canvas2, canvas)
+
+
+def test_io_edges_vector_and_element_forms_agree(dev):
+    """moe_to_float / moe_to_output (toTorch / toOutput, python/imageProcess.py:245-263): three-channel images whose pixel count is a multiple of 8 take the
+    eight-pixels-per-thread kernels, everything else the per-element ones.  Both against the oracle's edges, bit for bit, for uint8 / uint16 against fp16 /
+    fp32, with NaN, negative, > 1 and exactly-on-a-level values on the way out."""
+    from moephoto_amd import _lib
+    L = _lib.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(11)
+    for (H, W, C) in ((64, 40, 3), (7, 9, 3), (16, 24, 1), (33, 8, 3), (5, 8, 4)):
+        for bits, np_t, lib_t in ((8, np.uint8, _lib.U8), (16, np.uint16, _lib.U16), (10, np.uint16, _lib.U16)):
+            img = rng.integers(0, 1 << bits, (H, W, C)).astype(np_t)
+            want = oio.to_float_image(img, bits)
+            src = torch.from_numpy(img.view(np.int16) if np_t is np.uint16 else img).to(dev)
+            for dt, ldt in ((torch.float32, _lib.F32), (torch.float16, _lib.F16)):
+                dst = torch.full((C, H, W), float('nan'), dtype=dt, device=dev)
+                _lib.check(L.moe_to_float(src.data_ptr(), lib_t, bits, H, W, C, dst.data_ptr(), ldt, 0, stream))
+                w = torch.from_numpy(want).to(dt)
+                assert torch.equal(dst.cpu(), w), (H, W, C, bits, dt)
+            y = (rng.standard_normal((C, H, W)) * 0.6 + 0.5).astype(np.float32)
+            y.reshape(-1)[::13] = np.nan
+            y.reshape(-1)[1::17] = np.float32(37) / np.float32(1 << min(bits, 8))
+            for dt, ldt in ((torch.float32, _lib.F32), (torch.float16, _lib.F16)):
+                yd = torch.from_numpy(y).to(dev).to(dt)
+                out = torch.zeros((H, W, C), dtype=torch.uint8 if bits <= 8 else torch.int16, device=dev)
+                _lib.check(L.moe_to_output(yd.data_ptr(), ldt, H, W, C, bits, out.data_ptr(), lib_t, 0, stream))
+                got = out.cpu().numpy()
+                got = got.view(np.uint16) if bits > 8 else got
+                yy = yd.float().cpu().numpy()
+                q = np.float32(1 << bits)
+                with np.errstate(invalid='ignore'):
+                    ref = np.clip(yy * q, 0, q - 1)
+                ref = np.where(np.isnan(ref), 0, ref).astype(np.int64).transpose(1, 2, 0)
+                assert np.array_equal(got.astype(np.int64), ref), (H, W, C, bits, dt)
