@@ -184,6 +184,9 @@ hipError_t conv64_x3_init();
 // the same conv with its two correction products on fp8 operands (conv64_q8.hip); false: not applicable (caller uses conv64_x3)
 bool launch_conv64_q8(ConvX3Args a, int max_groups, hipStream_t s);
 hipError_t conv64_q8_init();
+// the chain form of that layer (fp8 low parts in) streamed down a column by one fp16 wave + one fp8 wave per workgroup (conv64_sq.hip); false: not applicable (caller uses conv64_q8)
+bool launch_conv64_sq(ConvX3Args a, int max_groups, hipStream_t s);
+hipError_t conv64_sq_init();
 
 // Workgroup count of a launch whose epilogue pools per plane into per-workgroup slabs (conv3x3_rw EPI 4, conv64_x3 EPI 3): a multiple or a divisor
 // of the patches per plane P, so that the patch -> workgroup map (item % G with item = plane * P + k) -- and with it every slab's content and

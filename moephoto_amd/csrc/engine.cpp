@@ -97,6 +97,7 @@ struct NetOptions {
     int x3_impl = 0;          // x3_impl     auto (0, default: q8 for the SR nets, x3 for the DN nets -- see forward) | x3 (1: conv64_x3.hip, three fp16 products) |
                               //             q8 (2: conv64_q8.hip, the two correction products on fp8 operands)
     int k48 = 1;              // k48         1 (default): kernels that can skip the zero k-slice of the 48-channel nets do | 0: they run all four (A/B)
+    int q8_impl = 1;          // q8_impl     s (1, default: conv64_sq.hip, the chain layers streamed down a column by an fp16 wave + an fp8 wave) | p (0: conv64_q8.hip, 8 x 32 patches)
     int arsb_impl = 3;        // arsb_impl   v3 (3, default: arsb32c.hip, ten-row patches) | s (4: arsb_s.hip, rows streamed down 30-pixel columns by two-wave workgroups:
                               //             bit-identical, measured 7 % SLOWER -- both forms sit at the package power cap with the same MFMA rate (busy x clock 0.73 x 1.65
                               //             vs 0.69 x 1.74 GHz) and the streamed one issues 9 % more MFMAs on rows it recomputes at range starts; kept as the A/B)
@@ -134,6 +135,7 @@ struct NetOptions {
         if (key == "lo8") { const int t = onoff(v); if (t < 0) return false; lo8 = t; return true; }
         if (key == "x3_impl") { const int t = tri(v, "auto", "x3", "q8", -1); if (t < 0) return false; x3_impl = t; return true; }
         if (key == "k48") { const int t = onoff(v); if (t < 0) return false; k48 = t; return true; }
+        if (key == "q8_impl") { if (v && !strcmp(v, "s")) q8_impl = 1; else if (v && !strcmp(v, "p")) q8_impl = 0; else return false; return true; }
         if (key == "arsb_impl") { if (v && !strcmp(v, "s")) arsb_impl = 4; else if (v && !strcmp(v, "v3")) arsb_impl = 3; else return false; return true; }
         if (key == "conv1x1") return flag(conv1x1);
         if (key == "x3_fuse") return flag(x3_fuse);
@@ -150,7 +152,7 @@ struct NetOptions {
     void from_env()
     {
         static const char* const names[][2] = {{"MOE_CONV_IMPL", "conv_impl"}, {"MOE_SP_IMPL", "sp_impl"}, {"MOE_TAIL_SPLIT", "tail_split"}, {"MOE_TAIL_FORM", "tail_form"}, {"MOE_UP_IMPL", "up_impl"},
-                                               {"MOE_CONV1X1", "conv1x1"}, {"MOE_ARSB_IMPL", "arsb_impl"}, {"MOE_K48", "k48"}, {"MOE_X3_IMPL", "x3_impl"}, {"MOE_LO8", "lo8"}, {"MOE_X3_FUSE", "x3_fuse"}, {"MOE_ARSB_FUSE", "arsb_fuse"}, {"MOE_FUSE_TAIL", "fuse_tail"},
+                                               {"MOE_CONV1X1", "conv1x1"}, {"MOE_ARSB_IMPL", "arsb_impl"}, {"MOE_Q8_IMPL", "q8_impl"}, {"MOE_K48", "k48"}, {"MOE_X3_IMPL", "x3_impl"}, {"MOE_LO8", "lo8"}, {"MOE_X3_FUSE", "x3_fuse"}, {"MOE_ARSB_FUSE", "arsb_fuse"}, {"MOE_FUSE_TAIL", "fuse_tail"},
                                                {"MOE_SEDN_FUSE", "sedn_fuse"}, {"MOE_POOL_FUSE", "pool_fuse"}, {"MOE_DBG", "dbg"}, {"MOE_TRACE_KEY", "trace_key"},
                                                {"MOE_TILES_PER_BATCH", "tiles_per_batch"}, {"MOE_MAX_GROUPS", "max_groups"}};
         for (const auto& nv : names)
@@ -855,7 +857,8 @@ struct Fwd {
                     ConvX3Args q8 = q;
                     q8.wq_hi16 = blob<half_t>(L.w_hi); q8.wq_hi8 = blob<unsigned char>(L.wq_hi8); q8.wq_lo8 = blob<unsigned char>(L.wq_lo8);
                     q8.in8 = in.lo8; q8.out8 = out.lo8;
-                    ok = launch_conv64_q8(q8, n.max_groups, s);
+                    if (n.opt.q8_impl == 1) ok = launch_conv64_sq(q8, n.max_groups, s);
+                    if (!ok) ok = launch_conv64_q8(q8, n.max_groups, s);
                 }
                 if (!ok && any8) { prof_end(rec); return false; }
                 if (!ok) ok = launch_conv64_x3(q, n.max_groups, s);
