@@ -42,12 +42,13 @@ def main():
                 m.set_option('max_groups', 0)
                 d = np.abs(y_s - y_p)
                 line = '%s %-7s %-12s s vs p %.3e' % (key, kind, shape, d.max())
-                if not (d.max() <= 3e-5):
+                if not (d.max() <= 6e-4):      # (the fp8 low words between the layers turn fp32-rounding differences of a sum into differences of a few 1e-5 .. 1e-4 at the output)
                     i = np.unravel_index(np.argmax(d), d.shape)
                     line += ' at plane %d Y %d X %d' % (i[0], i[-2], i[-1])
                     bad += 1
                 want = onets.forward(arch, sd, x).numpy()
                 line += ' | vs oracle: s %.3e p %.3e' % (np.abs(y_s - want).max(), np.abs(y_p - want).max())
+                bad += not (np.abs(y_s - want).max() <= 1e-3)
                 line += ' | repeat %s, 7 workgroups %s' % ('same bits' if np.array_equal(y_s, y_s2) else 'DIFFERS %.3e' % np.abs(y_s - y_s2).max(),
                                                              'same bits' if np.array_equal(y_s, y_g) else 'DIFFERS %.3e' % np.abs(y_s - y_g).max())
                 bad += (not np.array_equal(y_s, y_s2)) + (not np.array_equal(y_s, y_g)) + (not np.isfinite(y_s).all())
