@@ -16,7 +16,7 @@
 //   rows          two-row blocks, three blocks per ring (in use / landed / in flight); ONE barrier of the two waves per row step (it publishes the image row, and
 //                 in the first step of a block -- behind a counted vmcnt -- the block after it)
 //   ranges        a workgroup streams a contiguous range of two-row blocks (column-major, as arsb_s.hip); a range [ya, yb) runs input rows ya-1 .. yb+2
-//   LDS           a_hi 3 x 9,216 + a_lo8 3 x 5,120 + a_hi8 2 x 2,304 + 1,024 (+ EPI 2: residual 3 x 8,192) = 48,640 (73,216) bytes: two workgroups per CU
+//   LDS           a_hi 3 x 9,216 + a_lo8 3 x 5,120 + a_hi8 2 x 2,304 + 1,024 + DMA offset table 5,120 (+ EPI 2: residual 3 x 8,192) = 53,760 (78,336) bytes: two workgroups per CU
 //
 // A first form gave the fp16 product to one wave (64 channels: six MFMAs per fragment read) and both fp8 products to the other, with the correction handed over
 // through LDS as fp16: correct, and only 3-10 % faster than conv64_q8.hip -- the fp16 wave carried the whole epilogue (~250 VALU instructions in the half step
@@ -34,9 +34,16 @@
 #define SQ_FILL 5
 #endif
 // timing experiments (tools/mk_variant.sh; results of such builds are WRONG by design): 1 no DMA waits, 2 no DMA, 8 no epilogue (accumulators kept live), 16 no fp8 image,
-// 32 stores of a row as contiguous KiBs (what coalesced stores would cost)
+// 32 stores of a row as contiguous KiBs (what coalesced stores would cost), 64 no loads of the residual's low words, 128 stores issued and dropped
 #ifndef SQ_ABL
 #define SQ_ABL 0
+#endif
+// cache policy bits of the stores / the DMA loads (gfx942+: 1 sc0, 2 nt, 16 sc1): the tensors stream through once
+#ifndef SQ_STAUX
+#define SQ_STAUX 0
+#endif
+#ifndef SQ_LDAUX
+#define SQ_LDAUX 0
 #endif
 
 namespace {
@@ -50,8 +57,9 @@ constexpr int NRING = 3;
 constexpr int OFF_LO8 = NRING * BLKB;          // 27,648
 constexpr int OFF_Q8 = OFF_LO8 + NRING * BLKB8;   // 43,008
 constexpr int OFF_DUMP = OFF_Q8 + 2 * ROWB8;   // 47,616: where the pieces that do not exist land (wave 1's fifth a_hi piece, its third a_lo8 piece)
-constexpr int OFF_RES = OFF_DUMP + 1024;       // 48,640
-constexpr int LDS_PLAIN = OFF_RES, LDS_RES = OFF_RES + NRING * RESBLKB;      // 48,640 / 73,216
+constexpr int OFF_TAB = OFF_DUMP + 1024;       // 48,640: the lanes' DMA source offsets of the range, [entry 10][thread 128] words
+constexpr int OFF_RES = OFF_TAB + 10 * 512;    // 53,760
+constexpr int LDS_PLAIN = OFF_RES, LDS_RES = OFF_RES + NRING * RESBLKB;      // 53,760 / 78,336
 
 typedef unsigned u4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u2_t __attribute__((ext_vector_type(2)));
@@ -67,36 +75,57 @@ struct OpList {
     Op op[64] = {};
     constexpr void push(int kind, int a = 0, int b = 0, int c = 0) { op[n] = Op{kind, a, b, c}; ++n; }
 };
-// The ops of a row step in issue order, dealt to its 12 chunks proportionally: e = 1: the wave's DMA pieces of the block after the next; the wave's two units
-// of the next row's fp8 image (in LDS before the barrier at chunk 10); the two 16-byte slots of output row r - 2 -- [residual word from the ring, sums,]
-// [PReLU,] split, stores -- and LAST the residual's low words of the row two steps on (arsb_s.hip: no store is issued behind them before they are consumed)
-constexpr OpList step_ops(int e, int epi, int np)
+// The side work of a row step, two lists dealt to its chunks proportionally.  dma_ops (e = 1, chunks 0..7): the wave's DMA pieces of the block after the next --
+// half 0: the lane's table word, half 1: select + issue; the word of piece i + 1 is read in front of piece i's issue.  step_ops (chunks 0..11, behind the
+// chunk's DMA ops): the wave's two units of the next row's fp8 image (in LDS before the barrier at chunk 10); the two 16-byte slots of output row r - 2 --
+// [residual word from the ring, sums,] [PReLU,] split, stores -- and LAST the residual's low words of the row two steps on (arsb_s.hip: no store is issued
+// behind them before they are consumed).  LDS reads sit ahead of their consumers with something else in between.
+constexpr OpList dma_ops(int e, int np)
 {
     OpList r;
-    if (e == 1 && !(SQ_ABL & 2)) for (int i = 0; i < np; ++i) { r.push(OP_DMA, i, 0); r.push(OP_DMA, i, 1); }
-    if (!(SQ_ABL & 16)) { r.push(OP_CVR, 0); r.push(OP_CVR, 1); r.push(OP_CVW, 0); r.push(OP_CVW, 1); }
-    if (!(SQ_ABL & 8)) {
-        for (int o = 0; o < 2; ++o) {
-            if (epi == 2) { r.push(OP_RHI, o); r.push(OP_ADD, o, 0); r.push(OP_ADD, o, 2); }
-            if (epi == 1) { r.push(OP_ACT, o, 0); r.push(OP_ACT, o, 4); }
-            r.push(OP_SPL, o, 0); r.push(OP_SPL, o, 2);
-            r.push(OP_ST, o);
-        }
-        if (epi == 2) { r.push(OP_XLO, 0); r.push(OP_XLO, 1); }
+    if (e == 1 && !(SQ_ABL & 2)) {
+        for (int i = 0; i < np; ++i) { r.push(OP_DMA, i, 0); if (i >= 1) r.push(OP_DMA, i - 1, 1); }
+        r.push(OP_DMA, np - 1, 1);
     }
     return r;
 }
+constexpr OpList step_ops(int epi)
+{
+    OpList r;
+    if (!(SQ_ABL & 16)) r.push(OP_CVR, 0);
+    if (!(SQ_ABL & 8)) {
+        if (epi == 2) r.push(OP_RHI, 0);
+        if (epi == 2) { r.push(OP_ADD, 0, 0); r.push(OP_ADD, 0, 2); }
+        if (epi == 1) { r.push(OP_ACT, 0, 0); r.push(OP_ACT, 0, 4); }
+        if (!(SQ_ABL & 16)) { r.push(OP_CVW, 0); r.push(OP_CVR, 1); }
+        if (epi == 2) r.push(OP_RHI, 1);
+        r.push(OP_SPL, 0, 0); r.push(OP_SPL, 0, 2);
+        if (!(SQ_ABL & 16)) r.push(OP_CVW, 1);
+        r.push(OP_ST, 0);
+        if (epi == 2) { r.push(OP_ADD, 1, 0); r.push(OP_ADD, 1, 2); }
+        if (epi == 1) { r.push(OP_ACT, 1, 0); r.push(OP_ACT, 1, 4); }
+        r.push(OP_SPL, 1, 0); r.push(OP_SPL, 1, 2);
+        r.push(OP_ST, 1);
+        if (epi == 2 && !(SQ_ABL & 64)) { r.push(OP_XLO, 0); r.push(OP_XLO, 1); }
+    } else if (!(SQ_ABL & 16)) { r.push(OP_CVW, 0); r.push(OP_CVR, 1); r.push(OP_CVW, 1); }
+    return r;
+}
+// the image's writes are dealt to chunks in front of the barrier (chunk 10)
+constexpr bool cvw_in_time(int epi)
+{
+    const OpList l = step_ops(epi);
+    for (int i = 0; i < l.n; ++i) if (l.op[i].kind == OP_CVW && i >= 10 * l.n / 12) return false;
+    return true;
+}
 constexpr int vm_of(int kind) { return kind == OP_ST ? 2 : kind == OP_XLO ? 1 : 0; }
-// VM operations a wave issues behind its last DMA piece (step e = 1 of a block) and in front of the barrier of the next step (e = 0, head of chunk 10): they
+// VM operations a wave issues behind its last DMA piece (chunk 7 of step e = 1) and in front of the barrier of the next step (e = 0, head of chunk 10): they
 // may stay in flight at that barrier's counted wait -- vmcnt retires in order, so everything older, the pieces included, is then complete
-constexpr int vm_behind(int epi, int np)
+constexpr int vm_behind(int epi)
 {
     int n = 0;
-    const OpList l1 = step_ops(1, epi, np), l0 = step_ops(0, epi, np);
-    int last = -1;
-    for (int i = 0; i < l1.n; ++i) if (l1.op[i].kind == OP_DMA) last = i;
-    for (int i = last + 1; i < l1.n; ++i) n += vm_of(l1.op[i].kind);
-    for (int i = 0; i < 10 * l0.n / 12; ++i) n += vm_of(l0.op[i].kind);
+    const OpList l = step_ops(epi);
+    for (int i = 7 * l.n / 12; i < l.n; ++i) n += vm_of(l.op[i].kind);        // (the chunk's DMA ops run in front of its step ops)
+    for (int i = 0; i < 10 * l.n / 12; ++i) n += vm_of(l.op[i].kind);
     return n;
 }
 
@@ -161,51 +190,61 @@ __global__ __launch_bounds__(128) void conv64_sq_kernel(ConvX3Args a)
     // ---- DMA pieces of a block whose first input row is yr (columns x0 - 1 ..): slot i of the wave = a_hi piece 2 i + c (i < 5: 8 pixels x 8 slots), a_lo8 piece
     // 2 (i - 5) + c (i < 8: 16 pixels x 4 slots), the residual's fp16 rows yr - 2, yr - 1 -- the output rows finished in the block's two steps -- of columns x0 ..
     // x0 + 31, piece 2 (i - 8) + c (8 pixels x 8 slots).  d_off: the lane's source offset relative to the block's origin
-    unsigned d_off = 0, d_r = 0, d_cc = 0;
-    auto piece_addr = [&](int i) {
-        if (i < 5) {
-            unsigned q = (unsigned)((2 * i + c) * 8 + (lane >> 3));
-            asm volatile("" : "+v"(q));
-            d_r = q >= (unsigned)XW ? 1u : 0u;
-            d_cc = q - d_r * (unsigned)XW;
-            d_r = q >= 2u * XW ? 2u : d_r;                    // (piece 9: nothing)
-            const unsigned sl = (unsigned)(lane & 7) ^ ((d_cc >> 1) & 7u);
-            d_off = ((__umul24(d_r, (unsigned)W) + d_cc) << 7) | (sl << 4);
-        } else if (i < 8) {
-            unsigned q = (unsigned)((2 * (i - 5) + c) * 16 + (lane >> 2));
-            asm volatile("" : "+v"(q));
-            d_r = q >= (unsigned)XW ? 1u : 0u;
-            d_cc = q - d_r * (unsigned)XW;
-            d_r = q >= 2u * XW ? 2u : d_r;                    // (the upper half of piece 4, piece 5: nothing)
-            const unsigned sl = (unsigned)(lane & 3) ^ ((d_cc >> 2) & 3u);
-            d_off = ((__umul24(d_r, (unsigned)W) + d_cc) << 6) | (sl << 4);
-        } else {
-            unsigned q = (unsigned)((2 * (i - 8) + c) * 8 + (lane >> 3));
-            asm volatile("" : "+v"(q));
-            d_r = q >> 5;
-            d_cc = q & 31u;
-            const unsigned sl = (unsigned)(lane & 7) ^ ((d_cc >> 1) & 7u);
-            d_off = ((__umul24(d_r, (unsigned)W) + d_cc) << 7) | (sl << 4);
+    // Per range the lane's source offsets of the wave's pieces are formed ONCE (doff[i]: offset relative to the block's origin, bit 0 = the piece's row of the
+    // block for this lane, 0xFFFF0000 where the lane fetches nothing: columns outside the image, ring padding, pieces that do not exist); a block then costs a
+    // piece one select on its rows' validity instead of ~25 instructions of address arithmetic (the first PMC look: 4.6 VALU instructions per MFMA).
+    constexpr int NT = RES ? 10 : 8;           // table entries: the residual's pieces 2, 3 of a wave are its pieces 0, 1 one row further down
+    const unsigned tab = lds0 + (unsigned)OFF_TAB + (unsigned)(tid * 4);
+    unsigned dt[2];
+    auto piece_table = [&](int x0) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            unsigned d_off, d_r, d_cc;
+            bool ok;
+            if (i < 5) {
+                const unsigned q = (unsigned)((2 * i + c) * 8 + (lane >> 3));
+                d_r = q >= (unsigned)XW ? 1u : 0u;
+                d_cc = q - d_r * (unsigned)XW;
+                const unsigned sl = (unsigned)(lane & 7) ^ ((d_cc >> 1) & 7u);
+                d_off = ((d_r * (unsigned)W + d_cc) << 7) | (sl << 4);
+                ok = (q < 2u * XW) & (d_cc < 34u) & ((unsigned)(x0 - 1 + (int)d_cc) < (unsigned)W);
+            } else if (i < 8) {
+                const unsigned q = (unsigned)((2 * (i - 5) + c) * 16 + (lane >> 2));
+                d_r = q >= (unsigned)XW ? 1u : 0u;
+                d_cc = q - d_r * (unsigned)XW;
+                const unsigned sl = (unsigned)(lane & 3) ^ ((d_cc >> 2) & 3u);
+                d_off = ((d_r * (unsigned)W + d_cc) << 6) | (sl << 4);
+                ok = (q < 2u * XW) & (d_cc < 34u) & ((unsigned)(x0 - 1 + (int)d_cc) < (unsigned)W);
+            } else {
+                const unsigned q = (unsigned)((2 * (i - 8) + c) * 8 + (lane >> 3));
+                d_r = q >> 5;
+                d_cc = q & 31u;
+                const unsigned sl = (unsigned)(lane & 7) ^ ((d_cc >> 1) & 7u);
+                d_off = ((d_r * (unsigned)W + d_cc) << 7) | (sl << 4);
+                ok = (unsigned)(x0 + (int)d_cc) < (unsigned)W;
+            }
+            *(__attribute__((address_space(3))) unsigned*)(tab + (unsigned)(i * 512)) = ok ? (d_off | d_r) : kOOR;
         }
     };
-    auto piece_issue = [&](int i, int slot, int yr, int x0, int b, bool live) {
+    // piece i of the block with ring slot `slot` whose first input row is yr; ok0 / ok1: the block's two rows lie inside the image (and the block is wanted);
+    // for the residual's pieces: the rows yr - 2, yr - 1
+    auto piece_word = [&](int i) { return *(const __attribute__((address_space(3))) unsigned*)(tab + (unsigned)((i < 10 ? i : i - 2) * 512)); };
+    auto piece_issue = [&](int i, unsigned d, int slot, int yr, int x0, int b, bool ok0, bool ok1, bool rk0, bool rk1) {
+        const bool rowok = i >= 8 ? (i >= 10 ? rk1 : rk0) : (d & 1u) ? ok1 : ok0;
+        const unsigned off = rowok ? (d & ~1u) : kOOR;
         if (i < 8) {
-            const bool ok = ((unsigned)(yr + (int)d_r) < (unsigned)H) & ((unsigned)(x0 - 1 + (int)d_cc) < (unsigned)W) & (d_cc < 34u) & (d_r < 2u) & live;
-            const unsigned off = ok ? d_off : kOOR;
             const unsigned pix = (unsigned)((b * H + yr + RB) * W + x0 - 1 + 2);
             if (i < 5) {
                 const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(2 * i + c < 9 ? slot * BLKB + (2 * i + c) * 1024 : OFF_DUMP);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rhi, (__attribute__((address_space(3))) void*)(smem + dst), 16, off, (unsigned)__builtin_amdgcn_readfirstlane((int)(pix * 128u)), 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rhi, (__attribute__((address_space(3))) void*)(smem + dst), 16, off, (unsigned)__builtin_amdgcn_readfirstlane((int)(pix * 128u)), 0, SQ_LDAUX);
             } else {
                 const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(2 * (i - 5) + c < 5 ? OFF_LO8 + slot * BLKB8 + (2 * (i - 5) + c) * 1024 : OFF_DUMP);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rlo, (__attribute__((address_space(3))) void*)(smem + dst), 16, off, (unsigned)__builtin_amdgcn_readfirstlane((int)(pix * 64u)), 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rlo, (__attribute__((address_space(3))) void*)(smem + dst), 16, off, (unsigned)__builtin_amdgcn_readfirstlane((int)(pix * 64u)), 0, SQ_LDAUX);
             }
         } else {
-            const bool ok = ((unsigned)(yr - 2 + (int)d_r) < (unsigned)H) & ((unsigned)(x0 + (int)d_cc) < (unsigned)W) & live;
-            const unsigned off = ok ? d_off : kOOR;
-            const unsigned org = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((b * H + yr - 2 + RB + 1) * W + x0 + 2) * 128u));
+            const unsigned org = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((b * H + yr - 2 + RB + 1 + (i >= 10 ? 1 : 0)) * W + x0 + 2) * 128u));
             const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(OFF_RES + slot * RESBLKB + (2 * (i - 8) + c) * 1024);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rrh, (__attribute__((address_space(3))) void*)(smem + dst), 16, off, org, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rrh, (__attribute__((address_space(3))) void*)(smem + dst), 16, off, org, 0, SQ_LDAUX);
         }
     };
     // ---- LDS addressing.  fp16 rows: pixel col at col * 128, 16-B slot s at s ^ ((col >> 1) & 7); B fragment (dx, ks): lane (j, hh) reads slot 2 ks + hh of column
@@ -264,7 +303,7 @@ __global__ __launch_bounds__(128) void conv64_sq_kernel(ConvX3Args a)
     for (int i = 0; i < 4; ++i) acc[i] = zero16;
     half8_t fx[3];                             // fp16 fragment of chunk n in fx[n % 3], read two chunks ahead
     i8v_t f8[2];                               // [0]: fragment dx of the row's fp8 image, [1]: of the a_lo row
-    u4_t rh, cvw[2][2];
+    u4_t rh, cvw[2];
     u2_t xl[2][2];                             // the residual's fp8 low words, requested two steps ahead (set = step parity)
     unsigned sh[4], sl[4];
     xl[0][0] = xl[0][1] = xl[1][0] = xl[1][1] = u2_t{0u, 0u};
@@ -278,7 +317,9 @@ __global__ __launch_bounds__(128) void conv64_sq_kernel(ConvX3Args a)
         const int x0 = pxi * TW;
         const int ya = RB * s0, yb = RB * s1;
         const int nblk = (yb - ya) / RB + 2;                  // steps t = 0 .. yb - ya + 3: input rows ya - 1 .. yb + 2 (the last output row completes with row yb and is finished a step later)
-#if SQ_ABL & 32      // (timing experiment: every store instruction writes ONE contiguous KiB / half KiB of the row instead of 32 / 16-byte pieces 128 / 64 bytes apart)
+#if SQ_ABL & 128     // (timing experiment: every store is issued and dropped by the buffer's range check)
+        const unsigned vo = kOOR, vo8 = kOOR;
+#elif SQ_ABL & 32    // (timing experiment: every store instruction writes ONE contiguous KiB / half KiB of the row instead of 32 / 16-byte pieces 128 / 64 bytes apart)
         const unsigned vo = (unsigned)(c * 2048 + lane * 16) - 0u * lane_ob;
         const unsigned vo8 = (unsigned)(c * 1024 + lane * 8);
 #else
@@ -289,13 +330,14 @@ __global__ __launch_bounds__(128) void conv64_sq_kernel(ConvX3Args a)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                         // both waves have left the previous range: the rings are free
         asm volatile("" ::: "memory");
+        piece_table(x0);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 2; ++kb) {
+            const int yr = ya - 1 + RB * kb;
 #pragma unroll
-            for (int i = 0; i < NP; ++i) {
-                piece_addr(i);
-                piece_issue(i, kb, ya - 1 + RB * kb, x0, b, true);
-            }
+            for (int i = 0; i < NP; ++i)
+                piece_issue(i, piece_word(i), kb, yr, x0, b, (unsigned)yr < (unsigned)H, (unsigned)(yr + 1) < (unsigned)H, (unsigned)(yr - 2) < (unsigned)H, (unsigned)(yr - 1) < (unsigned)H);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -323,6 +365,8 @@ __global__ __launch_bounds__(128) void conv64_sq_kernel(ConvX3Args a)
             const int xnext2 = xnext + 1 == NRING ? 0 : xnext + 1;
             const bool live = RB * (k + 2) <= yb - ya + 3;    // the block after the next has rows somebody wants
             const int yrn = Rk + 2 * RB;
+            const bool nok0 = live & ((unsigned)yrn < (unsigned)H), nok1 = live & ((unsigned)(yrn + 1) < (unsigned)H);
+            const bool nrk0 = live & ((unsigned)(yrn - 2) < (unsigned)H), nrk1 = live & ((unsigned)(yrn - 1) < (unsigned)H);
 
             auto step = [&](auto E_) __attribute__((always_inline)) {
                 constexpr int e = decltype(E_)::value;
@@ -344,17 +388,17 @@ __global__ __launch_bounds__(128) void conv64_sq_kernel(ConvX3Args a)
 
                 auto op_dma = [&](auto I_, auto HALF_) __attribute__((always_inline)) {
                     constexpr int i = decltype(I_)::value, half = decltype(HALF_)::value;
-                    if constexpr (half == 0) piece_addr(i);
-                    else piece_issue(i, xnext2, yrn, x0, b, live);
+                    if constexpr (half == 0) dt[i & 1] = piece_word(i);
+                    else piece_issue(i, dt[i & 1], xnext2, yrn, x0, b, nok0, nok1, nrk0, nrk1);
                 };
                 auto op_cvr = [&](auto U_) __attribute__((always_inline)) {
                     constexpr int u = decltype(U_)::value;
-                    cvw[u][0] = *(lds_u4_t)(cv_src[u] + xo_nxt);
-                    cvw[u][1] = *(lds_u4_t)((cv_src[u] ^ 16u) + xo_nxt);
+                    cvw[0] = *(lds_u4_t)(cv_src[u] + xo_nxt);
+                    cvw[1] = *(lds_u4_t)((cv_src[u] ^ 16u) + xo_nxt);
                 };
                 auto op_cvw = [&](auto U_) __attribute__((always_inline)) {
                     constexpr int u = decltype(U_)::value;
-                    const u4_t d = cvt16(cvw[u][0], cvw[u][1]);
+                    const u4_t d = cvt16(cvw[0], cvw[1]);
                     const unsigned adr = cv_dst[u];
                     asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(adr), "v"(d), "n"(e * ROWB8) : "memory");
                 };
@@ -387,14 +431,14 @@ __global__ __launch_bounds__(128) void conv64_sq_kernel(ConvX3Args a)
                     constexpr int o = decltype(O_)::value;
                     const u4_t dh = {sh[0], sh[1], sh[2], sh[3]};
                     constexpr unsigned ostep = (SQ_ABL & 32) ? 1024u : 32u;
-                    __builtin_amdgcn_raw_buffer_store_b128(dh, ryh, vo + (unsigned)o * ostep, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(dh, ryh, vo + (unsigned)o * ostep, so, SQ_STAUX);
                     if (!OUT8) {
                         const u4_t dl = {sl[0], sl[1], sl[2], sl[3]};
-                        __builtin_amdgcn_raw_buffer_store_b128(dl, ryl, vo + (unsigned)o * ostep, so, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(dl, ryl, vo + (unsigned)o * ostep, so, SQ_STAUX);
                     } else {
                         unsigned p0, p1;
                         cvt4(sl[0], sl[1], sl[2], sl[3], p0, p1);
-                        __builtin_amdgcn_raw_buffer_store_b64(u2_t{p0, p1}, ryl, vo8 + (unsigned)o * (ostep / 2), so >> 1, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(u2_t{p0, p1}, ryl, vo8 + (unsigned)o * (ostep / 2), so >> 1, SQ_STAUX);
                     }
                 };
                 auto op_xlo = [&](auto O_) __attribute__((always_inline)) {
@@ -402,14 +446,15 @@ __global__ __launch_bounds__(128) void conv64_sq_kernel(ConvX3Args a)
                     xl[T4 & 1][o] = __builtin_amdgcn_raw_buffer_load_b64(rrl, vo8 + (unsigned)(o * 16), so2, 0);
                 };
 
-                constexpr OpList L = step_ops(e, EPI, NP);
+                constexpr OpList L = step_ops(EPI), LD = dma_ops(e, NP);
+                static_assert(cvw_in_time(EPI), "the image's writes must precede the barrier");
                 auto chunk = [&](auto A_) __attribute__((always_inline)) {
                     constexpr int ai = decltype(A_)::value;               // fp16 fragment (dx, ks) = (ai / 4, ai % 4)
                     constexpr int dx = ai / 4, ks = ai % 4;
                     if (ai == 10) {
                         // the next row's fp8 image is written; e = 0: the block after this one has landed (its pieces and everything older; what the wave has issued
                         // behind its last piece may still be on its way)
-                        if (e == 0 && !(SQ_ABL & 3)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(vm_behind(EPI, NP)) : "memory");
+                        if (e == 0 && !(SQ_ABL & 3)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(vm_behind(EPI)) : "memory");
                         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_s_barrier();
                         asm volatile("" ::: "memory");
@@ -437,12 +482,23 @@ __global__ __launch_bounds__(128) void conv64_sq_kernel(ConvX3Args a)
                         if constexpr (ks == 3 && dx == 2) { f8[0] = read8(0, q_nxt); f8[1] = read8(0, lo_nxt); }
                     }
                     {
+                        constexpr int dlo = ai < 8 ? ai * LD.n / 8 : LD.n, dhi = ai < 8 ? (ai + 1) * LD.n / 8 : LD.n;
+                        auto rund = [&](auto I_) __attribute__((always_inline)) {
+                            constexpr int I = decltype(I_)::value;
+                            if constexpr (I >= dlo && I < dhi) {
+                                constexpr Op o = LD.op[I];
+                                op_dma(std::integral_constant<int, o.a>{}, std::integral_constant<int, o.b>{});
+                            }
+                        };
+#define SQ_OP(I) rund(std::integral_constant<int, I>{});
+                        SQ_OP(0) SQ_OP(1) SQ_OP(2) SQ_OP(3) SQ_OP(4) SQ_OP(5) SQ_OP(6) SQ_OP(7) SQ_OP(8) SQ_OP(9) SQ_OP(10) SQ_OP(11) SQ_OP(12) SQ_OP(13) SQ_OP(14) SQ_OP(15)
+                        SQ_OP(16) SQ_OP(17) SQ_OP(18) SQ_OP(19) SQ_OP(20) SQ_OP(21) SQ_OP(22) SQ_OP(23) SQ_OP(24) SQ_OP(25) SQ_OP(26) SQ_OP(27) SQ_OP(28) SQ_OP(29) SQ_OP(30) SQ_OP(31)
+#undef SQ_OP
                         constexpr int lo_ = ai * L.n / 12, hi_ = (ai + 1) * L.n / 12;
                         auto run = [&](auto I_) __attribute__((always_inline)) {
                             constexpr int I = decltype(I_)::value;
                             if constexpr (I >= lo_ && I < hi_) {
                                 constexpr Op o = L.op[I];
-                                if constexpr (o.kind == OP_DMA) op_dma(std::integral_constant<int, o.a>{}, std::integral_constant<int, o.b>{});
                                 if constexpr (o.kind == OP_CVR) op_cvr(std::integral_constant<int, o.a>{});
                                 if constexpr (o.kind == OP_CVW) op_cvw(std::integral_constant<int, o.a>{});
                                 if constexpr (o.kind == OP_RHI) op_rhi(std::integral_constant<int, o.a>{});
@@ -525,6 +581,11 @@ bool launch_conv64_sq(ConvX3Args a, int max_groups, hipStream_t s)
     const int px = (a.W + TW - 1) / TW;
     const long long items = (long long)a.B * px * (a.H / RB);
     if (items >= (1ll << 31) / 4) return false;
+    // Small launch sets lose here (a range start costs three barriers and an exposed DMA round trip: 28 against 17 us for the smallest set of an a2 frame,
+    // profiles/r04/k_conv64_sq_frame_launches.txt) -- and still take this kernel: which form a layer runs on must not depend on how many tiles share its
+    // launch, or a tile's bits would (the two forms differ in the order of their sums).  MOE_SQ_MIN_ITEMS = blocks per workgroup below which the patch form runs (experiments).
+    static const long long min_items = [] { const char* e = getenv("MOE_SQ_MIN_ITEMS"); return e ? atoll(e) : 0ll; }();
+    if (items < min_items * 2 * max_groups) return false;
     const int G = (int)std::min<long long>(items, 2ll * max_groups);
     const dim3 grid(G), blk(128);
     if (epi == 0) conv64_sq_kernel<0, true><<<grid, blk, LDS_PLAIN, s>>>(a);
