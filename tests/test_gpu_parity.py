@@ -1221,3 +1221,47 @@ def test_io_edges_vector_and_element_forms_agree(dev):
                     ref = np.clip(yy * q, 0, q - 1)
                 ref = np.where(np.isnan(ref), 0, ref).astype(np.int64).transpose(1, 2, 0)
                 assert np.array_equal(got.astype(np.int64), ref), (H, W, C, bits, dt)
+
+
+@pytest.mark.parametrize('key,blocks', [('a2', -1), ('a4', -1), ('a3', -1), ('a2', 6)])
+def test_streamed_split_operand_layers_vs_patch_form(key, blocks, dev):
+    """Option q8_impl = s (default; conv64_sq.hip): the chain layers of conv64_q8.hip -- same operands, products and scales -- streamed down 32-pixel columns
+    by two-wave workgroups.  One accumulator set in both forms, a different order of the sums inside a row: the tensors between the layers agree to fp32
+    rounding, and the fp8 low words they travel in turn that into a few 1e-5 .. 1e-4 at the output.  So: both forms inside the tolerance against the ORACLE,
+    natural and noise, ragged shapes (odd widths, two-row tiles, heights the kernel does not take: odd ones fall back to the patch form); the streamed form
+    repeats bit for bit, and its bits do not depend on the workgroup count (rows at range ends are recomputed, not approximated)."""
+    arch = gd.MODELS[key][0]
+    sd = gd.state_dict_for(key, load_state_dict_file)
+    m = module_for(key)
+    try:
+        m.set_exact_blocks(blocks)
+        for shape in ((3, 8, 8), (2, 24, 40), (2, 40, 264), (3, 16, 72), (1, 88, 64), (1, 6, 33), (2, 2, 40), (1, 9, 35)):
+            for kind in ('natural', 'noise'):
+                x = (gd.natural_image(41, shape) if kind == 'natural' else gd.noise_image(41, shape))[:, None]
+                want = onets.forward(arch, sd, x).numpy()
+                xd = torch.from_numpy(x).to(dev)
+                y_p = m.set_option('q8_impl', 'p')(xd)[-1].cpu().numpy()
+                y_s = m.set_option('q8_impl', 's')(xd)[-1].cpu().numpy()
+                assert np.isfinite(y_s).all(), (key, shape, kind)
+                assert np.abs(y_s - want).max() <= TOL and np.abs(y_p - want).max() <= TOL, (key, shape, kind, float(np.abs(y_s - want).max()), float(np.abs(y_p - want).max()))
+                assert np.abs(y_s - y_p).max() <= 7e-4, (key, shape, kind, float(np.abs(y_s - y_p).max()))
+                assert np.array_equal(y_s, m(xd)[-1].cpu().numpy()), (key, shape, kind)
+                y_g = m.set_option('max_groups', 5)(xd)[-1].cpu().numpy()
+                m.set_option('max_groups', 0)
+                assert np.array_equal(y_s, y_g), (key, shape, kind)
+    finally:
+        m.set_option('q8_impl', 's')
+        m.set_exact_blocks(-1)
+
+
+def test_a2_noise_full_tile_vs_oracle(dev):
+    """A full 256 x 256 tile of uniform uint8 noise -- the input class with the least margin -- through a2 in the default arithmetic (nine split-operand layers
+    on the streamed form, fp8 low words between them) against the ORACLE's fp32 forward, not only against the exact mode."""
+    sd = gd.state_dict_for('a2', load_state_dict_file)
+    m = module_for('a2')
+    for seed in (0, 1):
+        x = (gd.noise_u8(seed, (1, 256, 256)).astype(np.float32) / 255.0)[:, None]
+        want = onets.forward('net2x', sd, x).numpy()
+        got = m(torch.from_numpy(x).to(dev))[-1].cpu().numpy()
+        err = float(np.abs(got - want).max())
+        assert err <= TOL, (seed, err)
