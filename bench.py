@@ -67,7 +67,7 @@ GROUPS = [
 ]
 
 
-# The split-operand layers (conv_input2, ARSB 1 of Net4x: conv64_q8.hip) are held by their bytes, not by the matrix pipe: their roofline object is
+# The split-operand layers (conv_input2, ARSB 1 of Net4x: conv64_sq.hip) are held by their bytes, not by the matrix pipe (DESIGN.md sections 4.4, 4.7): their roofline object is
 # an HBM one.  Algorithmic bytes per LR pixel and plane, hi + low part in and out (+ the residual): with the fp8 low parts of a conv64_q8 chain 192 in + 192 out |
 # 192 + 192 | 192 + 192 (residual) + 256 (fp16 low part again for the fused ARSB kernels); with fp16 low parts 512 | 512 | 768
 HBM_KEYS = ['input2', 'c1_', 'c2_']
@@ -274,8 +274,8 @@ def main():
         launches = sum(p['launches'] for p in hb)
         alg = 3.0 * FRAME[1] * FRAME[2] * _exact_bytes_px() * frames_timed                # algorithmic bytes of the three layers in the timed steps
         peak_gbs = 8000.0                                                                   # MI355X_MICROARCH.md: HBM3E ~8 TB/s
-        k = {'bound': 'hbm', 'kernel': 'conv64_q8_kernel (conv_input2 + the two convs of ARSB 1 with split operands: fp16 product + two fp8 correction products, fp8 low parts '
-                                       'between the layers) -- or conv64_x3_kernel under MOE_X3_IMPL=x3', 'layer_key': 'exact',
+        k = {'bound': 'hbm', 'kernel': 'conv64_sq_kernel (conv_input2 + the two convs of ARSB 1 with split operands: fp16 product + two fp8 correction products, fp8 low parts '
+                                       'between the layers; rows streamed down 32-pixel columns by two-wave workgroups; small or odd shapes: conv64_q8_kernel) -- or conv64_x3_kernel under MOE_X3_IMPL=x3', 'layer_key': 'exact',
              'achieved': round(alg / secs / 1e9, 1), 'peak': peak_gbs, 'unit': 'GB/s', 'frac': round(alg / secs / 1e9 / peak_gbs, 4),
              'bytes_per_pixel_algorithmic': _exact_bytes_px(), 'launches': launches, 'avg_launch_ms': round(secs * 1e3 / launches, 4),
              'ms_per_frame': round(secs * 1e3 / frames_timed, 3), 'share_of_step': round(secs * 1e3 / frames_timed / ms_per_step, 4)}
