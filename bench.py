@@ -70,11 +70,13 @@ GROUPS = [
 # The split-operand layers (conv_input2, ARSB 1 of Net4x: conv64_sq.hip) are held by their bytes, not by the matrix pipe (DESIGN.md sections 4.4, 4.7): their roofline object is
 # an HBM one.  Algorithmic bytes per LR pixel and plane, hi + low part in and out (+ the residual): with the fp8 low parts of a conv64_q8 chain 192 in + 192 out |
 # 192 + 192 | 192 + 192 (residual) + 256 (fp16 low part again for the fused ARSB kernels); with fp16 low parts 512 | 512 | 768
-HBM_KEYS = ['input2', 'c1_', 'c2_']
+HBM_KEYS = ['input2', 'c1_', 'c2_', 'xpair']      # (xpair: the exact ARSB as one launch, arsb_sq.hip -- then c1_ / c2_ record nothing)
 
 
-def _exact_bytes_px():
+def _exact_bytes_px(fused=False):
     chain = os.environ.get('MOE_X3_IMPL', 'auto') in ('auto', 'q8') and os.environ.get('MOE_LO8', 'on') not in ('0', 'off')
+    if fused:
+        return 384 + (192 + 256)      # conv_input2 | the exact ARSB in one launch: x in (fp16 + fp8 low word), y out (fp16 + fp16 low part for the single-pass ARSBs); conv_1's rows stay in LDS
     return (384 + 384 + 640) if chain else (512 + 512 + 768)
 
 
@@ -269,16 +271,23 @@ def main():
         if trunk:
             res['roofline_trunk'] = trunk[0]
     hb = profs[len(GROUPS):len(GROUPS) + len(HBM_KEYS)]
-    if len(hb) == len(HBM_KEYS) and all(p['launches'] > 0 and p['total_ms'] > 0 for p in hb):
+    fused = len(hb) == len(HBM_KEYS) and hb[3]['launches'] > 0
+    hb = [p for p in hb if p['launches'] > 0 and p['total_ms'] > 0]
+    if len(hb) >= 2:
         secs = sum(p['total_ms'] for p in hb) / 1e3
         launches = sum(p['launches'] for p in hb)
-        alg = 3.0 * FRAME[1] * FRAME[2] * _exact_bytes_px() * frames_timed                # algorithmic bytes of the three layers in the timed steps
+        alg = 3.0 * FRAME[1] * FRAME[2] * _exact_bytes_px(fused) * frames_timed            # algorithmic bytes of the three layers in the timed steps
         peak_gbs = 8000.0                                                                   # MI355X_MICROARCH.md: HBM3E ~8 TB/s
-        k = {'bound': 'hbm', 'kernel': 'conv64_sq_kernel (conv_input2 + the two convs of ARSB 1 with split operands: fp16 product + two fp8 correction products, fp8 low parts '
-                                       'between the layers; rows streamed down 32-pixel columns by two-wave workgroups; small or odd shapes: conv64_q8_kernel) -- or conv64_x3_kernel under MOE_X3_IMPL=x3', 'layer_key': 'exact',
+        flops = 3.0 * FRAME[1] * FRAME[2] * frames_timed * 3 * 2 * 64 * 64 * 9            # three 3x3 64->64 convs; executed: two product-times each (fp16 + two fp8 products at twice the rate)
+        k = {'bound': 'hbm', 'kernel': ('conv64_sq_kernel (conv_input2) + arsb_sq_kernel (ARSB 1 as ONE launch: conv_1 on producer waves, conv_2 on consumer waves, its rows in LDS)' if fused else
+                                        'conv64_sq_kernel (conv_input2 + the two convs of ARSB 1)') +
+                                       ': split operands -- fp16 product + two fp8 correction products, fp8 low parts between the layers; rows streamed down columns by '
+                                       'register-weight waves (small or odd shapes: conv64_q8_kernel; MOE_X3_IMPL=x3: conv64_x3_kernel)', 'layer_key': 'exact',
              'achieved': round(alg / secs / 1e9, 1), 'peak': peak_gbs, 'unit': 'GB/s', 'frac': round(alg / secs / 1e9 / peak_gbs, 4),
-             'bytes_per_pixel_algorithmic': _exact_bytes_px(), 'launches': launches, 'avg_launch_ms': round(secs * 1e3 / launches, 4),
-             'ms_per_frame': round(secs * 1e3 / frames_timed, 3), 'share_of_step': round(secs * 1e3 / frames_timed / ms_per_step, 4)}
+             'bytes_per_pixel_algorithmic': _exact_bytes_px(fused), 'launches': launches, 'avg_launch_ms': round(secs * 1e3 / launches, 4),
+             'ms_per_frame': round(secs * 1e3 / frames_timed, 3), 'share_of_step': round(secs * 1e3 / frames_timed / ms_per_step, 4),
+             'mfma_side': {'algorithmic_tflops': round(flops / secs / 1e12, 1), 'executed_tflops_fp16_equivalent': round(2 * flops / secs / 1e12, 1), 'peak': round(peak_tflops, 1),
+                           'note': 'with conv_1\'s rows kept in LDS these layers stopped being held by their bytes: PMC MFMA busy 0.78 at 1.7 GHz (profiles/r04), the package power cap again'}}
         t = pmc.get('exact')
         k['traffic'] = int(t['hbm_bytes_per_frame'] / max(1, t['launches_per_frame'])) if t else None
         if t:

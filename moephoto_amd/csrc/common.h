@@ -187,6 +187,16 @@ hipError_t conv64_q8_init();
 // the chain form of that layer (fp8 low parts in) streamed down a column by one fp16 wave + one fp8 wave per workgroup (conv64_sq.hip); false: not applicable (caller uses conv64_q8)
 bool launch_conv64_sq(ConvX3Args a, int max_groups, hipStream_t s);
 hipError_t conv64_sq_init();
+// arsb_sq.hip: ONE exact ARSB of such a chain in one launch -- conv_1's rows stay in LDS (producer / consumer wave pairs); false: not applicable (caller runs the two convs)
+struct ArsbSqArgs {
+    const half_t* x_hi; const unsigned char* x_lo8;      // stream in: [B][H][W][64] fp16 + the fp8 low words
+    half_t* y_hi; void* y_lo;                            // stream out, NOT aliasing x; y_lo: fp8 words (out8) or fp16
+    const half_t* w16[2]; const unsigned char* wh8[2]; const unsigned char* wl8[2];      // conv_1, conv_2: ConvLayer::w_hi, wq_hi8, wq_lo8
+    float slope;                                         // PReLU slope of conv_1 (<= 1)
+    int B, H, W, out8;
+};
+bool launch_arsb_sq(const ArsbSqArgs& a, int max_groups, hipStream_t s);
+hipError_t arsb_sq_init();
 
 // Workgroup count of a launch whose epilogue pools per plane into per-workgroup slabs (conv3x3_rw EPI 4, conv64_x3 EPI 3): a multiple or a divisor
 // of the patches per plane P, so that the patch -> workgroup map (item % G with item = plane * P + k) -- and with it every slab's content and

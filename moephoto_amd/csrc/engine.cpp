@@ -97,6 +97,7 @@ struct NetOptions {
     int x3_impl = 0;          // x3_impl     auto (0, default: q8 for the SR nets, x3 for the DN nets -- see forward) | x3 (1: conv64_x3.hip, three fp16 products) |
                               //             q8 (2: conv64_q8.hip, the two correction products on fp8 operands)
     int k48 = 1;              // k48         1 (default): kernels that can skip the zero k-slice of the 48-channel nets do | 0: they run all four (A/B)
+    int exact_fuse = 1;       // exact_fuse  1 (default): an exact ARSB of a chain runs as ONE launch (arsb_sq.hip: conv_1's rows stay in LDS) | 0: conv_1, conv_2 on conv64_sq / conv64_q8
     int q8_impl = 1;          // q8_impl     s (1, default: conv64_sq.hip, the chain layers streamed down a column by an fp16 wave + an fp8 wave) | p (0: conv64_q8.hip, 8 x 32 patches)
     int arsb_impl = 3;        // arsb_impl   v3 (3, default: arsb32c.hip, ten-row patches) | s (4: arsb_s.hip, rows streamed down 30-pixel columns by two-wave workgroups:
                               //             bit-identical, measured 7 % SLOWER -- both forms sit at the package power cap with the same MFMA rate (busy x clock 0.73 x 1.65
@@ -135,6 +136,7 @@ struct NetOptions {
         if (key == "lo8") { const int t = onoff(v); if (t < 0) return false; lo8 = t; return true; }
         if (key == "x3_impl") { const int t = tri(v, "auto", "x3", "q8", -1); if (t < 0) return false; x3_impl = t; return true; }
         if (key == "k48") { const int t = onoff(v); if (t < 0) return false; k48 = t; return true; }
+        if (key == "exact_fuse") { const int t = onoff(v); if (t < 0) return false; exact_fuse = t; return true; }
         if (key == "q8_impl") { if (v && !strcmp(v, "s")) q8_impl = 1; else if (v && !strcmp(v, "p")) q8_impl = 0; else return false; return true; }
         if (key == "arsb_impl") { if (v && !strcmp(v, "s")) arsb_impl = 4; else if (v && !strcmp(v, "v3")) arsb_impl = 3; else return false; return true; }
         if (key == "conv1x1") return flag(conv1x1);
@@ -152,7 +154,7 @@ struct NetOptions {
     void from_env()
     {
         static const char* const names[][2] = {{"MOE_CONV_IMPL", "conv_impl"}, {"MOE_SP_IMPL", "sp_impl"}, {"MOE_TAIL_SPLIT", "tail_split"}, {"MOE_TAIL_FORM", "tail_form"}, {"MOE_UP_IMPL", "up_impl"},
-                                               {"MOE_CONV1X1", "conv1x1"}, {"MOE_ARSB_IMPL", "arsb_impl"}, {"MOE_Q8_IMPL", "q8_impl"}, {"MOE_K48", "k48"}, {"MOE_X3_IMPL", "x3_impl"}, {"MOE_LO8", "lo8"}, {"MOE_X3_FUSE", "x3_fuse"}, {"MOE_ARSB_FUSE", "arsb_fuse"}, {"MOE_FUSE_TAIL", "fuse_tail"},
+                                               {"MOE_CONV1X1", "conv1x1"}, {"MOE_ARSB_IMPL", "arsb_impl"}, {"MOE_Q8_IMPL", "q8_impl"}, {"MOE_EXACT_FUSE", "exact_fuse"}, {"MOE_K48", "k48"}, {"MOE_X3_IMPL", "x3_impl"}, {"MOE_LO8", "lo8"}, {"MOE_X3_FUSE", "x3_fuse"}, {"MOE_ARSB_FUSE", "arsb_fuse"}, {"MOE_FUSE_TAIL", "fuse_tail"},
                                                {"MOE_SEDN_FUSE", "sedn_fuse"}, {"MOE_POOL_FUSE", "pool_fuse"}, {"MOE_DBG", "dbg"}, {"MOE_TRACE_KEY", "trace_key"},
                                                {"MOE_TILES_PER_BATCH", "tiles_per_batch"}, {"MOE_MAX_GROUPS", "max_groups"}};
         for (const auto& nv : names)
@@ -1068,6 +1070,31 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
                     }
                 }
                 if (done) { std::swap(cur, oth); f.tap("arsb" + std::to_string(i), cur, h, w, 64, n.C); continue; }
+            }
+            if (ex && chain8 && n.opt.exact_fuse && n.opt.q8_impl == 1 && cur.lo8 && cur.lo && oth.lo) {
+                // an exact block of the chain in ONE launch (arsb_sq.hip): x = cur (fp16 + fp8 low words) -> oth; the last exact block writes fp16 low parts (the
+                // single-pass ARSB kernels behind it read those)
+                bool done = f.dry();
+                if (!done) {
+                    const ConvLayer& L1 = n.convs[n.conv_index.at(k1)];
+                    const ConvLayer& L2 = n.convs[n.conv_index.at(k2)];
+                    if (L1.wq_hi8 && L2.wq_hi8 && !L1.has_bias && !L2.has_bias && L2.slope == 1.f) {
+                        ArsbSqArgs q{};
+                        q.x_hi = cur.hi; q.x_lo8 = (const unsigned char*)cur.lo; q.y_hi = oth.hi; q.y_lo = oth.lo;
+                        q.w16[0] = f.blob<half_t>(L1.w_hi); q.wh8[0] = f.blob<unsigned char>(L1.wq_hi8); q.wl8[0] = f.blob<unsigned char>(L1.wq_lo8);
+                        q.w16[1] = f.blob<half_t>(L2.w_hi); q.wh8[1] = f.blob<unsigned char>(L2.wq_hi8); q.wl8[1] = f.blob<unsigned char>(L2.wq_lo8);
+                        q.slope = L1.slope; q.B = B; q.H = h; q.W = w; q.out8 = i < nx;
+                        const int rec = f.prof_begin("xpair" + std::to_string(i), 2.0 * 2.0 * 3.0 * (double)B * h * w * L1.cout * L1.cin * 9);
+                        done = launch_arsb_sq(q, n.max_groups, s);
+                        f.prof_end(rec);
+                    }
+                }
+                if (done) {
+                    std::swap(cur, oth);
+                    cur.lo8 = i < nx;
+                    f.tap("arsb" + std::to_string(i), cur, h, w, 64, n.C);
+                    continue;
+                }
             }
             Act m = oth;
             if (mixed && !ex) m.lo = nullptr;                    // single-pass ARSB: conv_1's output is an fp16 operand only

@@ -1265,3 +1265,32 @@ def test_a2_noise_full_tile_vs_oracle(dev):
         got = m(torch.from_numpy(x).to(dev))[-1].cpu().numpy()
         err = float(np.abs(got - want).max())
         assert err <= TOL, (seed, err)
+
+
+@pytest.mark.parametrize('key,blocks', [('a2', -1), ('a4', -1), ('a3', -1), ('a2', 6), ('a4', 3)])
+def test_fused_exact_arsb_is_bit_identical_to_the_two_launch_form(key, blocks, dev):
+    """Option exact_fuse (default on; arsb_sq.hip): an exact ARSB of the chain in ONE launch -- producer waves run conv_1 on the x rings and leave its rows (fp16,
+    fp8 low word, fp8 image) in LDS, consumer waves run conv_2 on them and take the residual from the x rings.  Per conv the same MFMAs in the same order as
+    conv64_sq.hip, the same epilogue arithmetic, and m crosses as the very (fp16, fp8 word) pair the two-launch form stores: the outputs must be the SAME BITS,
+    on every shape (30-pixel columns against 32, ragged widths, two-row tiles), whatever the workgroup count -- and within the tolerance of the oracle."""
+    arch = gd.MODELS[key][0]
+    sd = gd.state_dict_for(key, load_state_dict_file)
+    m = module_for(key)
+    try:
+        m.set_exact_blocks(blocks)
+        for shape in ((3, 8, 8), (2, 24, 40), (2, 40, 264), (3, 16, 72), (1, 88, 64), (1, 6, 33), (2, 2, 40), (1, 64, 30), (1, 32, 61)):
+            for kind in ('natural', 'noise'):
+                x = (gd.natural_image(43, shape) if kind == 'natural' else gd.noise_image(43, shape))[:, None]
+                xd = torch.from_numpy(x).to(dev)
+                y0 = m.set_option('exact_fuse', 0)(xd)[-1].cpu().numpy()
+                y1 = m.set_option('exact_fuse', 1)(xd)[-1].cpu().numpy()
+                assert np.array_equal(y1, y0), (key, shape, kind, float(np.abs(y1 - y0).max()))
+                assert np.array_equal(y1, m(xd)[-1].cpu().numpy()), (key, shape, kind)
+                y_g = m.set_option('max_groups', 3)(xd)[-1].cpu().numpy()
+                m.set_option('max_groups', 0)
+                assert np.array_equal(y1, y_g), (key, shape, kind)
+                want = onets.forward(arch, sd, x).numpy()
+                assert np.abs(y1 - want).max() <= TOL, (key, shape, kind, float(np.abs(y1 - want).max()))
+    finally:
+        m.set_option('exact_fuse', 1)
+        m.set_exact_blocks(-1)

@@ -62,7 +62,7 @@ GROUP_KERNELS = {      # bench.py layer key -> regex of the kernel(s) that run i
     'convt_R1.up1': r'conv3x3_(sp_kernel<7>|rw_kernel<7[,>]|ps4_kernel<true)',
     'u.up1': r'conv3x3_(sp_kernel<3>|rw_kernel<3[,>]|ps4_kernel<false)',
     'arsb': r'arsb(32c?|_fused)_kernel',
-    'exact': r'conv64_(sq|q8|x3)_kernel',
+    'exact': r'(conv64_(sq|q8|x3)|arsb_sq)_kernel',
 }
 groups = {}
 for key, rx in GROUP_KERNELS.items():

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/${PMC_TAG:-r04r}
 mkdir -p $OUT
-RE='conv64_q8|conv64_sq'
+RE='conv64_q8|conv64_sq|arsb_sq'
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_ANY --kernel-include-regex "$RE" -d $OUT/pmc_sq -o pmc -f csv -- python tools/time_sq.py > $OUT/pmc_sq.log 2>&1
 timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM SQ_WAIT_ANY SQ_ACTIVE_INST_SCA SQ_INSTS_SALU --kernel-include-regex "$RE" -d $OUT/pmc_g -o pmc -f csv -- python tools/time_sq.py > $OUT/pmc_g.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/st -o st -f csv -- python tools/time_sq.py > $OUT/st.log 2>&1

@@ -3,7 +3,7 @@
 import csv, glob, sys, collections, re
 out = sys.argv[1]
 def key(n):
-    m = re.search(r'(conv64_\w+<[^>]*>)', n)
+    m = re.search(r'((?:conv64|arsb)_\w+<[^>]*>)', n)
     return m.group(1) if m else n[:40]
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.Counter()

@@ -23,11 +23,11 @@ for impl in os.environ.get('SQ_IMPLS', 'p,s').split(','):
         m(x)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 6 * 1e3
-    m.set_profile('input2,c1_,c2_')
+    m.set_profile('input2,c1_,c2_,xpair')
     for _ in range(6):
         m(x)
     torch.cuda.synchronize()
     pr = m.get_profile(all_keys=True)
     m.set_profile(None)
     print('%s %-8s q8_impl = %s: %.3f ms per launch set | split-operand layers: %s' % (key, os.environ.get('SQ_TAG', ''), impl, ms,
-          '  '.join('%s %.1f us x %d' % (k, p['total_ms'] / max(1, p['launches']) * 1e3, p['launches'] // 6) for k, p in zip(('input2', 'conv_1', 'conv_2'), pr))), flush=True)
+          '  '.join('%s %.1f us x %d' % (k, p['total_ms'] / max(1, p['launches']) * 1e3, p['launches'] // 6) for k, p in zip(('input2', 'conv_1', 'conv_2', 'fused exact ARSB'), pr) if p['launches'])), flush=True)
