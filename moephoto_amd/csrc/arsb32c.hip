@@ -506,6 +506,9 @@ __global__ __launch_bounds__(256) void arsb32c_kernel(ArsbArgs a)
                     if (i >= 0 && i < 5)
                         acc[(i + 1) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[(dy * 3 + dx) * 4 + ks], fr[(f + 14 - s) % 14], (dy == 0 && f == 0) ? zero16 : acc[(i + 1) & 3], 0, 0, 0);
                 }
+#ifdef A32_NOFRAG      // (timing experiment, results WRONG: what the fragment reads of the row steps cost -- every second one skipped, the registers kept live)
+                if (s < 6 && (f & 1)) asm volatile("" : "+v"(fr[(f + 13 - s) % 14])); else
+#endif
                 if (s < 6) fr[(f + 13 - s) % 14] = *(lds_h8_t)(fa[f] + (unsigned)((s + 1) * ROWB));
                 run_ops(std::integral_constant<int, 0>{}, S_, std::integral_constant<int, dx * KS + ks>{});
 #pragma unroll
@@ -577,6 +580,9 @@ __global__ __launch_bounds__(256) void arsb32c_kernel(ArsbArgs a)
                     if (i >= 0 && i < 5)
                         acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[(dy * 3 + dx) * 4 + ks], fr[(f + 14 - (7 + s)) % 14], (dy == 0 && f == 0) ? zero16 : acc[i & 3], 0, 0, 0);
                 }
+#ifdef A32_NOFRAG
+                if (s < 6 && (f & 1)) asm volatile("" : "+v"(fr[(f + 13 - (7 + s)) % 14])); else
+#endif
                 if (s < 6) fr[(f + 13 - (7 + s)) % 14] = *(lds_h8_t)(fa[f] + (unsigned)((s + 1) * ROWB));
                 else fr[f] = *(lds_h8_t)(fa[f]);            // row 0 of patch p+1's conv_1 (landed and published by barrier B): (f - 14) mod 14 = f
                 run_ops(std::integral_constant<int, 1>{}, S_, std::integral_constant<int, dx * KS + ks>{});
