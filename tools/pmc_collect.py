@@ -59,8 +59,8 @@ for k in sorted(K, key=lambda k: -DUR[k].get('grbm', DUR[k].get('sq', 0))):
     kernels[k] = e
 
 GROUP_KERNELS = {      # bench.py layer key -> regex of the kernel(s) that run it in the default build
-    'convt_R1.up1': r'conv3x3_(sp_kernel<7>|rw_kernel<7[,>]|ps4_kernel<true)',
-    'u.up1': r'conv3x3_(sp_kernel<3>|rw_kernel<3[,>]|ps4_kernel<false)',
+    'convt_R1.up1': r'conv3x3_(sp_kernel<7>|rw_kernel<7[,>]|ps4_kernel<2,)',
+    'u.up1': r'conv3x3_(sp_kernel<3>|rw_kernel<3[,>]|ps4_kernel<1,)',
     'arsb': r'arsb(32c?|_fused)_kernel',
     'exact': r'(conv64_(sq|q8|x3)|arsb_sq)_kernel',
 }
