@@ -346,7 +346,7 @@ def main():
                               'max_abs_vs_device_docrop': float('{:.3e}'.format(float((y_loop.float() - y_dev.float()).abs().max()))),
                               'what': "the reference's per-tile loop (python/imageProcess.py:157-172) with torch blends, calling models.Net4x.__call__ = moe_net_forward on "
                                       '3 planes of <= 256x256 per call (40 calls per frame, fp16 canvas AND fp16 blends as in the reference GPU path); '
-                                      'moe_run_plan (the headline) batches 16 tiles per launch set and stitches from fp32 tiles'}
+                                      'moe_run_plan (the headline) batches up to 32 same-shaped tiles per launch set and stitches from fp32 tiles'}
 
     # ---- CPU baseline + parity gate (rank 0) -----------------------------------------------------------------
     parity_ok = True

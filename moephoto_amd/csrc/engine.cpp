@@ -108,7 +108,7 @@ struct NetOptions {
     bool sedn_fuse = true;    // sedn_fuse   SEDN's fused block tail
     bool pool_fuse = true;    // pool_fuse   SE / FRM channel sums out of the producing conv's epilogue
     int exact_blocks_env = -1;   // MOE_EXACT_BLOCKS (moe_net_set_exact_blocks overrides)
-    int tiles_per_batch = 0;  // tiles_per_batch   tiles of 256^2 pixels per launch set when the caller passes 0 (0: 16)
+    int tiles_per_batch = 0;  // tiles_per_batch   tiles of 256^2 pixels per launch set when the caller passes 0 (0: 32)
     int max_groups = 0;       // max_groups  persistent workgroups per launch (0: one per CU), applied at finalize
     int dbg = 0;              // dbg         timing-ablation bits of the conv kernels (results are wrong when set)
     std::string trace_key = "convt_R1.up1";
@@ -2012,7 +2012,8 @@ int moe_run_plan_ex(moe_net* n, const moe_plan* pl, const void* img, int img_dty
         pool = p.pool;
     }
     if (max_tiles <= 0) {
-        max_tiles = n->opt.tiles_per_batch > 0 ? n->opt.tiles_per_batch : 16;     // (tiles of 256^2 pixels per launch set: 28.97 / 28.59 / 28.42 / 28.28 / 28.33 ms per 1080p x4 frame with 4 / 8 / 12 / 16 / 24, profiles/r03: fewer pipeline fills per pixel)
+        max_tiles = n->opt.tiles_per_batch > 0 ? n->opt.tiles_per_batch : 32;     // (tiles of 256^2 pixels per launch set: 28.97 / 28.59 / 28.42 / 28.28 / 28.33 ms per 1080p x4 frame with 4 / 8 / 12 / 16 / 24 in round 3: fewer pipeline
+                                                                                   // fills per pixel; round 4's kernels, 16 / 20 / 28: 24.32 / 24.20 / 24.09 -- the 28 full tiles of a 1080p frame as ONE launch set; a tile's bits do not depend on it)
     }
     for (size_t gi = 0; gi < p.groups.size(); ++gi) {
         const auto& g = p.groups[gi];
@@ -2095,7 +2096,7 @@ int moe_run_plan_tiles(moe_net* n, const moe_plan* pl, const void* imgs, int img
         d->n_frames = n_frames; d->tile_dst.assign(tile_dst, tile_dst + nt * n_frames);
     }
     if (max_tiles <= 0) {
-        max_tiles = n->opt.tiles_per_batch > 0 ? n->opt.tiles_per_batch : 16;     // (tiles of 256^2 pixels per launch set: 28.97 / 28.59 / 28.42 / 28.28 / 28.33 ms per 1080p x4 frame with 4 / 8 / 12 / 16 / 24, profiles/r03: fewer pipeline fills per pixel)
+        max_tiles = n->opt.tiles_per_batch > 0 ? n->opt.tiles_per_batch : 32;     // (as moe_run_plan_ex)
     }
     for (size_t gi = 0; gi < p.groups.size(); ++gi) {
         const auto& g = p.groups[gi];
