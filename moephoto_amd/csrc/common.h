@@ -187,6 +187,9 @@ hipError_t conv64_q8_init();
 // the chain form of that layer (fp8 low parts in) streamed down a column by one fp16 wave + one fp8 wave per workgroup (conv64_sq.hip); false: not applicable (caller uses conv64_q8)
 bool launch_conv64_sq(ConvX3Args a, int max_groups, hipStream_t s);
 hipError_t conv64_sq_init();
+// conv64_s.hip: SEDN's fused block tail (per-plane weights, LeakyReLU, residual) streamed down 32-pixel columns with the plane's weights in registers; false: not applicable
+bool launch_conv64_s(const ConvArgs& a, int max_groups, hipStream_t s);
+hipError_t conv64_s_init();
 // arsb_sq.hip: ONE exact ARSB of such a chain in one launch -- conv_1's rows stay in LDS (producer / consumer wave pairs); false: not applicable (caller runs the two convs)
 struct ArsbSqArgs {
     const half_t* x_hi; const unsigned char* x_lo8;      // stream in: [B][H][W][64] fp16 + the fp8 low words

@@ -383,6 +383,7 @@ hipError_t conv_mfma_init()
     if ((e = conv64_q8_init()) != hipSuccess) return e;
     if ((e = conv64_sq_init()) != hipSuccess) return e;
     if ((e = arsb_sq_init()) != hipSuccess) return e;
+    if ((e = conv64_s_init()) != hipSuccess) return e;
     if ((e = conv64_x3_init()) != hipSuccess) return e;
     if ((e = conv1x1_init()) != hipSuccess) return e;
     if ((e = conv3x3_rw_init()) != hipSuccess) return e;

@@ -97,6 +97,7 @@ struct NetOptions {
     int x3_impl = 0;          // x3_impl     auto (0, default: q8 for the SR nets, x3 for the DN nets -- see forward) | x3 (1: conv64_x3.hip, three fp16 products) |
                               //             q8 (2: conv64_q8.hip, the two correction products on fp8 operands)
     int k48 = 1;              // k48         1 (default): kernels that can skip the zero k-slice of the 48-channel nets do | 0: they run all four (A/B)
+    int s64 = 1;              // s64         1 (default): SEDN's fused block tail on conv64_s.hip (streamed, per-plane weights in registers) | 0: conv3x3_sp<6>
     int exact_fuse = 1;       // exact_fuse  1 (default): an exact ARSB of a chain runs as ONE launch (arsb_sq.hip: conv_1's rows stay in LDS) | 0: conv_1, conv_2 on conv64_sq / conv64_q8
     int q8_impl = 1;          // q8_impl     s (1, default: conv64_sq.hip, the chain layers streamed down a column by an fp16 wave + an fp8 wave) | p (0: conv64_q8.hip, 8 x 32 patches)
     int arsb_impl = 3;        // arsb_impl   v3 (3, default: arsb32c.hip, ten-row patches) | s (4: arsb_s.hip, rows streamed down 30-pixel columns by two-wave workgroups:
@@ -136,6 +137,7 @@ struct NetOptions {
         if (key == "lo8") { const int t = onoff(v); if (t < 0) return false; lo8 = t; return true; }
         if (key == "x3_impl") { const int t = tri(v, "auto", "x3", "q8", -1); if (t < 0) return false; x3_impl = t; return true; }
         if (key == "k48") { const int t = onoff(v); if (t < 0) return false; k48 = t; return true; }
+        if (key == "s64") { const int t = onoff(v); if (t < 0) return false; s64 = t; return true; }
         if (key == "exact_fuse") { const int t = onoff(v); if (t < 0) return false; exact_fuse = t; return true; }
         if (key == "q8_impl") { if (v && !strcmp(v, "s")) q8_impl = 1; else if (v && !strcmp(v, "p")) q8_impl = 0; else return false; return true; }
         if (key == "arsb_impl") { if (v && !strcmp(v, "s")) arsb_impl = 4; else if (v && !strcmp(v, "v3")) arsb_impl = 3; else return false; return true; }
@@ -154,7 +156,7 @@ struct NetOptions {
     void from_env()
     {
         static const char* const names[][2] = {{"MOE_CONV_IMPL", "conv_impl"}, {"MOE_SP_IMPL", "sp_impl"}, {"MOE_TAIL_SPLIT", "tail_split"}, {"MOE_TAIL_FORM", "tail_form"}, {"MOE_UP_IMPL", "up_impl"},
-                                               {"MOE_CONV1X1", "conv1x1"}, {"MOE_ARSB_IMPL", "arsb_impl"}, {"MOE_Q8_IMPL", "q8_impl"}, {"MOE_EXACT_FUSE", "exact_fuse"}, {"MOE_K48", "k48"}, {"MOE_X3_IMPL", "x3_impl"}, {"MOE_LO8", "lo8"}, {"MOE_X3_FUSE", "x3_fuse"}, {"MOE_ARSB_FUSE", "arsb_fuse"}, {"MOE_FUSE_TAIL", "fuse_tail"},
+                                               {"MOE_CONV1X1", "conv1x1"}, {"MOE_ARSB_IMPL", "arsb_impl"}, {"MOE_Q8_IMPL", "q8_impl"}, {"MOE_EXACT_FUSE", "exact_fuse"}, {"MOE_S64", "s64"}, {"MOE_K48", "k48"}, {"MOE_X3_IMPL", "x3_impl"}, {"MOE_LO8", "lo8"}, {"MOE_X3_FUSE", "x3_fuse"}, {"MOE_ARSB_FUSE", "arsb_fuse"}, {"MOE_FUSE_TAIL", "fuse_tail"},
                                                {"MOE_SEDN_FUSE", "sedn_fuse"}, {"MOE_POOL_FUSE", "pool_fuse"}, {"MOE_DBG", "dbg"}, {"MOE_TRACE_KEY", "trace_key"},
                                                {"MOE_TILES_PER_BATCH", "tiles_per_batch"}, {"MOE_MAX_GROUPS", "max_groups"}};
         for (const auto& nv : names)
@@ -1242,7 +1244,7 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
                     a.px = (w + kTileW - 1) / kTileW; a.py = (h + kTileH - 1) / kTileH;
                     a.G = (int)std::max<long long>(B, std::min<long long>(n.max_groups, (long long)B * a.px * a.py));   // total workgroups (plane b gets every B-th)
                     a.slope = 0.2f; a.scale = 1.f;
-                    if (!launch_conv3x3_sp(a, s)) return fail(MOE_EINVAL, "SEDN fused block tail: kernel rejected the layer");
+                    if (!(n.opt.s64 && launch_conv64_s(a, n.max_groups, s)) && !launch_conv3x3_sp(a, s)) return fail(MOE_EINVAL, "SEDN fused block tail: kernel rejected the layer");
                 }
                 continue;
             }

@@ -1294,3 +1294,27 @@ def test_fused_exact_arsb_is_bit_identical_to_the_two_launch_form(key, blocks, d
     finally:
         m.set_option('exact_fuse', 1)
         m.set_exact_blocks(-1)
+
+
+def test_sedn_block_tail_streamed_vs_patch_form(dev, key='l25'):
+    """Option s64 (default on; conv64_s.hip): SEDN's fused block tail -- y = x + LeakyReLU(conv(W_eff[b], t)) with PER-PLANE weights -- streamed down 32-pixel columns with
+    the plane's 36 A fragments in registers (reloaded where a range enters another plane), instead of conv3x3_sp<6>'s weights in LDS.  Same arithmetic (LeakyReLU in fp32, the
+    residual added in fp32, one rounding), another order of the sums inside a row: both forms within the tolerance of the ORACLE on natural and noise inputs, ragged shapes,
+    several planes per launch (each with its own weights); the streamed form repeats bit for bit."""
+    arch = gd.MODELS[key][0]
+    sd = gd.state_dict_for(key, load_state_dict_file)
+    m = module_for(key)
+    try:
+        for shape in ((3, 8, 8), (2, 24, 40), (2, 40, 264), (3, 16, 72), (1, 88, 64), (1, 6, 33), (2, 2, 40), (5, 32, 30)):
+            for kind in ('natural', 'noise'):
+                x = (gd.natural_image(47, shape) if kind == 'natural' else gd.noise_image(47, shape))[:, None]
+                xd = torch.from_numpy(x).to(dev)
+                want = onets.forward(arch, sd, x).numpy()
+                y0 = m.set_option('s64', 0)(xd)[-1].cpu().numpy()
+                y1 = m.set_option('s64', 1)(xd)[-1].cpu().numpy()
+                assert np.isfinite(y1).all(), (key, shape, kind)
+                assert np.abs(y1 - want).max() <= TOL and np.abs(y0 - want).max() <= TOL, (key, shape, kind, float(np.abs(y1 - want).max()), float(np.abs(y0 - want).max()))
+                assert np.abs(y1 - y0).max() <= 8e-4, (key, shape, kind, float(np.abs(y1 - y0).max()))
+                assert np.array_equal(y1, m(xd)[-1].cpu().numpy()), (key, shape, kind)
+    finally:
+        m.set_option('s64', 1)
