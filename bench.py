@@ -335,15 +335,56 @@ def main():
 
         def loop(_):
             return _reference_style_loop(opt, xin, plan, ramp, torch)
+
+        def loop_fused(_):
+            return _reference_style_loop(opt, xin, plan, ramp, torch, blend_tile=ip.blendTile)
         y_loop = loop(None)
+        y_fused = loop_fused(None)
         torch.cuda.synchronize()
         y_dev = ip.doCrop(opt, xin)
         n_l = max(3, args.steps // 2)
         dtl = timed(None, n_l, loop)
         ms_l = dtl / n_l * 1e3
+        ms_f = timed(None, n_l, loop_fused) / n_l * 1e3
+        # where the loop's time goes: the 40 forwards alone (results dropped), and the blends + assigns alone (on kept tile results)
+        xb_ = plan.padImage(xin).unsqueeze(1)
+
+        def engine_only(_):
+            for t in plan.tiles:
+                opt(xb_[..., t[0]:t[1], t[2]:t[3]])
+        kept = [opt(xb_[..., t[0]:t[1], t[2]:t[3]]).squeeze(1).clone() for t in plan.tiles]
+
+        class _Kept(object):
+            def __init__(self):
+                self.k = 0
+
+            def __call__(self, _):
+                self.k += 1
+                return kept[self.k - 1].unsqueeze(1)
+
+        def blends_only(_):
+            return _reference_style_loop(_Kept(), xin, plan, ramp, torch)
+
+        def blends_fused_only(_):
+            return _reference_style_loop(_Kept(), xin, plan, ramp, torch, blend_tile=ip.blendTile)
+        ms_e = timed(None, n_l, engine_only) / n_l * 1e3
+        ms_b = timed(None, n_l, blends_only) / n_l * 1e3
+        ms_bf = timed(None, n_l, blends_fused_only) / n_l * 1e3
+        del kept
         res['dropin_loop'] = {'value': round(FRAME[1] * FRAME[2] / 1e6 / (ms_l / 1e3), 3), 'unit': 'MP/s', 'ms_per_step': round(ms_l, 3), 'steps': n_l,
                               'ratio_to_value': round(ms_per_step / ms_l, 3),
                               'max_abs_vs_device_docrop': float('{:.3e}'.format(float((y_loop.float() - y_dev.float()).abs().max()))),
+                              'breakdown': {'engine_forwards_only_ms': round(ms_e, 3), 'torch_blends_and_assigns_only_ms': round(ms_b, 3),
+                                            'sum_ms': round(ms_e + ms_b, 3), 'loop_ms': round(ms_l, 3),
+                                            'device_resident_doCrop_ms': round(ms_per_step, 3),
+                                            'note': 'host-inclusive wall per frame, synchronised at both ends; engine_forwards_only = the 40 per-tile calls of 3 planes each with '
+                                                    'the results dropped: what separates it from the headline is launch geometry (3 planes per launch set instead of up to 96); '
+                                                    'rocprofv3 kernel trace of the loop: profiles/r05/'},
+                              'with_moe_blend_tile': {'value': round(FRAME[1] * FRAME[2] / 1e6 / (ms_f / 1e3), 3), 'ms_per_step': round(ms_f, 3), 'ratio_to_value': round(ms_per_step / ms_f, 3),
+                                                      'blend_tile_only_ms': round(ms_bf, 3),
+                                                      'max_abs_vs_device_docrop': float('{:.3e}'.format(float((y_fused.float() - y_dev.float()).abs().max()))),
+                                                      'what': 'the same loop with its two blend() calls + slice-assign replaced by ONE kernel per tile (moe_blend_tile = imageProcess.blendTile, '
+                                                              "INTEGRATION.md section 2: a two-line change in the reference's doCrop); arithmetic = the reference's own fp16 expression, operation by operation"},
                               'what': "the reference's per-tile loop (python/imageProcess.py:157-172) with torch blends, calling models.Net4x.__call__ = moe_net_forward on "
                                       '3 planes of <= 256x256 per call (40 calls per frame, fp16 canvas AND fp16 blends as in the reference GPU path); '
                                       'moe_run_plan (the headline) batches up to 32 same-shaped tiles per launch set and stitches from fp32 tiles'}
@@ -443,7 +484,7 @@ def main():
         raise SystemExit('parity gate failed: the engine differs from the oracle by more than {} (tiles) or the fp16 canvas by more than that plus half an ulp'.format(PARITY_TOL))
 
 
-def _reference_style_loop(opt, x, plan, ramp, torch):
+def _reference_style_loop(opt, x, plan, ramp, torch, blend_tile=None):
     """The loop a MoePhoto maintainer keeps when only the class in runSR.mode_switch is swapped (python/imageProcess.py:157-172): for every
     tile, hand the net a slice VIEW of the planes-as-batch image, cross-fade the fresh result into what the canvas window already
     holds (rows first, then columns, each over `padSc` entries in front of the tile's first new entry), and assign it aligned to the
@@ -464,6 +505,9 @@ def _reference_style_loop(opt, x, plan, ramp, torch):
         return torch.cat([band, fresh.narrow(dim, first_new, n - first_new)], dim), held.narrow(dim, a, n - a)
     wr, wc = ramp.view(-1, 1), ramp.view(1, -1)
     for (top, bottom, left, right, tt, lt, bsc, rsc) in plan.tiles:
+        if blend_tile is not None:       # moe_blend_tile: the two fades + the assign below as one kernel (in place on the canvas)
+            blend_tile(opt(xb[..., top:bottom, left:right]), canvas, (top, bottom, left, right, tt, lt, bsc, rsc), sc, psc, ramp)
+            continue
         r = opt(xb[..., top:bottom, left:right]).squeeze(1)[..., :plan.outH - top * sc, :plan.outW - left * sc]
         held = canvas[..., top * sc:bsc, left * sc:rsc]
         r, held = fade(r, held, tt, -2, wr)

@@ -236,9 +236,9 @@ def run_config(cfg, args):
     {3: _config3, 4: _config4, 5: _config5}[cfg](ns, args)
 
 
-def _run_frames(ns, opt, frames, args):
+def _run_frames(ns, opt, frames, args, bands=False):
     from moephoto_amd.dist import run_frames
-    return run_frames(opt, frames, out_dtype=ns['torch'].float16, max_tiles_per_batch=args.tiles_per_batch, wire=args.wire)
+    return run_frames(opt, frames, out_dtype=ns['torch'].float16, max_tiles_per_batch=args.tiles_per_batch, bands=bands, wire=args.wire)
 
 
 def _config3(ns, args):
@@ -389,7 +389,7 @@ def _config5(ns, args):
     def step():
         if world == 1:
             return ip.doCrop(opt, frame)
-        return _run_frames(ns, opt, [frame], args)       # ONE frame: its 144 tiles over the ranks (strong scaling); the canvas stays sharded in bands (dist.py)
+        return _run_frames(ns, opt, [frame], args, bands=True)       # ONE frame: its 144 tiles over the ranks (strong scaling); the canvas stays sharded in bands (dist.py)
     step()
     steps = args.steps if args.steps_given else 3
     model = opt.modelCached

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MOE_ABI_VERSION 2      /* 2: MOE_PREC_AUTO, moe_net_resolved_precision, moe_plan_rows / moe_stitch_band, moe_plan_seams / moe_wire_* (round 4); 1 also lacked a bump for moe_net_set_option / moe_device_info / moe_stitch_dev */
+#define MOE_ABI_VERSION 3      /* 3: moe_net_calibrate / moe_net_exact_blocks, MOE_PREC_AUTO measures the checkpoint at finalize, moe_blend_tile (round 5); 2: MOE_PREC_AUTO, moe_net_resolved_precision, moe_plan_rows / moe_stitch_band, moe_plan_seams / moe_wire_* (round 4); 1 also lacked a bump for moe_net_set_option / moe_device_info / moe_stitch_dev */
 
 /* error codes */
 #define MOE_OK 0
@@ -101,8 +101,20 @@ int moe_net_set_param(moe_net* net, const char* name, const float* data, const i
  * May be called again to move / change precision.  precision: MOE_PREC_AUTO for the family's default (what a drop-in caller
  * passes), or a specific arithmetic (MIXED is refused for SEDN / lite, which have no such recipe). */
 int moe_net_finalize(moe_net* net, int device, int precision);
-/* what `precision` resolves to for this net's family (MOE_PREC_AUTO -> FP16 / FP16X3 / MIXED; anything else -> itself) */
+/* what `precision` resolves to for this net's family (MOE_PREC_AUTO -> FP16 / FP16X3 / MIXED; anything else -> itself).  After a finalize with MOE_PREC_AUTO:
+ * what that finalize settled on for the loaded weights (see moe_net_calibrate). */
 int moe_net_resolved_precision(const moe_net* net, int precision);
+/* The precision policy for checkpoints the build has never seen (the reference's contract is "load any state dict, get the fp32 answer":
+ * python/imageProcess.py:319-334; its own dtype policy is castModel, :309-317).  Net2x/3x/4x and NetDN under MOE_PREC_MIXED run their first `blocks` ARSBs with
+ * split operands; how many a checkpoint needs depends on how wide its trunk swings.  moe_net_calibrate measures it on the device: uniform uint8-noise tiles (2 x 3
+ * planes of 192 x 192) through the exact arithmetic (FP16X3) and through MIXED with blocks = the architecture's default .. 6; *blocks = the smallest count whose
+ * worst max-abs difference is <= target (target <= 0: 8.5e-4), *err = that difference; *blocks = -1 when six blocks do not reach it (*err = what they reach).
+ * The count is kept (moe_net_exact_blocks) until a parameter changes or moe_net_set_exact_blocks overrides it.  moe_net_finalize(MOE_PREC_AUTO) runs this by itself,
+ * once per checkpoint, and finalizes in MOE_PREC_FP16X3 when no count reaches the target: a drop-in caller needs no extra line.  SEDN / lite: *blocks = 0, nothing
+ * is measured (their AUTO arithmetic has no such knob).  Synchronises `stream`; ~0.1-0.3 s. */
+int moe_net_calibrate(moe_net* net, double target, int* blocks, double* err, void* stream);
+/* the count of split-operand ARSBs the next forward runs with (0 when the net is not in MOE_PREC_MIXED) */
+int moe_net_exact_blocks(const moe_net* net);
 /* device bytes of scratch a forward of B planes of h x w needs (allocated lazily, grow-only, owned by the net) */
 int64_t moe_net_workspace_bytes(const moe_net* net, int B, int h, int w);
 /* largest tile (pixels of one input plane) a forward accepts: the convolution kernels address their tensors with 32-bit byte
@@ -124,13 +136,13 @@ int moe_net_forward(moe_net* net, const void* x, int x_dtype, int B, int h, int 
 int moe_net_set_profile(moe_net* net, const char* layer_substrings);
 int moe_net_get_profile_at(moe_net* net, int index, double* total_ms, int64_t* launches, double* flops);
 int moe_net_get_profile(moe_net* net, double* total_ms, int64_t* launches, double* flops);
-/* MOE_PREC_MIXED only: how many leading ARSBs run with split operands (0..6; -1 = the architecture's default:
- * Net2x 4, Net3x 2, Net4x 1, NetDN 1).  Takes effect at the next forward. */
+/* MOE_PREC_MIXED only: how many leading ARSBs run with split operands (0..6; -1 = the calibrated count of these weights if there is one, else the
+ * architecture's default: Net2x 4, Net3x 2, Net4x 1, NetDN 1).  Takes effect at the next forward. */
 int moe_net_set_exact_blocks(moe_net* net, int blocks);
 /* Kernel-form switches of one net, for A/B measurements and the parity tests that compare forms of one layer in-process
  * ("sp_impl" = "auto" | "rw" | "sp", "arsb_fuse" / "x3_fuse" / "conv1x1" / "fuse_tail" / "sedn_fuse" / "pool_fuse" = "0" | "1",
  * "tail_split" = "0" | "r" | "ru", "tail_form" = "sums" | "planes", "conv_impl" = "sp" | "v1", "tiles_per_batch", "max_groups",
- * "arsb_impl" = "v1" | "v2" | "v3", "k48" = "0" | "1", "x3_impl" = "auto" | "x3" | "q8" (the split-operand layers' kernel: three fp16 products, or the two
+ * "k48" = "0" | "1", "repeat" = "<layer key>:<n>" (measurement: the matching bracketed launches are issued n times -- tools/kernel_power.py), "x3_impl" = "auto" | "x3" | "q8" (the split-operand layers' kernel: three fp16 products, or the two
  * corrections on fp8 operands; auto = q8 for the SR nets), "lo8" = "on" | "off" (fp8 low parts between conv64_q8 layers)).
  * Defaults come from the MOE_* environment variables of the same names ONCE, at moe_net_create; the forward path itself reads no
  * environment.  The reference has no such switches: its forward is torch.nn (python/imageProcess.py:391-395). */
@@ -176,6 +188,16 @@ int moe_stitch_dev(const moe_plan* plan, int device, const float* tiles_dev, con
  * only those strips cross between neighbouring bands), bit-identical to the rows of moe_stitch's canvas. */
 int moe_stitch_band(const moe_plan* plan, int device, const float* tiles_dev, const int64_t* tile_off_dev, int C,
                     void* out, int out_dtype, int row0, int row1, int strip, void* stream);
+/* The body of the reference's tile loop behind the net call, for a caller that KEEPS that loop -- python/imageProcess.py:167-170:
+ *     t = tmp_image[..., top*sc:bsc, left*sc:rsc];  q, _ = blend(*blend(unpad(r), t, topT, padSc, -2, bl.t()), leftT, padSc, -1, bl);  tmp_image[..., bsc-h:bsc, rsc-w:rsc] = q
+ * as one kernel, in place on the canvas.  r: the tile result, C planes, element (c,i,j) at r + c*r_sC + i*r_sH + j (its first bsc-top_sc rows and rsc-left_sc
+ * columns are used: opt.unpad); canvas: element (c,i,j) at canvas + c*c_sC + i*c_sH + j; (top_sc, left_sc, bsc, rsc, topT, leftT) = the tile tuple of iterClip
+ * with top, left already multiplied by the scale; ramp: opt.blend, pad_sc values.  r, canvas and ramp share `dtype` (MOE_F16 on the reference's GPU path, MOE_F32)
+ * and live on the device; the arithmetic is the reference's expression b = bx + blend * (b - bx) evaluated in that dtype, operation by operation: the canvas gets
+ * the very bits the two torch calls produce.  Asynchronous on `stream`. */
+int moe_blend_tile(const void* r, int64_t r_sC, int64_t r_sH, void* canvas, int64_t c_sC, int64_t c_sH, int dtype, int C,
+                   int top_sc, int left_sc, int bsc, int rsc, int topT, int leftT, int pad_sc, const void* ramp, void* stream);
+
 /* ---- wire format of tile results between ranks (moephoto_amd/dist.py, wire = 'f16s') ------------------------------------------------
  * The reference has no multi-device code; this belongs to the tile-parallel layer around doCrop (python/imageProcess.py:120-172).  A tile's fp32
  * value is needed exactly only where a blend reads it: in the tile's own blend band and under the blend bands of later tiles (imageProcess.py:

@@ -127,6 +127,9 @@ struct Ps4Args {
 };
 bool launch_conv3x3_ps4(const Ps4Args& a, int max_groups, hipStream_t s);   // false: not applicable (caller keeps conv3x3_rw + tapsum4)
 bool ps4_applicable(int B, int H, int W);                                    // the shape conditions of the launcher (planning)
+// the ONE predicate of the fused-tail form: the engine plans its buffers with it and launch_conv3x3_ps4 refuses with it -- a condition added to one side only would
+// turn a performance choice into a failed forward
+inline bool ps4_tail_applicable(int B, int H, int W, float slope) { return slope < 1.f && ps4_applicable(B, H, W); }
 size_t ps4_plane_bytes(int B, int H, int W);
 size_t ps4_apron_bytes(int B, int H, int W);
 hipError_t conv3x3_ps4_init();
@@ -155,9 +158,6 @@ struct ArsbArgs {
 // arsb32c.hip: v_mfma_f32_32x32x16_f16, four waves in lock-step, both convs' weights resident (w1 / w2 in the pack_conv fragment order, ConvLayer::w_hi), ten output rows
 // per patch, the two last m rows of a patch stay in LDS for the patch below.  false: not applicable (the caller runs the two convs)
 bool launch_arsb32c(ArsbArgs a, int max_groups, hipStream_t s);
-// arsb_s.hip: the same ARSB streamed down 30-pixel columns (two waves per workgroup, two workgroups per CU, every row step 72 MFMAs), bit-identical results
-bool launch_arsb_s(ArsbArgs a, int max_groups, hipStream_t s);
-hipError_t arsb_s_init();
 hipError_t arsb32c_init();
 
 // One 3x3 64->64 conv with split operands, three products in one launch (conv64_x3.hip); weights in the fused-ARSB order
@@ -332,6 +332,17 @@ struct StitchArgs {
     int y0, rows;                                    // the canvas rows [y0, y0 + rows) are folded into `out` = (C, rows, out_w): the whole canvas (0, out_h) or a band (moe_stitch_band)
 };
 void launch_stitch(const StitchArgs& a, hipStream_t s);
+
+// blend.hip: the two blend() calls + slice-assign of doCrop's loop body for ONE tile, in the canvas dtype (moe_blend_tile)
+struct BlendTileArgs {
+    const void* r; void* canvas; const void* ramp;   // tile result (C planes, unit column stride), canvas (C planes), ramp [pad_sc]: all of the canvas dtype, device
+    long long r_sC, r_sH, c_sC, c_sH;                // strides in elements
+    int C, rh, rw;                                   // window extent = rows / columns of the tile result that are used (opt.unpad)
+    int top_sc, left_sc;                             // window origin in the canvas
+    int r0, c0;                                      // first assigned row / column of the window (lt - pad_sc, or 0 without a band)
+    int lt_h, lt_w;                                  // first un-blended row / column (band = [r0, lt_h) / [c0, lt_w); equal to r0 / c0 without a band)
+};
+void launch_blend_tile(const BlendTileArgs& a, bool f16, hipStream_t s);
 
 // One record of the inter-rank wire format (moe_wire_pack / moe_wire_unpack; the public moe_wire_rec has the same layout): a tile (or strip) of C planes of
 // th x tw fp32 values <-> [fp16 image of all values | fp32 seam rows | fp32 seam columns], offsets in 4-byte words.

@@ -639,7 +639,7 @@ bool ps4_applicable(int B, int H, int W)
 // false: not applicable (the caller keeps conv3x3_rw + tapsum4)
 bool launch_conv3x3_ps4(const Ps4Args& a, int max_groups, hipStream_t s)
 {
-    if (!(a.slope < 1.f) || !ps4_applicable(a.B, a.H, a.W)) return false;
+    if (!ps4_tail_applicable(a.B, a.H, a.W, a.slope)) return false;      // (the store form below has the same shape conditions)
     const int px = (a.W + kTileW - 1) / kTileW;
     const long long items = (long long)a.B * px * (a.H / RB);
     const int G = (int)std::min<long long>(items, max_groups);

@@ -379,7 +379,6 @@ hipError_t conv_mfma_init()
     if ((e = set_lds_limit<1, 3>()) != hipSuccess) return e;
     if ((e = conv3x3_sp_init()) != hipSuccess) return e;
     if ((e = arsb32c_init()) != hipSuccess) return e;
-    if ((e = arsb_s_init()) != hipSuccess) return e;
     if ((e = conv64_q8_init()) != hipSuccess) return e;
     if ((e = conv64_sq_init()) != hipSuccess) return e;
     if ((e = arsb_sq_init()) != hipSuccess) return e;

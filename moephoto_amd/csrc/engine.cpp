@@ -57,7 +57,7 @@ struct ConvLayer {               // one MFMA convolution
     size_t w_hi = 0, w_lo = 0, bias = 0, bias_img = 0, w_plain = 0, bias_plain = 0, w_pk32 = 0;   // offsets into the device blob
     size_t w_arsb_lo = 0;        // ... and their low parts ((w - fp16(w)) * 2^11) in the same order, for conv64_x3.hip
     size_t wq_hi8 = 0, wq_lo8 = 0;   // ... w_hi 2^8 and w_lo 2^8 as fp8 e4m3 A fragments of v_mfma_scale_f32_32x32x64_f8f6f4 (conv64_q8.hip): [tap 9][half 2][lane 64][32 B]
-    size_t w_arsb = 0;           // 3x3 64->64 trunk convs: A fragments of v_mfma_f32_16x16x32_f16 in the fused ARSB kernel's order (arsb_fused.hip)
+    size_t w_arsb = 0;           // 3x3 64->64 trunk convs: A fragments of v_mfma_f32_16x16x32_f16 in conv64_x3.hip's order (the register-weight 16x16x32 form; round 2's arsb_fused.hip, retired, introduced it)
     size_t w_x3 = 0;             // 1x1, one segment, split precision: [chunk][w_lo | w_hi | w_hi] for the single-launch path (acc_mode 4)
     bool has_x3 = false;
     bool has_bias = false;
@@ -100,20 +100,21 @@ struct NetOptions {
     int s64 = 1;              // s64         1 (default): SEDN's fused block tail on conv64_s.hip (streamed, per-plane weights in registers) | 0: conv3x3_sp<6>
     int exact_fuse = 1;       // exact_fuse  1 (default): an exact ARSB of a chain runs as ONE launch (arsb_sq.hip: conv_1's rows stay in LDS) | 0: conv_1, conv_2 on conv64_sq / conv64_q8
     int q8_impl = 1;          // q8_impl     s (1, default: conv64_sq.hip, the chain layers streamed down a column by an fp16 wave + an fp8 wave) | p (0: conv64_q8.hip, 8 x 32 patches)
-    int arsb_impl = 3;        // arsb_impl   v3 (3, default: arsb32c.hip, ten-row patches) | s (4: arsb_s.hip, rows streamed down 30-pixel columns by two-wave workgroups:
-                              //             bit-identical, measured 7 % SLOWER -- both forms sit at the package power cap with the same MFMA rate (busy x clock 0.73 x 1.65
-                              //             vs 0.69 x 1.74 GHz) and the streamed one issues 9 % more MFMAs on rows it recomputes at range starts; kept as the A/B)
-                              // (arsb_impl: round 3 kept three generations of the one-launch ARSB side by side -- arsb_fused.hip, arsb32.hip, arsb32c.hip; only the last,
-                              // the default since, is built now: the earlier two are in the history at 689845f)
+                              // (the one-launch ARSB of the single-pass blocks is arsb32c.hip.  Earlier generations -- arsb_fused.hip, arsb32.hip (history at 689845f) and the streamed
+                              // form arsb_s.hip (round 4: bit-identical, 7 % slower, both at the package power cap; history at 321d022, profiles/r04/d_arsb_streamed_vs_patch.txt) -- are
+                              // no longer built)
     bool fuse_tail = true;    // fuse_tail   last upsampler conv + 64->1 / 48->1 tail conv in one kernel
     bool sedn_fuse = true;    // sedn_fuse   SEDN's fused block tail
     bool pool_fuse = true;    // pool_fuse   SE / FRM channel sums out of the producing conv's epilogue
+    int auto_calibrate = 1;   // auto_calibrate  1 (default): moe_net_finalize(MOE_PREC_AUTO) measures the count of split-operand ARSBs on the loaded weights | 0: per-architecture defaults
     int exact_blocks_env = -1;   // MOE_EXACT_BLOCKS (moe_net_set_exact_blocks overrides)
     int tiles_per_batch = 0;  // tiles_per_batch   tiles of 256^2 pixels per launch set when the caller passes 0 (0: 32)
     int max_groups = 0;       // max_groups  persistent workgroups per launch (0: one per CU), applied at finalize
     int dbg = 0;              // dbg         timing-ablation bits of the conv kernels (results are wrong when set)
     std::string trace_key = "convt_R1.up1";
     bool arsb_trace = false;
+    std::string repeat_key;   // repeat      "<layer key substring>:<n>": the bracketed launches (prof_begin sites) of matching layers are issued n times -- measurement only (tools/kernel_power.py:
+    int repeat_n = 1;         //             one kernel looped by itself while rocm-smi samples the package power and clock); the launches are idempotent, results do not change
 
     static int tri(const char* v, const char* a0, const char* a1, const char* a2, int dflt)
     {
@@ -138,9 +139,9 @@ struct NetOptions {
         if (key == "x3_impl") { const int t = tri(v, "auto", "x3", "q8", -1); if (t < 0) return false; x3_impl = t; return true; }
         if (key == "k48") { const int t = onoff(v); if (t < 0) return false; k48 = t; return true; }
         if (key == "s64") { const int t = onoff(v); if (t < 0) return false; s64 = t; return true; }
+        if (key == "auto_calibrate") { const int t = onoff(v); if (t < 0) return false; auto_calibrate = t; return true; }
         if (key == "exact_fuse") { const int t = onoff(v); if (t < 0) return false; exact_fuse = t; return true; }
         if (key == "q8_impl") { if (v && !strcmp(v, "s")) q8_impl = 1; else if (v && !strcmp(v, "p")) q8_impl = 0; else return false; return true; }
-        if (key == "arsb_impl") { if (v && !strcmp(v, "s")) arsb_impl = 4; else if (v && !strcmp(v, "v3")) arsb_impl = 3; else return false; return true; }
         if (key == "conv1x1") return flag(conv1x1);
         if (key == "x3_fuse") return flag(x3_fuse);
         if (key == "arsb_fuse") return flag(arsb_fuse);
@@ -151,12 +152,18 @@ struct NetOptions {
         if (key == "tiles_per_batch") { tiles_per_batch = atoi(v); return tiles_per_batch >= 0; }
         if (key == "max_groups") { max_groups = atoi(v); return max_groups >= 0; }
         if (key == "trace_key") { trace_key = v; return true; }
+        if (key == "repeat") {
+            const char* c = strrchr(v, ':');
+            if (!c) { repeat_key.clear(); repeat_n = 1; return !*v || !strcmp(v, "0"); }
+            repeat_key.assign(v, c - v); repeat_n = atoi(c + 1);
+            return repeat_n >= 1;
+        }
         return false;
     }
     void from_env()
     {
         static const char* const names[][2] = {{"MOE_CONV_IMPL", "conv_impl"}, {"MOE_SP_IMPL", "sp_impl"}, {"MOE_TAIL_SPLIT", "tail_split"}, {"MOE_TAIL_FORM", "tail_form"}, {"MOE_UP_IMPL", "up_impl"},
-                                               {"MOE_CONV1X1", "conv1x1"}, {"MOE_ARSB_IMPL", "arsb_impl"}, {"MOE_Q8_IMPL", "q8_impl"}, {"MOE_EXACT_FUSE", "exact_fuse"}, {"MOE_S64", "s64"}, {"MOE_K48", "k48"}, {"MOE_X3_IMPL", "x3_impl"}, {"MOE_LO8", "lo8"}, {"MOE_X3_FUSE", "x3_fuse"}, {"MOE_ARSB_FUSE", "arsb_fuse"}, {"MOE_FUSE_TAIL", "fuse_tail"},
+                                               {"MOE_CONV1X1", "conv1x1"}, {"MOE_Q8_IMPL", "q8_impl"}, {"MOE_EXACT_FUSE", "exact_fuse"}, {"MOE_AUTO_CALIBRATE", "auto_calibrate"}, {"MOE_S64", "s64"}, {"MOE_K48", "k48"}, {"MOE_X3_IMPL", "x3_impl"}, {"MOE_LO8", "lo8"}, {"MOE_X3_FUSE", "x3_fuse"}, {"MOE_ARSB_FUSE", "arsb_fuse"}, {"MOE_FUSE_TAIL", "fuse_tail"},
                                                {"MOE_SEDN_FUSE", "sedn_fuse"}, {"MOE_POOL_FUSE", "pool_fuse"}, {"MOE_DBG", "dbg"}, {"MOE_TRACE_KEY", "trace_key"},
                                                {"MOE_TILES_PER_BATCH", "tiles_per_batch"}, {"MOE_MAX_GROUPS", "max_groups"}};
         for (const auto& nv : names)
@@ -177,7 +184,12 @@ struct moe_net {
     std::map<std::string, int> index;
     bool finalized = false;
     int device = -1, precision = MOE_PREC_FP16;
-    int exact_blocks = -1;       // MOE_PREC_MIXED: leading ARSBs computed with split operands (-1: per-architecture default)
+    int exact_blocks = -1;       // MOE_PREC_MIXED: leading ARSBs computed with split operands (-1: the calibrated count if there is one, else the per-architecture default)
+    // calibration of THESE weights (moe_net_calibrate; run by moe_net_finalize(MOE_PREC_AUTO) on the ARSB nets): valid until a parameter changes
+    bool calib_valid = false;
+    int calib_blocks = -1;       // smallest count of split-operand ARSBs whose worst noise-tile error against the exact mode is within the target (-1: none is -> FP16X3)
+    double calib_err = 0.0;      // that error
+    int auto_resolved = -1;      // what MOE_PREC_AUTO resolved to at the last finalize with it (-1: not finalized that way since the parameters changed)
     // device weights
     char* blob = nullptr;
     size_t blob_bytes = 0;
@@ -377,7 +389,7 @@ void pack_conv(const Param& W, const Param* bias, int r, ConvLayer& L, BlobBuild
 
 }  // namespace
 
-// Fused-ARSB weight order (arsb_fused.hip): [wave w][fragment f = tap * 2 + kh][lane l][e], lane l = (m = l & 15, kq = l >> 4) holds
+// conv64_x3.hip's weight order (introduced by round 2's arsb_fused.hip, retired): [wave w][fragment f = tap * 2 + kh][lane l][e], lane l = (m = l & 15, kq = l >> 4) holds
 // W[cout = 16w + m][cin = 8 * SL(kh, kq) + e][tap] with SL(kh, kq) = (2kh + (kq >> 1)) ^ 4(kq & 1) -- the k order in which that kernel's
 // bank-conflict-free LDS image delivers the activations
 static void pack_arsb(const Param& W, ConvLayer& L, BlobBuilder& bb, float fold, bool want_lo)
@@ -466,7 +478,7 @@ static int build_device_weights(moe_net& n, int precision)
         pack_conv(*n.get(wname), b, r, L, bb, lo, plain, per_plane, plain ? 1.f : scale);
         L.slope = slope; L.scale = plain ? scale : 1.f; L.per_plane = per_plane;
         // every bias-free 3x3 conv with <= 64 channels in and out (the trunks of Net*x / NetDN, lite's LB convs, SEDN's rblock.0/2) also gets
-        // the register-resident weight order of arsb_fused.hip / conv64_x3.hip (+ its low part where split operands may be asked for)
+        // the register-resident weight order of conv64_x3.hip (+ its low part where split operands may be asked for)
         if (!plain && r == 1 && L.taps == 9 && L.nseg == 1 && L.nchunks == 1 && !b && !per_plane)
         {
             pack_arsb(*n.get(wname), L, bb, scale, lo);
@@ -694,6 +706,7 @@ struct Fwd {
         return -1;
     }
     void prof_end(int rec) { if (rec >= 0) (void)hipEventRecord(n.prof_ev[rec].e1, s); }
+    int repeats(const std::string& key) const { return (!n.opt.repeat_key.empty() && key.find(n.opt.repeat_key) != std::string::npos) ? n.opt.repeat_n : 1; }
 
     // one convolution layer: in [B][H][W][64*nseg] -> out [B][H*r][W*r][r>1 ? 64 : 64*nchunks]
     // returns false only when asked for the fused tail (tplanes != nullptr) and the fused kernel cannot take the layer
@@ -914,6 +927,8 @@ size_t acc32_need(const moe_net& n, int B, int h, int w)
     return best;
 }
 
+int default_exact_blocks(int arch);
+
 int exact_blocks_of(const moe_net& n)
 {
     // leading ARSBs with split operands under MOE_PREC_MIXED.  Emulated error budget (tools/emu_precision.py), worst
@@ -922,7 +937,13 @@ int exact_blocks_of(const moe_net& n)
     if (n.exact_blocks >= 0) return n.exact_blocks > 6 ? 6 : n.exact_blocks;
     const int env = n.opt.exact_blocks_env;
     if (env >= 0) return env > 6 ? 6 : env;
-    switch (n.arch) {
+    if (n.calib_valid && n.calib_blocks >= 0) return n.calib_blocks;      // measured on this checkpoint (moe_net_calibrate), never below the architecture's default
+    return default_exact_blocks(n.arch);
+}
+
+int default_exact_blocks(int arch)
+{
+    switch (arch) {
         case MOE_ARCH_NET2X: return 4;      // measured on the GPU, worst tile of three 1080p uint8-noise frames vs the exact mode: 1.6e-3 / 1.3e-3 / 8.8e-4 / 7.0e-4 / 5.3e-4
                                             // with 1 / 2 / 3 / 4 / 6 blocks at 14.4 / 16.0 / 17.6 / 19.0 / 22.2 ms per frame (profiles/r03): 4 keeps 30 % of margin
         case MOE_ARCH_NET3X: return 2;
@@ -1059,8 +1080,8 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
                         ArsbArgs q2 = q;
                         q2.w1 = f.blob<half_t>(L1.w_hi); q2.w2 = f.blob<half_t>(L2.w_hi);      // (pack_conv order; conv_2's carry the ScaleLayer factor as well)
                         q2.cin = (L1.cin == 48 && L2.cin == 48 && n.opt.k48) ? 48 : 64;      // NetDN: channels 48..63 are zeros in activations and weights
-                        if (n.opt.arsb_impl == 4) done = launch_arsb_s(q2, n.max_groups, s);
-                        if (!done) done = launch_arsb32c(q2, n.max_groups, s);      // (false: the shape does not fit its 32-bit offsets -- the two-launch form below)
+                        for (int rep = f.repeats("arsb" + std::to_string(i)); rep > 0; --rep)
+                            done = launch_arsb32c(q2, n.max_groups, s);      // (false: the shape does not fit its 32-bit offsets -- the two-launch form below)
                     }
                     f.prof_end(rec);
                     if (q.trace) {
@@ -1071,7 +1092,7 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
                         (void)hipFree(q.trace);
                     }
                 }
-                if (done) { std::swap(cur, oth); f.tap("arsb" + std::to_string(i), cur, h, w, 64, n.C); continue; }
+                if (done) { std::swap(cur, oth); cur.lo8 = oth.lo8 = false; f.tap("arsb" + std::to_string(i), cur, h, w, 64, n.C); continue; }      // (fp16 low parts out; the scratch side's form is its next writer's)
             }
             if (ex && chain8 && n.opt.exact_fuse && n.opt.q8_impl == 1 && cur.lo8 && cur.lo && oth.lo) {
                 // an exact block of the chain in ONE launch (arsb_sq.hip): x = cur (fp16 + fp8 low words) -> oth; the last exact block writes fp16 low parts (the
@@ -1094,6 +1115,7 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
                 if (done) {
                     std::swap(cur, oth);
                     cur.lo8 = i < nx;
+                    oth.lo8 = false;             // (scratch now: whoever writes it next decides its form)
                     f.tap("arsb" + std::to_string(i), cur, h, w, 64, n.C);
                     continue;
                 }
@@ -1123,13 +1145,15 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
             for (int st = 0; st + 1 < n.stages; ++st) { hl *= n.r; wl *= n.r; }
             bool ok = fuse && n.opt.tail_form == 1 && n.r == 2 && wl % 4 == 0 && tailsum_fits(B, hl, wl) &&
                       2ll * B * hl * wl * 64 + 2ll * (wl + 1) * 64 < (1ll << 32) - 65536;
+            bool ps4_ok = true;
             for (const char* br : {"u", "convt_R1"}) {
                 const auto it = n.conv_index.find(std::string(br) + ".up" + std::to_string(n.stages - 1));
                 ok = ok && it != n.conv_index.end() && n.convs[it->second].slope < 1.f;
+                ps4_ok = ps4_ok && it != n.conv_index.end() && ps4_tail_applicable(B, hl, wl, n.convs[it->second].slope);      // (the launcher's own predicate: common.h)
             }
             f.tail_form = ok ? 1 : 0;
             // the same layer with all four phases in one workgroup (conv3x3_ps4.hip): one fp32 plane + column aprons per branch, added by tailadd
-            ps4 = ok && n.opt.up_impl == 1 && ps4_applicable(B, hl, wl) && (2 * wl) % 8 == 0;
+            ps4 = ok && n.opt.up_impl == 1 && ps4_ok && (2 * wl) % 8 == 0;
         }
         float* ps_plane[2] = {nullptr, nullptr};
         float* ps_apron[2] = {nullptr, nullptr};
@@ -1149,7 +1173,8 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
                         q.plane = ps_plane[br]; q.apron = ps_apron[br]; q.slope = L.slope; q.B = B; q.H = H; q.W = W;
                         q.split = (f.mixed && f.tail_split_for(key)) ? 1 : 0;
                         const int rec = f.prof_begin(key, 2.0 * (double)B * H * W * L.cout * L.cin * L.taps);
-                        const bool done = launch_conv3x3_ps4(q, n.max_groups, s);
+                        bool done = false;
+                        for (int rep = f.repeats(key); rep > 0; --rep) done = launch_conv3x3_ps4(q, n.max_groups, s);
                         f.prof_end(rec);
                         if (!done) return fail(MOE_EINVAL, "fused tail kernel (ps4) rejected layer %s", key.c_str());
                     }
@@ -1410,6 +1435,69 @@ int forward_dev_chunk(moe_net& n, const void* x, int x_dtype, int B, int h, int 
     return MOE_OK;
 }
 
+// ---- calibration of one checkpoint (moe_net_calibrate) ---------------------------------------------------------------------------------
+// The per-architecture counts of split-operand ARSBs were chosen on the zoo's weights with ~2e-4 of the 1e-3 budget to spare on uint8 noise; a checkpoint
+// whose trunk swings wider spends more (profiles/r04/n_margin_sweep_and_fuzz_final_tree.txt: the trunk's weights x 1.15 -> 1.3e-3 / 1.8e-3 with the defaults).
+// The reference's contract is "load any state dict, get the fp32 answer" (python/imageProcess.py:319-334), so the count is a property of the CHECKPOINT and is
+// measured when it is loaded: two uniform uint8-noise tiles of 3 x 192 x 192 (the input class that spends the most: SURVEY.md appendix) go through the exact mode
+// (FP16X3: pinned to the fp32 oracle at 2e-5 by the tests) and through MIXED with n = default .. 6 blocks; the smallest n whose worst max-abs difference is within
+// `target` is kept, and when not even six blocks reach it the net runs in FP16X3.  ~0.1-0.3 s once per checkpoint and device.
+constexpr double kCalibTarget = 8.5e-4;       // leaves 1.5e-4 of the 1e-3 contract to tile-to-tile spread (all-tile sweeps: the worst tile of a 1080p noise frame is
+                                              // within 0.5e-4 of its median) and to the exact mode's own 2e-5
+
+bool calibratable(const moe_net& n) { return n.arch == MOE_ARCH_NET2X || n.arch == MOE_ARCH_NET3X || n.arch == MOE_ARCH_NET4X || n.arch == MOE_ARCH_NETDN; }
+
+int calibrate_blocks(moe_net& n, double target, hipStream_t s)
+{
+    if (!(target > 0)) target = kCalibTarget;
+    const int B = 6, h = 192, w = 192, sc = n.scale;
+    const size_t nin = (size_t)B * h * w, nout = nin * sc * sc;
+    std::vector<float> x(nin), ref(nout), got(nout);
+    unsigned long long st = 0x9E3779B97F4A7C15ull;             // splitmix64 -> bytes -> / 255: the uint8 noise of SURVEY 8(d), from a fixed seed
+    for (size_t i = 0; i < nin; i += 8) {
+        unsigned long long z = (st += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+        for (size_t k = 0; k < 8 && i + k < nin; ++k) x[i + k] = (float)((z >> (8 * k)) & 255) / 255.f;
+    }
+    float *xd = nullptr, *yd = nullptr;
+    HIP_TRY(hipSetDevice(n.device));
+    HIP_TRY(hipMalloc((void**)&xd, nin * 4));
+    if (hipMalloc((void**)&yd, nout * 4) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(xd); return fail(MOE_ENOMEM, "moe_net_calibrate: %zu bytes of scratch do not fit", nout * 4); }
+    struct Guard { float *a, *b; ~Guard() { (void)hipFree(a); (void)hipFree(b); } } guard{xd, yd};
+    HIP_TRY(hipMemcpyAsync(xd, x.data(), nin * 4, hipMemcpyHostToDevice, s));
+    const int prec0 = n.precision, blocks0 = n.exact_blocks;
+    const bool debug0 = n.debug;
+    n.debug = false;
+    auto run = [&](std::vector<float>& out) -> int {
+        int rc = forward_dev(n, xd, MOE_F32, B, h, w, (long long)h * w, w, 1, nullptr, yd, MOE_F32, nullptr, s);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(out.data(), yd, nout * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        return MOE_OK;
+    };
+    auto restore = [&](int rc) { n.exact_blocks = blocks0; n.debug = debug0; return rc; };
+    int rc = build_device_weights(n, MOE_PREC_FP16X3);
+    if (rc) return restore(rc);
+    n.precision = MOE_PREC_FP16X3;
+    if ((rc = run(ref))) { n.precision = prec0; (void)build_device_weights(n, prec0); return restore(rc); }
+    if ((rc = build_device_weights(n, MOE_PREC_MIXED))) return restore(rc);
+    n.precision = MOE_PREC_MIXED;
+    n.calib_valid = false; n.calib_blocks = -1; n.calib_err = 0.0;
+    int best = -1;
+    double err = 0.0;
+    for (int nb = default_exact_blocks(n.arch); nb <= 6; ++nb) {
+        n.exact_blocks = nb;
+        if ((rc = run(got))) break;
+        double e = 0.0;
+        for (size_t i = 0; i < nout; ++i) { const double d = std::fabs((double)got[i] - (double)ref[i]); if (!(d <= e)) e = d; }      // (a NaN counts as a failure)
+        err = e;
+        if (e <= target) { best = nb; break; }
+    }
+    if (!rc) { n.calib_valid = true; n.calib_blocks = best; n.calib_err = err; }
+    if (prec0 != MOE_PREC_MIXED) { n.precision = prec0; const int rc2 = build_device_weights(n, prec0); if (!rc) rc = rc2; }
+    return restore(rc);
+}
+
 }  // namespace
 
 // =====================================================================================================
@@ -1572,6 +1660,8 @@ int moe_net_set_param(moe_net* n, const char* name, const float* data, const int
     p.data.assign(data, data + p.numel());
     p.set = true;
     n->finalized = false;
+    n->calib_valid = false;          // (a measurement of other weights)
+    n->auto_resolved = -1;
     return MOE_OK;
 }
 
@@ -1591,12 +1681,14 @@ int moe_net_resolved_precision(const moe_net* n, int precision)
 {
     if (!n) return fail(MOE_EINVAL, "moe_net_resolved_precision: NULL net");
     if (precision < MOE_PREC_FP16 || precision > MOE_PREC_AUTO) return fail(MOE_EINVAL, "moe_net_resolved_precision: unknown precision %d", precision);
+    if (precision == MOE_PREC_AUTO && n->auto_resolved >= 0) return n->auto_resolved;      // (what the last finalize with AUTO settled on for these weights)
     return resolve_precision(n->arch, precision);
 }
 
 int moe_net_finalize(moe_net* n, int device, int precision)
 {
     if (!n) return fail(MOE_EINVAL, "moe_net_finalize: NULL net");
+    const bool autop = precision == MOE_PREC_AUTO;
     if (precision == MOE_PREC_AUTO) precision = resolve_precision(n->arch, precision);
     if (precision != MOE_PREC_FP16 && precision != MOE_PREC_FP16X3 && precision != MOE_PREC_DEBUG_DIRECT && precision != MOE_PREC_MIXED)
         return fail(MOE_EINVAL, "moe_net_finalize: unknown precision %d", precision);
@@ -1617,7 +1709,43 @@ int moe_net_finalize(moe_net* n, int device, int precision)
     int rc = build_device_weights(*n, precision);
     if (rc) return rc;
     n->finalized = true;
+    if (autop) {
+        // MOE_PREC_AUTO promises the 1e-3 contract for THIS checkpoint, not for the zoo's: the ARSB nets measure their count of split-operand blocks on the device
+        // now (calibrate_blocks above; once per checkpoint -- the result is kept until a parameter changes), and fall back to FP16X3 when no count reaches the target.
+        // An explicit moe_net_set_exact_blocks / MOE_EXACT_BLOCKS or option auto_calibrate = 0 leaves the per-architecture default in force.
+        if (precision == MOE_PREC_MIXED && calibratable(*n) && n->opt.auto_calibrate && n->exact_blocks < 0 && n->opt.exact_blocks_env < 0) {
+            if (!n->calib_valid) {
+                rc = calibrate_blocks(*n, 0.0, nullptr);
+                if (rc) { n->finalized = false; return rc; }
+            }
+            if (n->calib_blocks < 0) {
+                rc = build_device_weights(*n, MOE_PREC_FP16X3);
+                if (rc) { n->finalized = false; return rc; }
+                n->precision = precision = MOE_PREC_FP16X3;
+            }
+        }
+        n->auto_resolved = precision;
+    }
     return MOE_OK;
+}
+
+int moe_net_calibrate(moe_net* n, double target, int* blocks, double* err, void* stream)
+{
+    if (!n) return fail(MOE_EINVAL, "moe_net_calibrate: NULL net");
+    if (!n->finalized) return fail(MOE_ESTATE, "moe_net_calibrate: net is not finalized");
+    if (!calibratable(*n)) { if (blocks) *blocks = 0; if (err) *err = 0.0; return MOE_OK; }      // SEDN / lite: no such knob (their AUTO arithmetic has no split-block count)
+    if (n->precision != MOE_PREC_MIXED && n->precision != MOE_PREC_FP16X3) return fail(MOE_ESTATE, "moe_net_calibrate: finalize with MOE_PREC_AUTO or MOE_PREC_MIXED first");
+    const int rc = calibrate_blocks(*n, target, (hipStream_t)stream);
+    if (rc) return rc;
+    if (blocks) *blocks = n->calib_blocks;
+    if (err) *err = n->calib_err;
+    return MOE_OK;
+}
+
+int moe_net_exact_blocks(const moe_net* n)
+{
+    if (!n) return fail(MOE_EINVAL, "moe_net_exact_blocks: NULL net");
+    return (n->precision == MOE_PREC_MIXED && calibratable(*n)) ? exact_blocks_of(*n) : 0;
 }
 
 int64_t moe_net_workspace_bytes(const moe_net* n, int B, int h, int w)
@@ -1986,6 +2114,32 @@ int moe_stitch_band(const moe_plan* p, int device, const float* tiles_dev, const
     launch_stitch(a, (hipStream_t)stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MOE_EHIP, "stitch launch failed: %s", hipGetErrorString(e));
+    return MOE_OK;
+}
+
+int moe_blend_tile(const void* r, int64_t r_sC, int64_t r_sH, void* canvas, int64_t c_sC, int64_t c_sH, int dtype, int C,
+                   int top_sc, int left_sc, int bsc, int rsc, int topT, int leftT, int pad_sc, const void* ramp, void* stream)
+{
+    if (!r || !canvas || C < 1) return fail(MOE_EINVAL, "moe_blend_tile: NULL argument");
+    if (dtype != MOE_F32 && dtype != MOE_F16) return fail(MOE_EINVAL, "moe_blend_tile: dtype must be MOE_F32 or MOE_F16");
+    const int rh = bsc - top_sc, rw = rsc - left_sc;
+    if (rh < 1 || rw < 1 || top_sc < 0 || left_sc < 0 || pad_sc < 0) return fail(MOE_EINVAL, "moe_blend_tile: empty or negative window (%d..%d, %d..%d)", top_sc, bsc, left_sc, rsc);
+    // blend(r, x, lt, pad, dim, ..), python/imageProcess.py:120-131: lt < 0 counts from the end; lt < 1: nothing is blended and the whole extent is assigned
+    auto band = [&](int lt, int l, int& first, int& solid) {
+        if (lt < 0) lt += l;
+        if (lt < 1) { first = solid = 0; return true; }
+        first = lt - pad_sc; solid = lt;
+        return first >= 0 && lt <= l;
+    };
+    BlendTileArgs a{};
+    if (!band(topT, rh, a.r0, a.lt_h) || !band(leftT, rw, a.c0, a.lt_w))
+        return fail(MOE_EINVAL, "moe_blend_tile: blend band outside the window (topT %d, leftT %d, pad_sc %d, window %d x %d)", topT, leftT, pad_sc, rh, rw);
+    if ((a.lt_h > a.r0 || a.lt_w > a.c0) && !ramp) return fail(MOE_EINVAL, "moe_blend_tile: ramp is NULL");
+    a.r = r; a.canvas = canvas; a.ramp = ramp; a.r_sC = r_sC; a.r_sH = r_sH; a.c_sC = c_sC; a.c_sH = c_sH;
+    a.C = C; a.rh = rh; a.rw = rw; a.top_sc = top_sc; a.left_sc = left_sc;
+    launch_blend_tile(a, dtype == MOE_F16, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MOE_EHIP, "blend launch failed: %s", hipGetErrorString(e));
     return MOE_OK;
 }
 

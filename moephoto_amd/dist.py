@@ -483,11 +483,18 @@ def _layout(opt, frames, group, dev, rank, world, C, bands, nbuf=1, wire=None):
     return plan, ex, bufs, padded, fstride
 
 
-def run_frames(opt, frames, group=None, out_dtype=None, max_tiles_per_batch=0, bands=None, wire=None):
+def run_frame_bands(opt, frames, group=None, out_dtype=None, max_tiles_per_batch=0, wire=None):
+    """run_frames in BAND mode: {frame index: (first output row, band tensor (C, rows, sc*W))} for EVERY frame -- this rank's row band of each canvas, which stays
+    sharded over the ranks (gather_bands concatenates them).  The form for jobs with fewer frames than ranks (BASELINE config 5: one 8K frame, a 3.19-GB canvas):
+    every rank folds its own band instead of one rank folding everything.  A rank whose band is empty (more ranks than tile rows) gets (0, a (C, 0, sc*W) tensor)."""
+    return run_frames(opt, frames, group, out_dtype, max_tiles_per_batch, bands=True, wire=wire)
+
+
+def run_frames(opt, frames, group=None, out_dtype=None, max_tiles_per_batch=0, bands=False, wire=None):
     """Tile-parallel doCrop over a list of equally-shaped (C,H,W) frames that every rank holds
     (broadcast them first).  Returns {frame index: stitched (C, sc*H, sc*W) tensor} for the frames
-    this rank stitches -- or, in band mode (bands=True; default when there are fewer frames than ranks), {frame index: (first output row, band tensor
-    (C, rows, sc*W))} for every frame: this rank's row band of the canvas, which stays sharded over the ranks (gather_bands concatenates them).
+    this rank stitches (frame f is folded by rank f mod N; a rank that stitches nothing gets {}: use out.get(f)).  bands=True (opt-in: the return type differs -- see
+    run_frame_bands) returns {frame index: (first output row, band tensor (C, rows, sc*W))} for every frame instead.
     wire: None / 'f32' -- fp32 tiles on the links; 'f16s' -- fp16 + fp32 seams (module docstring): for fp16 (or narrower) canvases, where the result is
     bit-identical; an fp32 canvas would carry fp16-rounded values outside the seams."""
     from .imageProcess import _DT
@@ -496,8 +503,6 @@ def run_frames(opt, frames, group=None, out_dtype=None, max_tiles_per_batch=0, b
     x0 = frames[0]
     dev = x0.device
     C = x0.shape[0]
-    if bands is None:
-        bands = world > 1 and len(frames) < world
     bands = bool(bands)
     plan, ex, bufs, padded, fstride = _layout(opt, frames, group, dev, rank, world, C, bands, wire=wire)
     buf = bufs[0]
@@ -520,6 +525,9 @@ def run_frames(opt, frames, group=None, out_dtype=None, max_tiles_per_batch=0, b
             y = torch.empty((C, y1 - y0, plan.outW), dtype=odt, device=dev)
             _lib.check(L.moe_stitch_band(plan._h, dev.index or 0, buf.data_ptr(), ctypes.c_void_p(tables[f]), C, y.data_ptr(), _DT[odt], i0, i1, 1, stream))
             out[f] = (y0, y)
+        if i1 <= i0:         # more ranks than tile rows: this rank's band is empty -- every frame still has an entry (a (C, 0, W) tensor on this rank's device)
+            for f in range(len(frames)):
+                out[f] = (0, torch.empty((C, 0, plan.outW), dtype=odt, device=dev))
         return out
     for f in mine:
         y = torch.empty((C, plan.outH, plan.outW), dtype=odt, device=dev)
@@ -533,13 +541,23 @@ def gather_bands(band, group=None):
     the sharded bands are the product: a 32K canvas is 3.19 GB)."""
     world = dist.get_world_size(group)
     y0, y = band if band is not None else (0, None)
+    if y is not None and y.shape[-2] == 0:
+        y = None                                             # an empty band (more ranks than tile rows) takes no part as a source
     metas = [None] * world
     dist.all_gather_object(metas, None if y is None else (int(y0), tuple(y.shape), str(y.dtype)), group=group)
+    # receive buffers live where this rank's collectives run: on its HIP device for RCCL (a CPU tensor in an RCCL broadcast raises on this rank while the others
+    # sit in the collective), on the host for gloo -- also on a rank that holds no band of its own
+    if y is not None:
+        rdev = y.device
+    elif dist.get_backend(group) != 'gloo' and torch.cuda.is_available():
+        rdev = torch.device('cuda', torch.cuda.current_device())
+    else:
+        rdev = None
     parts = []
     for r, m in enumerate(metas):
         if m is None:
             continue
-        t = y if r == dist.get_rank(group) else torch.empty(m[1], dtype=getattr(torch, m[2].split('.')[-1]), device=y.device if y is not None else None)
+        t = y if r == dist.get_rank(group) else torch.empty(m[1], dtype=getattr(torch, m[2].split('.')[-1]), device=rdev)
         if dist.get_backend(group) == 'gloo' and t.is_cuda:
             h = t.cpu()
             dist.broadcast(h, src=r, group=group)

@@ -285,6 +285,34 @@ def doCrop(opt, x, *args, **_):
 
 
 # ---- resize step (python/imageProcess.py:174-214, 555-556) --------------------------------------------------
+def blendTile(r, canvas, tile, sc, padSc, ramp):
+    """The two `blend` calls and the slice-assign of the reference's tile loop (python/imageProcess.py:120-131,167-170) for ONE tile, as one kernel
+    (moe_blend_tile) -- for a caller that keeps MoePhoto's own doCrop loop around the drop-in model class:
+
+        for tile in opt.iterClip():                          # tile = (top, bottom, left, right, topT, leftT, bsc, rsc)
+            r = opt.squeeze(opt(x[..., tile[0]:tile[1], tile[2]:tile[3]]))
+            blendTile(r, tmp_image, tile, sc, padSc, opt.blend)      # instead of: t = ...; q, _ = blend(*blend(...)); tmp_image[...] = q
+
+    r: (C, h, w) tile result (rows / columns beyond the window are ignored: opt.unpad); canvas: (C, H, W); ramp: opt.blend (padSc values); all three of one
+    dtype (fp16 / fp32), on the device, unit stride along the last axis.  The canvas receives the bits the reference's torch expression produces."""
+    top, bottom, left, right, topT, leftT, bsc, rsc = [int(v) for v in tile]
+    if r.dim() == 4:
+        r = r.squeeze(1)
+    if not (r.dtype == canvas.dtype and (ramp is None or ramp.dtype == canvas.dtype)) or r.dtype not in _DT:
+        raise TypeError('blendTile: tile, canvas and ramp must share one dtype (fp16 or fp32)')
+    if r.stride(-1) != 1 or canvas.stride(-1) != 1 or r.device != canvas.device or r.shape[0] != canvas.shape[0]:
+        raise ValueError('blendTile: unit stride along the last axis, one device and one plane count expected')
+    if r.shape[-2] < bsc - top * sc or r.shape[-1] < rsc - left * sc or bsc > canvas.shape[-2] or rsc > canvas.shape[-1]:
+        raise ValueError('blendTile: the window {}..{} x {}..{} does not fit the tile result {} / the canvas {}'.format(top * sc, bsc, left * sc, rsc, tuple(r.shape), tuple(canvas.shape)))
+    rp = ramp.reshape(-1) if ramp is not None else None
+    if rp is not None and (rp.numel() < padSc or rp.stride(0) != 1):
+        raise ValueError('blendTile: ramp must hold padSc contiguous values')
+    stream = torch.cuda.current_stream(canvas.device).cuda_stream
+    _lib.check(_lib.lib().moe_blend_tile(r.data_ptr(), r.stride(0), r.stride(1), canvas.data_ptr(), canvas.stride(0), canvas.stride(1), _DT[canvas.dtype], int(canvas.shape[0]),
+                                         int(top * sc), int(left * sc), bsc, rsc, topT, leftT, int(padSc), rp.data_ptr() if rp is not None else None, stream))
+    return canvas
+
+
 def resizeByTorch(x, width, height, mode='bilinear'):
     """The reference's `resizeByTorch` = F.interpolate(x[None], size=(height, width), mode=mode, align_corners=False)[0]; the name
     is kept for the callers, the work is moe_resize on the device (nearest / bilinear / bicubic)."""

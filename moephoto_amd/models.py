@@ -175,35 +175,23 @@ class EngineModule(object):
         _lib.check(_lib.lib().moe_net_set_exact_blocks(self._h, int(blocks)))
         return self
 
-    def calibrate(self, target=8e-4, tile=(3, 192, 192), seeds=(0, 1)):
-        """Pick the number of split-operand ARSBs for THESE weights: the per-architecture defaults (Net2x 4, Net3x 2, Net4x 1, NetDN 1) were chosen on the zoo's
-        weights with ~2e-4 of the 1e-3 budget to spare on uint8 noise; a checkpoint whose trunk swings wider spends more (tools/margin_sweep.py: the same a2
-        with its trunk weights x 1.15 needs more blocks).  Runs uniform uint8-noise tiles through the default arithmetic with n = default .. 6 blocks against
-        this engine's exact mode ('fp16x3', pinned to the oracle at 2e-5 by the tests) and keeps the smallest n whose worst max-abs difference is <= target.
-        A host-side convenience on top of moe_net_set_exact_blocks (no reference counterpart); returns (n, worst error at n).  Only for precision 'auto' /
-        'mixed' on the ARSB nets; the module must be on its device."""
-        import numpy as np
+    def calibrate(self, target=0.0):
+        """Measure the number of split-operand ARSBs THESE weights need (moe_net_calibrate: uint8-noise tiles through the exact mode and through 'mixed' with
+        n = default .. 6 blocks, on the device) and keep it.  Returns (n, worst error at n); n = -1 when six blocks do not reach `target` (<= 0: the library's
+        8.5e-4).  `.to(device)` with precision 'auto' already does this once per checkpoint (moe_net_finalize(MOE_PREC_AUTO)); this is the explicit call, e.g. with
+        another target.  None for families without the knob (SEDN, lite) or when the module runs in another arithmetic."""
         if self._device is None:
             raise _lib.EngineError('calibrate: move the module to its device first')
-        if self.resolved_precision() != 'mixed':
+        if self.ARCH in (_lib.ARCH_LITE, _lib.ARCH_SEDN) or self.resolved_precision() not in ('mixed', 'fp16x3') or self.precision not in ('auto', 'mixed'):
             return None
-        prec = self.precision
-        xs = [torch.from_numpy(np.random.default_rng(s).integers(0, 256, tile, dtype=np.uint8).astype(np.float32) / np.float32(255)).to(self._device)[:, None] for s in seeds]
-        try:
-            self.set_precision('fp16x3')
-            want = [self(x)[-1].clone() for x in xs]
-            self.set_precision(prec)
-            n0 = {_lib.ARCH_NET2X: 4, _lib.ARCH_NET3X: 2, _lib.ARCH_NET4X: 1, _lib.ARCH_NETDN: 1}.get(self.ARCH, 1)
-            best = None
-            for n in range(n0, 7):
-                self.set_exact_blocks(n)
-                err = max(float((self(x)[-1] - w).abs().amax()) for x, w in zip(xs, want))
-                best = (n, err)
-                if err <= target:
-                    break
-            return best
-        finally:
-            self.set_precision(prec)
+        n, err = ctypes.c_int(), ctypes.c_double()
+        stream = torch.cuda.current_stream(self._device).cuda_stream
+        _lib.check(_lib.lib().moe_net_calibrate(self._h, float(target), ctypes.byref(n), ctypes.byref(err), stream))
+        return n.value, err.value
+
+    def exact_blocks(self):
+        """The count of split-operand ARSBs the next forward runs with (moe_net_exact_blocks)."""
+        return int(_lib.check(_lib.lib().moe_net_exact_blocks(self._h)))
 
     def set_option(self, key, value):
         """A kernel-form switch of this net (moe_net_set_option): e.g. ('sp_impl', 'rw'), ('arsb_fuse', 0).  Takes effect at the next forward."""
@@ -212,7 +200,7 @@ class EngineModule(object):
         return self
 
     def _finalize(self):
-        key = (self._device.index, self.resolved_precision())
+        key = (self._device.index, self.precision)      # (the REQUESTED arithmetic: what 'auto' resolves to may depend on the loaded weights -- moe_net_calibrate)
         if self._finalized_key == key:
             return
         _lib.require_device()

@@ -45,9 +45,9 @@ assert sorted(out3) == [f for f in range(len(more)) if (f % world) == rank], (so
 for f, y in out3.items():
     assert torch.equal(y, ip.doCrop(opt, more[f])), f
 # band-sharded stitch: ONE frame, every rank folds its row band of the canvas; concatenated, the bands are doCrop's canvas bit for bit
-from moephoto_amd.dist import gather_bands  # noqa: E402
+from moephoto_amd.dist import gather_bands, run_frame_bands  # noqa: E402
 for fr in (frames[1], torch.from_numpy(gd.natural_image(77, (3, 264, 136))).cuda().half()):      # (7 and 6 tile rows at crop 64)
-    bands = run_frames(opt, [fr], out_dtype=torch.float16)            # fewer frames than ranks: band mode by default
+    bands = run_frame_bands(opt, [fr], out_dtype=torch.float16)      # fewer frames than ranks: band mode (opt-in since round 5)
     torch.cuda.synchronize()
     assert sorted(bands) == [0] and isinstance(bands[0], tuple), bands
     whole = gather_bands(bands[0])
@@ -68,7 +68,7 @@ torch.cuda.synchronize()
 for f, y in out5.items():
     assert torch.equal(y, out3[f]), ('wire overlapped', f)
 fr = torch.from_numpy(gd.natural_image(77, (3, 264, 136))).cuda().half()
-whole = gather_bands(run_frames(opt, [fr], out_dtype=torch.float16, wire='f16s')[0])
+whole = gather_bands(run_frame_bands(opt, [fr], out_dtype=torch.float16, wire='f16s')[0])
 torch.cuda.synchronize()
 assert torch.equal(whole, ip.doCrop(opt, fr)), 'wire bands'
 ex = [e for k, e in opt._exchanges.items() if k[-1]][0][1]

@@ -125,6 +125,18 @@ for nf, wire in ((1, None), (2, None), (1, wspec), (2, wspec)):
     total = [None] * world
     dist.all_gather_object(total, (i0, i1))
     assert sorted(set(v for a, b in total for v in range(a, b))) == list(range(nrow))  # the bands tile the canvas
+# gather_bands incl. EMPTY bands (more ranks than tile rows: 2 tile rows here, so rank(s) of a world of 3 hold a (C, 0, W) band; ADVICE r04: such a rank must
+# still allocate its receive buffers where its collectives run and must not become a broadcast source)
+from moephoto_amd.dist import gather_bands
+want = ostitch.fold_stitch([tile_value(0, k) for k in range(nt)], pl, sc)
+i0, i1 = ((rank * nrow) // world, ((rank + 1) * nrow) // world)
+if i1 > i0:
+    band = (rows_tab[i0][1], torch.from_numpy(want[:, rows_tab[i0][1]:(rows_tab[i1][1] if i1 < nrow else pl.out_shape[-2])].copy()))
+else:
+    band = (0, torch.empty((C, 0, want.shape[-1])))
+assert world <= nrow or any(((r * nrow) // world) == (((r + 1) * nrow) // world) for r in range(world))      # (world 3: one band is empty)
+whole = gather_bands(band)
+assert np.array_equal(whole.numpy(), want)
 sd = OrderedDict([('a.weight', torch.arange(12.).reshape(3, 4)), ('b', torch.tensor([2.5]))]) if rank == 0 else None
 out = broadcast_state_dict(sd, src=0)
 assert list(out.keys()) == ['a.weight', 'b'] and out['a.weight'].shape == (3, 4) and float(out['b']) == 2.5

@@ -412,6 +412,57 @@ def test_dropin_protocol_reference_loop(dev):
     assert np.abs(out.cpu().numpy() - z['y']).max() <= TOL
 
 
+def test_blend_tile_kernel_equals_the_reference_blend_expression(dev):
+    """moe_blend_tile (imageProcess.blendTile): the two blend() calls + the slice-assign of the reference's loop body (python/imageProcess.py:120-131,167-170)
+    as one kernel, for a maintainer who keeps that loop.  Held against the reference's own expression `bx + blend * (b - bx)` evaluated by
+    torch in the canvas dtype, BIT FOR BIT, over every tile of plans with ragged last tiles, a reflect-padded single-tile axis (unpad), scale 2 / 3 / 4 windows that are
+    and are not 4-element aligned, in fp16 (the reference's GPU path: ramp and canvas in half) and fp32; and end to end through the real net against the golden."""
+    from moephoto_amd import imageProcess as ip
+
+    def blend(r, ex, lt, pad, dim, b):
+        l = r.shape[dim]
+        lt = l + lt if lt < 0 else lt
+        if lt < 1:
+            return r, ex
+        st = lt - pad
+        rb, rc = r.narrow(dim, st, pad), r.narrow(dim, lt, l - lt)
+        eb = ex.narrow(dim, st, pad)
+        return torch.cat([eb + b * (rb - eb), rc], dim), ex.narrow(dim, st, l - st)
+    rng = np.random.default_rng(11)
+    for (shape, crop, pad, sc) in (((3, 100, 140), 48, 5, 2), ((2, 37, 150), 64, 5, 4), ((4, 90, 75), 40, 9, 3), ((3, 130, 61), 56, 7, 1)):
+        pl = oplanner.prepare(shape, 1 << 40, 1e-3, pad, sc, 8, crop)
+        outh, outw = pl.out_shape[-2:]
+        for dt in (torch.float16, torch.float32):
+            ramp = ((torch.arange(pl.pad_sc, dtype=dt, device=dev) / pl.pad_sc - .5) * 9).sigmoid().view(1, -1)      # prepare(), python/imageProcess.py:109
+            want = torch.from_numpy(rng.random((shape[0], outh, outw), dtype=np.float32)).to(dev).to(dt)            # (new_empty in the reference: stale values the bands read)
+            got = want.clone()
+            for (top, bottom, left, right, tt, lt, bsc, rsc) in pl.tiles:
+                r = torch.from_numpy(rng.standard_normal((shape[0], (bottom - top) * sc, (right - left) * sc)).astype(np.float32)).to(dev).to(dt)
+                t = want[..., top * sc:bsc, left * sc:rsc]
+                q, t2 = blend(r[..., :outh, :outw], t, tt, pl.pad_sc, -2, ramp.t())
+                q, _ = blend(q, t2, lt, pl.pad_sc, -1, ramp)
+                hh, ww = q.shape[-2:]
+                want[..., bsc - hh:bsc, rsc - ww:rsc] = q
+                ip.blendTile(r, got, (top, bottom, left, right, tt, lt, bsc, rsc), sc, pl.pad_sc, ramp)
+            assert torch.equal(got, want), (shape, dt, float((got.float() - want.float()).abs().max()))
+    # the loop of test_dropin_protocol_reference_loop with the fused kernel in place of the two blends
+    from moephoto_amd.imageProcess import Option, initModel
+    from moephoto_amd.models import Net2x
+    from moephoto_amd.config import config
+    config.fp16, config.deviceId = False, 0
+    opt = Option()
+    opt.modelDef = Net2x
+    opt.modelCached = initModel(opt, {k: torch.from_numpy(v) for k, v in gd.state_dict_for('a2', load_state_dict_file).items()})
+    z = np.load(os.path.join(G, 'stitched', 'a2_natural.npz'))
+    xu = torch.from_numpy(gd.natural_image(101, (3, 100, 140))).to(dev).unsqueeze(1)
+    pl = oplanner.prepare((3, 100, 140), 1 << 40, 1e-3, 5, 2, 8, 48)
+    ramp = torch.from_numpy(oplanner.blend_ramp(pl.pad_sc)).to(dev)
+    out = torch.full((3, 200, 280), float('nan'), device=dev)
+    for tile in pl.tiles:
+        ip.blendTile(opt(xu[..., tile[0]:tile[1], tile[2]:tile[3]]), out, tile, 2, pl.pad_sc, ramp)
+    assert np.abs(out.cpu().numpy() - z['y']).max() <= TOL
+
+
 def test_run_plan_frames_owner_sharding(dev):
     """moe_run_plan_frames (the multi-GPU step of dist.run_frames): three frames in one call, tiles of different frames share
     launches.  With one owner, and with the work split over three owners (each computing (f * n_tiles + k) % 3 == i), every
@@ -1071,33 +1122,71 @@ def test_stitch_band_equals_rows_of_the_canvas(dev):
 
 
 def test_calibrate_exact_blocks_for_other_weights(dev):
-    """EngineModule.calibrate: the per-architecture number of split-operand blocks was chosen on the zoo's weights; a checkpoint whose trunk swings wider
-    needs more (tools/margin_sweep.py).  On a2 as shipped the default (4) holds the target and is kept; on a2 with its trunk weights x 1.15 the default spends
-    more than the target on uint8 noise, and calibrate() moves to more blocks with a smaller error."""
+    """moe_net_calibrate (behind the C ABI since round 5; EngineModule.calibrate is a thin call): the per-architecture number of split-operand blocks was chosen on
+    the zoo's weights; a checkpoint whose trunk swings wider needs more (tools/margin_sweep.py).  `.to(device)` under precision 'auto' measures it by itself
+    (moe_net_finalize(MOE_PREC_AUTO)): a2 as shipped keeps the default (4), a2 with its trunk weights x 1.15 -- where 4 blocks spend more than the target on uint8
+    noise -- moves to more blocks with a smaller error; an explicit set_exact_blocks overrides, -1 returns to the measured count; option auto_calibrate = 0 keeps the
+    architecture's default."""
     from moephoto_amd import models
     sd = gd.state_dict_for('a2', load_state_dict_file)
 
-    def build(scale):
+    def build(scale, pre=None):
         v = {k: (a * np.float32(scale) if (k.startswith('conv_input2') or (k.startswith('convt_F') and a.ndim == 4)) else a) for k, a in sd.items()}
         m = models.Net2x()
+        if pre:
+            pre(m)
         m.load_state_dict({n: torch.from_numpy(np.ascontiguousarray(a, np.float32)) for n, a in v.items()})
         return m.eval().to(dtype=torch.float32, device=dev)
     m = build(1.0)
+    assert m.exact_blocks() == 4 and m.resolved_precision() == 'mixed'
     n, err = m.calibrate()
-    assert n == 4 and err <= 8e-4, (n, err)
+    assert n == 4 and err <= 8.5e-4, (n, err)
     m = build(1.15)
-    m.set_exact_blocks(4)
+    na = m.exact_blocks()
+    assert na > 4 or m.resolved_precision() == 'fp16x3', na
     x = torch.from_numpy(gd.noise_u8(0, (3, 192, 192)).astype(np.float32) / np.float32(255)).to(dev)[:, None]
-    e4 = float((m(x)[-1] - m.set_precision('fp16x3')(x)[-1]).abs().amax())
+    ya = m(x)[-1].clone()
+    want = m.set_precision('fp16x3')(x)[-1].clone()
     m.set_precision('auto')
-    n, err = m.calibrate()
-    assert n > 4 and err < e4, (n, err, e4)
+    ea = float((ya - want).abs().amax())
+    e4 = float((m.set_exact_blocks(4)(x)[-1] - want).abs().amax())
+    assert ea < e4 and ea <= 9e-4, (na, ea, e4)
+    m.set_exact_blocks(-1)
+    assert m.exact_blocks() == na and torch.equal(m(x)[-1], ya)
+    m0 = build(1.15, pre=lambda q: q.set_option('auto_calibrate', 0))
+    assert m0.exact_blocks() == 4
 
 
-def test_streamed_arsb_is_bit_identical_to_the_patch_form(dev):
-    """Option arsb_impl = s (arsb_s.hip: the ARSB streamed down 30-pixel columns by two-wave workgroups, conv_2 four rows behind conv_1 through an m ring in LDS,
-    the rows a range needs from its neighbours recomputed) against the default arsb32c.hip: the same MFMAs in the same order and the same epilogue arithmetic
-    -- not a bit may differ, on ragged shapes, 48- and 64-channel nets, with and without the hi + lo stream, and however the ranges are cut."""
+def test_integration_md_stub_holds_the_contract_on_checkpoints_with_a_wider_trunk(dev):
+    """the INTEGRATION.md stub, executed as written, loads checkpoints the defaults were NOT tuned on -- a2 and a4-synth with every trunk conv
+    (conv_input2, the twelve ARSB convs) x 1.15, which the per-architecture block counts miss by 1.3e-3 / 1.8e-3 (profiles/r04/n_margin_sweep_and_fuzz_final_tree.txt)
+    -- and must hold 1e-3 against the fp32 ORACLE on a full 256 x 256 uint8-noise tile: moe_net_finalize(MOE_PREC_AUTO) measures the checkpoint when it is loaded."""
+    import re
+    from moephoto_amd import _lib
+    from oracle import nets as onets
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'INTEGRATION.md')).read()
+    code = re.search(r'```python\n(.*?)```', text, re.S).group(1).replace("'libmoephoto_amd.so'", repr(_lib.LIB_PATH))
+    ns = {}
+    exec(compile(code, 'INTEGRATION.md', 'exec'), ns)
+    x = gd.noise_u8(5, (3, 256, 256)).astype(np.float32)[:, None] / np.float32(255)
+    for key, cls, oname in (('a2', 'Net2x', 'net2x'), ('a4', 'Net4x', 'net4x')):
+        sd = gd.state_dict_for(key, load_state_dict_file)
+        sd = {k: (np.ascontiguousarray(a * np.float32(1.15)) if (k.startswith('conv_input2') or (k.startswith('convt_F') and a.ndim == 4)) else a) for k, a in sd.items()}
+        m = ns[cls]()
+        m.load_state_dict({n: torch.from_numpy(np.ascontiguousarray(v, np.float32)) for n, v in sd.items()})
+        m.eval()
+        m = m.to(dtype=torch.float32, device=dev)
+        y = m(torch.from_numpy(x).to(dev))[-1].float().cpu().numpy()
+        want = onets.forward(oname, sd, x).numpy()
+        err = float(np.abs(y - want).max())
+        assert err <= TOL, '{} x1.15 trunk through the INTEGRATION.md stub vs the oracle: {:.3e}'.format(key, err)
+
+
+def test_one_launch_arsb_does_not_depend_on_how_its_ranges_are_cut(dev):
+    """arsb32c.hip gives a workgroup a contiguous range of the column-major patch sequence; the first patch of a range recomputes the two m rows it would have
+    inherited, from the same operands in the same order -- not a bit may depend on the number of workgroups, on ragged shapes, 48- and 64-channel nets, with and
+    without the hi + lo stream.  (Round 4 held the streamed form arsb_s.hip against it here, bit for bit; that form measured 7 % slower and left the build in round 5
+    -- profiles/r04/d_arsb_streamed_vs_patch.txt, history at 321d022.)"""
     touched = []
     try:
         for key, prec in (('a2', 'auto'), ('a2', 'fp16'), ('dn_lite5', 'auto'), ('dn_lite5', 'fp16'), ('a4', 'auto')):
@@ -1106,15 +1195,13 @@ def test_streamed_arsb_is_bit_identical_to_the_patch_form(dev):
             for shape in ((3, 8, 16), (3, 24, 40), (2, 40, 264), (3, 16, 35), (5, 88, 64), (2, 128, 61)):
                 x = gd.noise_image(17, shape)[:, None]
                 xd = torch.from_numpy(x).to(dev)
-                y3 = m.set_option('arsb_impl', 'v3')(xd)[-1]
-                ys = m.set_option('arsb_impl', 's')(xd)[-1]
+                y3 = m(xd)[-1]
                 yg = m.set_option('max_groups', 5)(xd)[-1]
                 m.set_option('max_groups', 0)
-                assert torch.equal(y3, ys), (key, prec, shape, float((y3 - ys).abs().max()))
-                assert torch.equal(ys, yg), (key, prec, shape)
+                assert torch.equal(y3, yg), (key, prec, shape, float((y3 - yg).abs().max()))
     finally:
         for m in touched:
-            m.set_option('arsb_impl', 'v3').set_option('max_groups', 0)
+            m.set_option('max_groups', 0)
 
 
 def test_wire_pack_unpack_kernels_vs_numpy_codec(dev):

@@ -103,7 +103,7 @@ def test_library_exports_every_header_symbol():
     for name in declared:
         assert hasattr(L, name), name
     assert sorted(_lib.EXPORTS) == declared
-    assert _lib.lib().moe_abi_version() == _lib.ABI_VERSION == 2
+    assert _lib.lib().moe_abi_version() == _lib.ABI_VERSION == 3
 
 
 def _plan(case):

@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""Per-kernel package power and shader clock ("find the joules"): ONE kernel of the a4 forward looped by itself -- option repeat = "<layer key>:<n>"
+issues the bracketed launches of that layer n times per forward (idempotent launches, results unchanged) -- while rocm-smi samples power and sclk twice a second.
+96 planes of 256 x 256 (one launch set of the headline frame).  Prints one line per kernel: ms per launch under sustained load, W, GHz, algorithmic TFLOP/s.
+
+    python tools/kernel_power.py [seconds per kernel, default 4]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'tests')):
+    sys.path.insert(0, p)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import golden_defs as gd  # noqa: E402
+from bench import _ClockSampler  # noqa: E402
+from moephoto_amd import models  # noqa: E402
+from moephoto_amd.weights import load_state_dict_file  # noqa: E402
+
+secs = float(sys.argv[1]) if len(sys.argv) > 1 else 4.0
+dev = torch.device('cuda', 0)
+m = models.Net4x()
+m.load_state_dict({k: torch.from_numpy(v) for k, v in gd.synth_state_dict('a4', load_state_dict_file).items()})
+m = m.eval().to(dtype=torch.float16, device=dev)
+B = 96
+x = torch.from_numpy(np.stack([gd.natural_image(7 + b // 3, (3, 256, 256))[b % 3] for b in range(B)])).to(dev).half()[:, None]
+for _ in range(2):
+    m(x)
+torch.cuda.synchronize()
+FLOP = {'arsb3': 2 * 2 * 64 * 64 * 9, 'u.up1': 4 * 2 * 256 * 64 * 9, 'convt_R1.up1': 4 * 2 * 256 * 64 * 9, 'u.up0': 2 * 256 * 64 * 9, 'xpair1': 2 * 2 * 64 * 64 * 9}
+print('kernel_power: {} planes of 256x256, {} s per kernel'.format(B, secs))
+for key, label in (('arsb3', 'arsb32c_kernel<true,4>'), ('u.up1', 'conv3x3_ps4_kernel<1,false> (U last stage)'), ('convt_R1.up1', 'conv3x3_ps4_kernel<2,false> (R last stage)'), (None, 'whole a4 forward')):
+    rep = 200 if key else 1
+    m.set_option('repeat', '{}:{}'.format(key, rep) if key else '0')
+    m.set_profile(key or 'arsb3')
+    m(x)
+    torch.cuda.synchronize()
+    m.get_profile()
+    t0 = time.perf_counter()
+    m(x)
+    torch.cuda.synchronize()
+    one = time.perf_counter() - t0
+    n = max(2, int(secs / one))
+    m.get_profile()
+    sm = _ClockSampler(0)
+    sm.start()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        m(x)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    clk = sm.stop() or {}
+    pr = m.get_profile()
+    line = '{:46s} wall {:.2f} s'.format(label, wall)
+    if key:
+        per = pr['total_ms'] / max(1, pr['launches'] * rep)      # (one event pair brackets the rep launches)
+        line += ' | {:.4f} ms per launch ({} launches) | {:.0f} TFLOP/s algorithmic on its {} planes'.format(per, pr['launches'] * rep, FLOP[key] * B * 65536 * (4 if 'up1' in key else 1) / per / 1e9, B)
+    line += ' | {} W, {} GHz (min {} max {}, {} samples)'.format(clk.get('package_power_w_mean'), clk.get('sclk_ghz_mean'), clk.get('sclk_ghz_min'), clk.get('sclk_ghz_max'), clk.get('samples'))
+    print(line, flush=True)
+m.set_option('repeat', '0')

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Run the fixed Net4x workload with the -DA32_TRACE library (tools/mk_variant.sh trace32 arsb32.hip -DA32_TRACE) and print, for arsb32_kernel, the
+"""Run the fixed Net4x workload with the -DA32_TRACE library (tools/mk_variant.sh trace32 arsb32c.hip -DA32_TRACE) and print, for arsb32c_kernel, the
 cycles each wave spends per phase of a patch iteration (s_memtime ticks = shader cycles)."""
 import os
 import shutil
@@ -12,7 +12,7 @@ lib, trace = os.path.join(ROOT, 'moephoto_amd', 'libmoephoto_amd.so'), os.path.j
 shutil.copy(lib, '/tmp/lib_orig.so')
 try:
     shutil.copy(trace, lib)
-    env = dict(os.environ, MOE_ARSB_TRACE='1', MOE_ARSB_IMPL=os.environ.get('TRACE_IMPL', 'v2'), PROF_ITER='1', PROF_B=os.environ.get('PROF_B', '12'))
+    env = dict(os.environ, MOE_ARSB_TRACE='1', PROF_ITER='1', PROF_B=os.environ.get('PROF_B', '12'))
     subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'prof_workload.py')], env=env, check=True, stdout=subprocess.DEVNULL)
 finally:
     shutil.copy('/tmp/lib_orig.so', lib)
