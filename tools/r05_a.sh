@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/r05a
 mkdir -p $OUT
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "calibrate or integration_md or one_launch_arsb or net_forward_vs_reference_golden or dropin_protocol or layer_by_layer" > $OUT/pytest_subset.txt 2>&1
+timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "blend_tile or calibrate or integration_md or one_launch_arsb or net_forward_vs_reference_golden or dropin_protocol or layer_by_layer" > $OUT/pytest_subset.txt 2>&1
 echo "pytest subset rc=$?"; tail -3 $OUT/pytest_subset.txt
 timeout 300 python tools/calib_report.py > $OUT/calib_report.txt 2>&1; echo "calib rc=$?"; cat $OUT/calib_report.txt | tail -20
 timeout 200 python tools/kernel_power.py 4 > $OUT/kernel_power.txt 2>&1; echo "power rc=$?"; cat $OUT/kernel_power.txt
