@@ -104,6 +104,9 @@ def main():
                     '4 = batch of 64 1080p frames, 5 = one 8K frame -> 32K with 512-px tiles (bench_extra.py)')
     ap.add_argument('--wire', default='f32', choices=['f32', 'f16s'], help='configs 3-5 under --gpus N: tile results between ranks as fp32, or as fp16 + fp32 seams (dist.py)')
     ap.add_argument('--no-extras', action='store_true', help='config 2: skip the roofline objects of the HBM-bound members and the I/O edges')
+    ap.add_argument('--no-configs', action='store_true', help="config 2: skip the short legs of BASELINE's configs 3, 4, 5 (object `configs`: one timed step each, in child processes)")
+    ap.add_argument('--no-pmc', action='store_true', help='config 2: do not try the rocprofv3 --pmc passes over a short child of this command (`traffic` then comes from the committed, '
+                    'digest-gated profiles/pmc_bench.json)')
     args = ap.parse_args()
     args.steps_given = any(a == '--steps' or a.startswith('--steps=') for a in sys.argv[1:])
 
@@ -229,7 +232,15 @@ def main():
     }
 
     # ---- roofline objects: one per bracketed group, dominant (by time) first ----------------------------------------
-    pmc = _pmc_table()
+    # HBM bytes per launch (`traffic`) and MFMA busy from rocprofv3 --pmc passes over a 2-frame child of THIS command on THIS box, when the tool is here
+    # (`traffic_source: "this run"`); otherwise from the committed, digest-gated profiles/pmc_bench.json (`"committed"`)
+    pmc, pmc_source = None, None
+    if rank == 0 and world == 1 and not args.no_pmc:
+        pmc = _pmc_live()
+        pmc_source = 'this run' if pmc else None
+    if not pmc:
+        pmc = _pmc_table()
+        pmc_source = 'committed' if pmc else None
     kernels = []
     frames_timed = args.steps        # every rank computes one frame's worth of tiles per step
     for (key, label, flop_px), prof in zip(GROUPS, profs):
@@ -247,6 +258,7 @@ def main():
         t = pmc.get(key)
         if t:       # PMC passes of this same command: bytes per frame / launches per frame
             k['traffic'] = int(t['hbm_bytes_per_frame'] / max(1, t['launches_per_frame']))
+            k['traffic_source'] = pmc_source
             k['traffic_note'] = t.get('note', '')
             if t.get('mfma_busy') is not None:
                 k['mfma_busy_pmc'] = t['mfma_busy']
@@ -279,21 +291,26 @@ def main():
         alg = 3.0 * FRAME[1] * FRAME[2] * _exact_bytes_px(fused) * frames_timed            # algorithmic bytes of the three layers in the timed steps
         peak_gbs = 8000.0                                                                   # MI355X_MICROARCH.md: HBM3E ~8 TB/s
         flops = 3.0 * FRAME[1] * FRAME[2] * frames_timed * 3 * 2 * 64 * 64 * 9            # three 3x3 64->64 convs; executed: two product-times each (fp16 + two fp8 products at twice the rate)
-        k = {'bound': 'hbm', 'kernel': ('conv64_sq_kernel (conv_input2) + arsb_sq_kernel (ARSB 1 as ONE launch: conv_1 on producer waves, conv_2 on consumer waves, its rows in LDS)' if fused else
+        exe_tflops = 2 * flops / secs / 1e12      # fp16-equivalent executed: per conv one fp16 product-time + two fp8 products at twice the rate = two product-times
+        k = {'bound': 'mfma', 'kernel': ('conv64_sq_kernel (conv_input2) + arsb_sq_kernel (ARSB 1 as ONE launch: conv_1 on producer waves, conv_2 on consumer waves, its rows in LDS)' if fused else
                                         'conv64_sq_kernel (conv_input2 + the two convs of ARSB 1)') +
                                        ': split operands -- fp16 product + two fp8 correction products, fp8 low parts between the layers; rows streamed down columns by '
                                        'register-weight waves (small or odd shapes: conv64_q8_kernel; MOE_X3_IMPL=x3: conv64_x3_kernel)', 'layer_key': 'exact',
-             'achieved': round(alg / secs / 1e9, 1), 'peak': peak_gbs, 'unit': 'GB/s', 'frac': round(alg / secs / 1e9 / peak_gbs, 4),
-             'bytes_per_pixel_algorithmic': _exact_bytes_px(fused), 'launches': launches, 'avg_launch_ms': round(secs * 1e3 / launches, 4),
+             'achieved': round(exe_tflops, 1), 'peak': round(peak_tflops, 1), 'unit': 'TFLOP/s', 'frac': round(exe_tflops / peak_tflops, 4),
+             'frac_note': 'fp16-equivalent EXECUTED product-times over the fp16 MFMA peak (VERDICT r04 item 5c): these layers are held by the matrix pipe under the power cap since '
+                          'conv_1\'s rows stay in LDS (arsb_sq); algorithmic (one fp32-grade conv = 2 x 64 x 64 x 9 FLOP a pixel) is half of it',
+             'achieved_algorithmic': round(flops / secs / 1e12, 1), 'frac_algorithmic': round(flops / secs / 1e12 / peak_tflops, 4),
+             'hbm_side': {'achieved': round(alg / secs / 1e9, 1), 'peak': peak_gbs, 'unit': 'GB/s', 'frac': round(alg / secs / 1e9 / peak_gbs, 4), 'bytes_per_pixel_algorithmic': _exact_bytes_px(fused)},
+             'launches': launches, 'avg_launch_ms': round(secs * 1e3 / launches, 4),
              'ms_per_frame': round(secs * 1e3 / frames_timed, 3), 'share_of_step': round(secs * 1e3 / frames_timed / ms_per_step, 4),
-             'mfma_side': {'algorithmic_tflops': round(flops / secs / 1e12, 1), 'executed_tflops_fp16_equivalent': round(2 * flops / secs / 1e12, 1), 'peak': round(peak_tflops, 1),
-                           'note': 'with conv_1\'s rows kept in LDS these layers stopped being held by their bytes: PMC MFMA busy 0.78 at 1.7 GHz (profiles/r04), the package power cap again'}}
+             }
         t = pmc.get('exact')
         k['traffic'] = int(t['hbm_bytes_per_frame'] / max(1, t['launches_per_frame'])) if t else None
         if t:
+            k['traffic_source'] = pmc_source
             k['traffic_note'] = t.get('note', '')
             k['achieved_measured_bytes'] = round(t['hbm_bytes_per_frame'] * frames_timed / secs / 1e9, 1)      # the PMC passes' bytes over this run's time
-        res['roofline_hbm'] = k
+        res['roofline_split_operand'] = k
 
     # ---- the HBM-bound members of the path and the I/O edges the headline excludes (bench_extra.py) --------------------------------------
     if world == 1 and not args.no_extras:
@@ -471,6 +488,10 @@ def main():
         res['config']['parity_max_abs_vs_oracle'] = max(p['worst_max_abs'] for p in parity.values())
         res['config']['parity_tolerance'] = PARITY_TOL
         res['config']['parity_ok'] = bool(parity_ok)
+    # ---- the other BASELINE configs, one timed step each, in child processes of this same script (so that the driver's default command times them too) -------
+    if rank == 0 and world == 1 and not args.no_configs:
+        res['configs'] = _other_configs(args)
+        parity_ok = parity_ok and all(c.get('parity_ok', True) is not False for c in res['configs'].values() if isinstance(c, dict))
     if rank == 0:
         print(json.dumps(res))
         sys.stdout.flush()
@@ -607,6 +628,74 @@ def _power_roofline():
         return v
     except Exception:
         return None
+
+
+def _other_configs(args):
+    """{'config3' | 'config4' | 'config5': {...}}: `python bench.py --config N --steps 1` run as children (their own process: config 5 alone holds a 3.19-GB canvas and
+    a 6.4-GB tile pool), condensed to ms_per_step / value / parity / roofline.  A child that fails or times out leaves {'error': ...}: the headline line must not die with it."""
+    out = {}
+    for cfg in (3, 4, 5):
+        t0 = time.perf_counter()
+        try:
+            cmd = [sys.executable, os.path.abspath(__file__), '--config', str(cfg), '--steps', '1', '--warmup', '1']
+            if args.no_cpu_baseline:
+                cmd.append('--no-cpu-baseline')
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+            line = next((l for l in reversed(p.stdout.strip().splitlines()) if l.startswith('{')), None)
+            if p.returncode != 0 or line is None:
+                out['config%d' % cfg] = {'error': 'rc {}: {}'.format(p.returncode, (p.stderr or p.stdout)[-300:]), 'parity_ok': False if 'parity gate failed' in (p.stderr or '') else None}
+                continue
+            r = json.loads(line)
+            rf = r.get('roofline') or {}
+            out['config%d' % cfg] = {'workload': r['config']['workload'], 'metric': r['metric'], 'value': r['value'], 'unit': r['unit'], 'ms_per_step': r['ms_per_step'], 'steps': r['steps'],
+                                     'scaling': r['scaling'], 'dtype': r['dtype'], 'tflops_algorithmic': r['config'].get('tflops_algorithmic'),
+                                     'parity_max_abs_vs_oracle': r['config'].get('parity_max_abs_vs_oracle'), 'parity_ok': r['config'].get('parity_ok'),
+                                     'roofline': {k: rf.get(k) for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac')} if rf else None,
+                                     'roofline_hbm': ({k: r['roofline_hbm'].get(k) for k in ('kernel', 'achieved', 'peak', 'unit', 'frac', 'ms')} if r.get('roofline_hbm') else None),
+                                     'cpu_baseline': ({k: r['cpu_baseline'].get(k) for k in ('value', 'unit', 'cores', 'kind', 'sample')} if r.get('cpu_baseline') else None),
+                                     'child_wall_s': round(time.perf_counter() - t0, 1)}
+        except Exception as e:
+            out['config%d' % cfg] = {'error': repr(e)[:300]}
+    out['note'] = 'one timed step each (after one warm-up step) of `python bench.py --config 3 | 4 | 5`, run as children of this command; full lines: profiles/r05/bench_c{3,4,5}.json'
+    return out
+
+
+def _pmc_live():
+    """rocprofv3 --pmc over a short child of this command (counters only: no tracing beside them), three passes -- FETCH_SIZE | WRITE_SIZE + GRBM_GUI_ACTIVE | eight SQ
+    counters (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not share a pass) -- condensed by tools/pmc_collect.py into the table _pmc_table() reads.  None when
+    rocprofv3 is not on the box, a pass fails or takes too long: the caller then falls back to the committed table."""
+    import shutil
+    import tempfile
+    exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    collect = os.path.join(ROOT, 'tools', 'pmc_collect.py')
+    if not exe or not os.path.exists(collect):
+        return None
+    out = tempfile.mkdtemp(prefix='moe_pmc_', dir='/tmp')
+    steps, warm = 1, 1
+    child = [sys.executable, os.path.abspath(__file__), '--steps', str(steps), '--warmup', str(warm), '--no-cpu-baseline', '--sustain', '0', '--no-noise-input', '--no-dropin-loop',
+             '--no-extras', '--no-configs', '--no-pmc']
+    regex = 'conv3x3_ps4|arsb32c|arsb_sq|conv64_sq|conv64_q8|conv64_x3'
+    env = dict(os.environ, TMPDIR='/tmp')
+    t0 = time.perf_counter()
+    try:
+        for name, counters in (('fetch', ['FETCH_SIZE']), ('grbm', ['WRITE_SIZE', 'GRBM_GUI_ACTIVE']),
+                               ('sq', ['SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_INSTS_MFMA', 'SQ_LDS_BANK_CONFLICT'])):
+            cmd = [exe, '--pmc'] + counters + ['--kernel-include-regex', regex, '-d', os.path.join(out, 'pmc_' + name), '-o', 'pmc', '-f', 'csv', '--'] + child
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=150, env=env, cwd='/tmp')
+            if p.returncode != 0:
+                return None
+        p = subprocess.run([sys.executable, collect, out, str(steps + warm)], capture_output=True, text=True, timeout=60)
+        d = json.load(open(os.path.join(out, 'pmc_bench.json')))
+        g = d.get('groups', {})
+        if not g:
+            return None
+        for v in g.values():
+            v['note'] = (v.get('note', '') + ' | rocprofv3 --pmc passes of a {}-frame child of this run, {:.0f} s'.format(steps + warm, time.perf_counter() - t0)).strip(' |')
+        return g
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
 
 
 def _pmc_table():

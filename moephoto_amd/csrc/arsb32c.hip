@@ -29,6 +29,19 @@
 #else
 #define A32_LO_BYTES(n) (n)
 #endif
+// round 5, "where do the joules go" (tools/r05_b.sh; results WRONG by design, the instruction stream is the product's): A32_NOST -- the output descriptors cover nothing (every
+// store is issued and dropped), A32_NODMA -- the input descriptor covers nothing (the LDS-DMA pieces are issued and deliver zeros: no fetch traffic, and conv_1's B operand stops
+// toggling), A32_NOEPI -- the epilogues' arithmetic (PReLU, residual add, hi / lo split) is left out, their LDS writes and stores stay
+#ifdef A32_NOST
+#define A32_ST_BYTES(n) 0u
+#else
+#define A32_ST_BYTES(n) (n)
+#endif
+#ifdef A32_NODMA
+#define A32_IN_BYTES(n) 0u
+#else
+#define A32_IN_BYTES(n) (n)
+#endif
 
 namespace {
 
@@ -223,11 +236,11 @@ __global__ __launch_bounds__(256) void arsb32c_kernel(ArsbArgs a)
     // ---- patch DMA: the lane's source offset of piece i (its pixel of the 12 x 34 patch, its logical 16-byte slot) is formed when the piece is issued ------
     const unsigned in_pad = (unsigned)(2 * a.W + 2) * 128u;
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.x_hi - in_pad), 0,
-                                                                         (unsigned)a.B * a.H * a.W * 128u + in_pad, 0x00020000);
+                                                                         A32_IN_BYTES((unsigned)a.B * a.H * a.W * 128u + in_pad), 0x00020000);
     const unsigned nbytes = (unsigned)a.B * a.H * a.W * 128u;
     const __amdgpu_buffer_rsrc_t rlo = __builtin_amdgcn_make_buffer_rsrc((void*)(LO ? a.x_lo : a.x_hi), 0, A32_LO_BYTES(nbytes), 0x00020000);
-    const __amdgpu_buffer_rsrc_t ryh = __builtin_amdgcn_make_buffer_rsrc((void*)a.y_hi, 0, nbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ryl = __builtin_amdgcn_make_buffer_rsrc((void*)(LO ? a.y_lo : a.y_hi), 0, A32_LO_BYTES(nbytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ryh = __builtin_amdgcn_make_buffer_rsrc((void*)a.y_hi, 0, A32_ST_BYTES(nbytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ryl = __builtin_amdgcn_make_buffer_rsrc((void*)(LO ? a.y_lo : a.y_hi), 0, A32_ST_BYTES(A32_LO_BYTES(nbytes)), 0x00020000);
     const int qlane = w4 * 8 + (lane >> 3);
     unsigned d_off = 0, d_r = 0, d_cc = 0;                    // DMA piece in the making: byte offset inside the patch, patch row / column of the lane's pixel
     auto piece_addr = [&](int i) {
@@ -383,6 +396,11 @@ __global__ __launch_bounds__(256) void arsb32c_kernel(ArsbArgs a)
         };
         auto op_p = [&](auto I_, auto K0_, auto N_) __attribute__((always_inline)) {      // PReLU on packed halves (slope <= 1) of channel pairs k0 .. k0+n-1 of m row i
             constexpr int i = decltype(I_)::value, k0 = decltype(K0_)::value, n = decltype(N_)::value;
+#ifdef A32_NOEPI
+#pragma unroll
+            for (int k = k0; k < k0 + n; ++k) { hp[k] = __builtin_bit_cast(unsigned, acc[(i + 1) & 3][2 * k]); asm volatile("" :: "v"(acc[(i + 1) & 3][2 * k + 1])); }
+            return;
+#endif
 #pragma unroll
             for (int k = k0; k < k0 + n; ++k) {
                 const half2_t pr = {(half_t)acc[(i + 1) & 3][2 * k], (half_t)acc[(i + 1) & 3][2 * k + 1]};
@@ -425,6 +443,12 @@ __global__ __launch_bounds__(256) void arsb32c_kernel(ArsbArgs a)
         };
         auto op_res = [&](auto I_, auto O_, auto K0_) __attribute__((always_inline)) {      // acc += x_hi [+ x_lo 2^-11] (in place) for channel pairs k0, k0+1 of slot o
             constexpr int i = decltype(I_)::value, o = decltype(O_)::value, k0 = decltype(K0_)::value;
+#ifdef A32_NOEPI
+#pragma unroll
+            for (int k = k0; k < k0 + 2; ++k) { sh[k] = __builtin_bit_cast(unsigned, acc[i & 3][8 * o + 2 * k]); sl[k] = __builtin_bit_cast(unsigned, acc[i & 3][8 * o + 2 * k + 1]); }
+            asm volatile("" :: "v"(xhv[o]), "v"(xlo[i][o]));
+            return;
+#endif
 #pragma unroll
             for (int k = k0; k < k0 + 2; ++k) {
                 float v0 = acc[i & 3][8 * o + 2 * k], v1 = acc[i & 3][8 * o + 2 * k + 1];
@@ -442,6 +466,9 @@ __global__ __launch_bounds__(256) void arsb32c_kernel(ArsbArgs a)
         };
         auto op_spl = [&](auto I_, auto O_, auto K0_) __attribute__((always_inline)) {
             constexpr int i = decltype(I_)::value, o = decltype(O_)::value, k0 = decltype(K0_)::value;
+#ifdef A32_NOEPI
+            return;
+#endif
 #pragma unroll
             for (int k = k0; k < k0 + 2; ++k) split2(acc[i & 3][8 * o + 2 * k], acc[i & 3][8 * o + 2 * k + 1], -2048.f, sh[k], sl[k]);
         };

@@ -22,6 +22,7 @@ template <> struct Arith<float> {
 template <> struct Arith<half_t> {
     static __device__ __forceinline__ half_t mix(half_t b, half_t bx, half_t w)
     {
+#pragma clang fp contract(off)      // (the compiler narrows these to v_sub_f16 / v_mul_f16 / v_add_f16 -- same roundings -- and would then fuse the last two into ONE v_fma_f16: one rounding less than torch)
         const half_t d = (half_t)((float)b - (float)bx);          // (fp32 difference of two halves is exact: one rounding, as torch's fp16 sub)
         const half_t p = (half_t)((float)w * (float)d);
         return (half_t)((float)bx + (float)p);

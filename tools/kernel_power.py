@@ -19,6 +19,8 @@ from moephoto_amd import models  # noqa: E402
 from moephoto_amd.weights import load_state_dict_file  # noqa: E402
 
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 4.0
+only = sys.argv[2].split(',') if len(sys.argv) > 2 else None      # e.g. arsb3 -- that kernel alone
+tag = sys.argv[3] if len(sys.argv) > 3 else ''
 dev = torch.device('cuda', 0)
 m = models.Net4x()
 m.load_state_dict({k: torch.from_numpy(v) for k, v in gd.synth_state_dict('a4', load_state_dict_file).items()})
@@ -29,8 +31,11 @@ for _ in range(2):
     m(x)
 torch.cuda.synchronize()
 FLOP = {'arsb3': 2 * 2 * 64 * 64 * 9, 'u.up1': 4 * 2 * 256 * 64 * 9, 'convt_R1.up1': 4 * 2 * 256 * 64 * 9, 'u.up0': 2 * 256 * 64 * 9, 'xpair1': 2 * 2 * 64 * 64 * 9}
-print('kernel_power: {} planes of 256x256, {} s per kernel'.format(B, secs))
+if not tag:
+    print('kernel_power: {} planes of 256x256, {} s per kernel'.format(B, secs))
 for key, label in (('arsb3', 'arsb32c_kernel<true,4>'), ('u.up1', 'conv3x3_ps4_kernel<1,false> (U last stage)'), ('convt_R1.up1', 'conv3x3_ps4_kernel<2,false> (R last stage)'), (None, 'whole a4 forward')):
+    if only and (key or 'whole') not in only:
+        continue
     rep = 200 if key else 1
     m.set_option('repeat', '{}:{}'.format(key, rep) if key else '0')
     m.set_profile(key or 'arsb3')
@@ -52,8 +57,10 @@ for key, label in (('arsb3', 'arsb32c_kernel<true,4>'), ('u.up1', 'conv3x3_ps4_k
     wall = time.perf_counter() - t0
     clk = sm.stop() or {}
     pr = m.get_profile()
-    line = '{:46s} wall {:.2f} s'.format(label, wall)
-    if key:
+    line = '{:46s} wall {:.2f} s'.format((tag + ' ' if tag else '') + label, wall)
+    if key and not pr['total_ms']:
+        line += ' | profile empty: {}'.format(pr)
+    elif key:
         per = pr['total_ms'] / max(1, pr['launches'] * rep)      # (one event pair brackets the rep launches)
         line += ' | {:.4f} ms per launch ({} launches) | {:.0f} TFLOP/s algorithmic on its {} planes'.format(per, pr['launches'] * rep, FLOP[key] * B * 65536 * (4 if 'up1' in key else 1) / per / 1e9, B)
     line += ' | {} W, {} GHz (min {} max {}, {} samples)'.format(clk.get('package_power_w_mean'), clk.get('sclk_ghz_mean'), clk.get('sclk_ghz_min'), clk.get('sclk_ghz_max'), clk.get('samples'))
