@@ -103,6 +103,8 @@ def main():
     ap.add_argument('--config', type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json's configs[N-1]: 2 = the headline (default), 3 = 4K l25 -> a2 chain, "
                     '4 = batch of 64 1080p frames, 5 = one 8K frame -> 32K with 512-px tiles (bench_extra.py)')
     ap.add_argument('--wire', default='f32', choices=['f32', 'f16s'], help='configs 3-5 under --gpus N: tile results between ranks as fp32, or as fp16 + fp32 seams (dist.py)')
+    ap.add_argument('--strong', action='store_true', help='--gpus N: ONE frame per step, its 40 tiles dealt over the N ranks and the canvas folded in row bands (strong scaling: '
+                    'the north star\'s "tiles of a frame across the GPUs") instead of N frames per step (weak scaling, the default)')
     ap.add_argument('--no-extras', action='store_true', help='config 2: skip the roofline objects of the HBM-bound members and the I/O edges')
     ap.add_argument('--no-configs', action='store_true', help="config 2: skip the short legs of BASELINE's configs 3, 4, 5 (object `configs`: one timed step each, in child processes)")
     ap.add_argument('--no-pmc', action='store_true', help='config 2: do not try the rocprofv3 --pmc passes over a short child of this command (`traffic` then comes from the committed, '
@@ -163,7 +165,8 @@ def main():
     peak_tflops = dinfo['compute_units'] * 4 * 1024 * dinfo['clock_khz'] * 1e3 / 1e12
 
     # ---- input frames, resident in HBM ------------------------------------------------------------------
-    nframes = world
+    strong = bool(args.strong and world > 1)
+    nframes = 1 if strong else world
 
     def make_frames(kind):
         if kind == 'natural':
@@ -180,7 +183,9 @@ def main():
     def step(fr):
         if world == 1:
             return ip.doCrop(opt, fr[0])
-        from moephoto_amd.dist import run_frames
+        from moephoto_amd.dist import run_frame_bands, run_frames
+        if strong:      # one frame: tiles round-robin over the ranks, every rank folds its row band; the canvas stays sharded
+            return run_frame_bands(opt, fr[:1], out_dtype=torch.float16, max_tiles_per_batch=args.tiles_per_batch)
         return run_frames(opt, fr, out_dtype=torch.float16, max_tiles_per_batch=args.tiles_per_batch)
 
     def fence():
@@ -218,14 +223,15 @@ def main():
     res = {
         'metric': 'megapixels/sec (input), 1080p 4x SR (Net4x a4), 256-px tiles with overlap',
         'value': round(value, 3), 'unit': 'MP/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
         'dtype': 'fp16' if precision != 'fp16x3' else 'fp16x3 (split fp16 operands, three MFMA passes)', 'data': 'synthetic',
         'config': {'workload': 'BASELINE configs[1]: {} frame(s) 1920x1080 RGB -> 7680x4320, model a4 (Net4x, synthetic weights in zoo format), '
                                'crop 256 pad 5 align 8 -> 40 tiles/frame, fp16 I/O, fp16 MFMA operands + fp32 accumulate'.format(nframes),
                    'frames_per_step': nframes, 'tiles_per_frame': plan.n_tiles, 'output_mp_per_s': round(value * SCALE * SCALE, 2),
                    'tflops_algorithmic': round(nframes * 3 * FRAME[1] * FRAME[2] * MFLOP_PER_PX_PLANE * 1e6 / (ms_per_step / 1e3) / 1e12, 2),
                    'tile_overlap_factor': round(overlap, 4),
-                   'parallelism': 'tile-parallel x{} (round-robin tiles, all-to-all of tile results, stitch on rank f%N)'.format(world) if world > 1 else 'single GPU',
+                   'parallelism': ('tile-parallel x{}: ONE frame, tiles round-robin over the ranks, all-to-all of tile results + blend strips, every rank folds its row band (canvas stays sharded)'.format(world) if strong else
+                                   'tile-parallel x{} (round-robin tiles, all-to-all of tile results, stitch on rank f%N)'.format(world)) if world > 1 else 'single GPU',
                    'precision': precision, 'input': 'natural-image-like synthetic frame (tests/golden_defs.natural_image)'},
         'device': {'compute_units': dinfo['compute_units'], 'max_clock_ghz': round(dinfo['clock_khz'] / 1e6, 3),
                    'peak_fp16_mfma_tflops': round(peak_tflops, 1), 'peak_formula': 'CUs x 4 SIMD x 1024 FLOP/clk x max clock (hipDeviceProp)'},
@@ -242,7 +248,7 @@ def main():
         pmc = _pmc_table()
         pmc_source = 'committed' if pmc else None
     kernels = []
-    frames_timed = args.steps        # every rank computes one frame's worth of tiles per step
+    frames_timed = args.steps / float(world) if strong else args.steps        # every rank computes one frame's worth of tiles per step (--strong: 1/N of one)
     for (key, label, flop_px), prof in zip(GROUPS, profs):
         if prof['launches'] <= 0 or prof['total_ms'] <= 0:
             continue

@@ -393,11 +393,14 @@ def _agreed_plan(opt, shape, group, device):
     return it.plan
 
 
-def run_frames_overlapped(opt, frames, group=None, out_dtype=None, max_tiles_per_batch=0, wire=None):
+def run_frames_overlapped(opt, frames, group=None, out_dtype=None, max_tiles_per_batch=0, wire=None, probe=None):
     """run_frames for a BATCH of frames (config 4: 64 of them), in groups of `world` frames with the exchange of a group overlapping the convolutions of the
     next: per group every rank computes its share of the group's tiles into one of TWO exchange buffers, starts the all-to-all asynchronously (it runs on
     the backend's stream), enqueues the next group's convolutions, and only then lets its stream wait for the previous group's exchange and folds the frame
-    it stitches.  The result is the same dict as run_frames(opt, frames): same layout, same arithmetic per group."""
+    it stitches.  The result is the same dict as run_frames(opt, frames): same layout, same arithmetic per group.
+    probe: a list (tests): per group whose exchange ran behind another group's convolutions, one dict {'group', 'exchange_done_while_computing'} -- the host polls the
+    collective's handle after the NEXT group's kernels are enqueued and notes whether it completed while an event recorded behind those kernels was still pending, i.e.
+    whether transfer and compute really overlapped in time (an asynchronous backend only: RCCL; under gloo the exchange is staged through the host and blocks)."""
     from .imageProcess import _DT
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     if len(frames) <= world:
@@ -432,6 +435,18 @@ def run_frames_overlapped(opt, frames, group=None, out_dtype=None, max_tiles_per
             p_.record_stream(torch.cuda.current_stream(dev))
         work = ex.exchange(buf, async_op=True)
         if pending is not None:
+            if probe is not None:
+                inner = getattr(pending[0], 'work', pending[0])
+                if hasattr(inner, 'is_completed'):
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(dev))      # behind THIS group's convolutions (and the start of its exchange)
+                    seen = None
+                    while seen is None:
+                        if inner.is_completed():
+                            seen = not ev.query()                    # the previous group's exchange is done; are this group's kernels still running?
+                        elif ev.query():
+                            seen = False                             # the kernels finished first: the exchange did not hide behind them
+                    probe.append({'group': gi - 1, 'exchange_done_while_computing': bool(seen)})
             finish(pending)      # (its buffer is the OTHER one; the convolutions above are already enqueued in front of this wait)
         pending = (work, ex, buf, f0)
     finish(pending)

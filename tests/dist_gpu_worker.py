@@ -15,9 +15,13 @@ from moephoto_amd.config import config  # noqa: E402
 from moephoto_amd.dist import run_frames  # noqa: E402
 from moephoto_amd.weights import load_state_dict_file, save_state_dict_file  # noqa: E402
 
-dist.init_process_group('gloo')
-rank, world = dist.get_rank(), dist.get_world_size()
+BACKEND = os.environ.get('MOE_DIST_BACKEND', 'gloo')      # 'nccl' = RCCL with the ranks on ONE device (tests/test_gpu_fullsize.py: test_dist_two_ranks_on_one_gpu_over_rccl)
 torch.cuda.set_device(0)
+if BACKEND == 'nccl':
+    dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
+else:
+    dist.init_process_group('gloo')
+rank, world = dist.get_rank(), dist.get_world_size()
 config.deviceId, config.fp16, config.crop_sr, config.modelRoot = 0, True, 64, gd.ZOO
 path = '/tmp/moe_chk_a4_{}.pth'.format(rank)
 save_state_dict_file(gd.synth_state_dict('a4', load_state_dict_file), path)
@@ -39,8 +43,12 @@ for f, y in out2.items():
 # a batch of frames in groups of `world` with the exchange of a group overlapping the next group's convolutions (two exchange buffers)
 from moephoto_amd.dist import run_frames_overlapped  # noqa: E402
 more = frames + [torch.from_numpy(gd.natural_image(60 + f, (3, 150, 200))).cuda().half() for f in range(4)]        # 7 frames: groups of `world`, a short last one
-out3 = run_frames_overlapped(opt, more, out_dtype=torch.float16)
+probe = []
+out3 = run_frames_overlapped(opt, more, out_dtype=torch.float16, probe=probe)
 torch.cuda.synchronize()
+if BACKEND == 'nccl' and world > 1:      # the asynchronous all-to-all of a group really ran WHILE the next group's convolutions were running
+    assert probe and all(p['exchange_done_while_computing'] for p in probe), probe
+    os.write(1, 'RANK {} OVERLAP {}\n'.format(rank, probe).encode())
 assert sorted(out3) == [f for f in range(len(more)) if (f % world) == rank], (sorted(out3), rank)
 for f, y in out3.items():
     assert torch.equal(y, ip.doCrop(opt, more[f])), f
