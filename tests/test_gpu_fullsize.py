@@ -383,7 +383,10 @@ def test_dist_two_ranks_on_one_gpu_over_rccl(dev):
         pytest.skip('RCCL with two ranks on one device did not finish in 420 s (a hang at communicator setup is how some builds refuse it): ' + str(e)[-200:])
     text = p.stdout + p.stderr
     if p.returncode != 0:
-        refusal = [l.strip() for l in text.splitlines() if any(w in l for w in ('Duplicate GPU', 'invalid usage', 'ncclInvalidUsage', 'multiple ranks', 'same device', 'ncclUnhandledCudaError', 'NCCL WARN'))]
+        lines = [l.strip() for l in text.splitlines()]
+        refusal = [l for l in lines if any(w in l for w in ('Duplicate GPU', 'invalid usage', 'ncclInvalidUsage', 'multiple ranks', 'same device'))]
+        refusal = refusal or [l for l in lines if 'DistBackendError' in l or ('NCCL WARN' in l and 'iommu' not in l) or 'ncclUnhandledCudaError' in l or 'ncclSystemError' in l or 'ncclInternalError' in l]
+        open(os.path.join(ROOT, 'gpurun_out', 'rccl_two_ranks_one_device.log'), 'w').write(text[-20000:]) if os.path.isdir(os.path.join(ROOT, 'gpurun_out')) else None
         if refusal:
             _report('rccl_two_ranks_one_device', {'refused': refusal[0][:300]})
             pytest.skip('RCCL refuses two ranks on one device: ' + refusal[0][:300])
