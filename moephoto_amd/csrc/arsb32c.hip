@@ -175,16 +175,13 @@ constexpr int TRACE_LDS = 0;
 
 // KS: 16-channel k-slices of the convs' INPUT that carry data -- 4, or 3 for the 48-channel nets (NetDN: channels 48..63 of every activation and
 // the weights on them are zero; the fourth slice's fragments, MFMAs and reads are simply left out: -25 % MFMAs, bit-identical results)
-// L8 (round 5; requires LO): the stream's low part travels as ONE byte per channel in and out -- the OCP e4m3 word of ((v - fp16(v)) 2^11) / 4, the form the split-operand
-// chain in front of the single-pass blocks already writes (conv64_sq.hip / arsb_sq.hip, Act::lo8 in engine.cpp): 64 instead of 128 bytes per pixel each way.  The
-// convolutions see the same fp16 operands; the residual additions see ~15 instead of 22 bits of the stream.  Why: profiles/r05/b_arsb32c_ablations_power_clock.txt --
-// this kernel sits at the package power cap at 1.45 GHz, and every 100 bytes per pixel it does not move buy ~4.4 % (no lo loads, no stores: 1.72 GHz, -17 %).
-template <bool LO, int KS, bool L8>
+// (Round 5 built and measured a third parameter, L8: the stream's low part as the chain's fp8 words in and out, 430 instead of 558 bytes a pixel.  Looped by itself the
+// kernel went 0.973 -> 0.939 ms per 96 planes (1.48 -> 1.66 GHz under the power cap); inside the frame the trunk stayed at 5.15 ms, the frame moved 23.73 -> 23.65 ms and the
+// error budget paid 0.5e-4 (a4) to 3.8e-4 (a2, single tiles): dropped again -- profiles/r05/c_stream8_ab.txt, source in the history at 0486050.)
+template <bool LO, int KS>
 __global__ __launch_bounds__(256) void arsb32c_kernel(ArsbArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    static_assert(LO || !L8, "fp8 low parts are a form of the hi + lo stream");
-    if (L8) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1\n\ts_nop 3" ::: "memory");      // MODE.FP16_OVFL: the fp8 conversions saturate (conv64_q8.hip)
     constexpr unsigned kOOR = 0xFFFF0000u;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
@@ -244,10 +241,10 @@ __global__ __launch_bounds__(256) void arsb32c_kernel(ArsbArgs a)
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.x_hi - in_pad), 0,
                                                                          A32_IN_BYTES((unsigned)a.B * a.H * a.W * 128u + in_pad), 0x00020000);
     const unsigned nbytes = (unsigned)a.B * a.H * a.W * 128u;
-    const __amdgpu_buffer_rsrc_t rlo = __builtin_amdgcn_make_buffer_rsrc((void*)(LO ? a.x_lo : a.x_hi), 0, A32_LO_BYTES(L8 ? nbytes / 2 : nbytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rlo = __builtin_amdgcn_make_buffer_rsrc((void*)(LO ? a.x_lo : a.x_hi), 0, A32_LO_BYTES(nbytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t ryh = __builtin_amdgcn_make_buffer_rsrc((void*)a.y_hi, 0, A32_ST_BYTES(nbytes), 0x00020000);
     // drop_lo: nobody reads this block's low part (the last ARSB of an SR net: the upsampler takes the fp16 part) -- its stores are issued against an empty range
-    const __amdgpu_buffer_rsrc_t ryl = __builtin_amdgcn_make_buffer_rsrc((void*)(LO ? a.y_lo : a.y_hi), 0, a.drop_lo ? 0u : A32_ST_BYTES(A32_LO_BYTES(L8 ? nbytes / 2 : nbytes)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ryl = __builtin_amdgcn_make_buffer_rsrc((void*)(LO ? a.y_lo : a.y_hi), 0, a.drop_lo ? 0u : A32_ST_BYTES(A32_LO_BYTES(nbytes)), 0x00020000);
     const int qlane = w4 * 8 + (lane >> 3);
     unsigned d_off = 0, d_r = 0, d_cc = 0;                    // DMA piece in the making: byte offset inside the patch, patch row / column of the lane's pixel
     auto piece_addr = [&](int i) {
@@ -286,16 +283,6 @@ __global__ __launch_bounds__(256) void arsb32c_kernel(ArsbArgs a)
         xh[o] = (unsigned)(5 * h * ROWB + (j + 2) * 128 + ((s ^ (((j + 2) >> 1) & 7)) << 4));
     }
     const unsigned lane_ob = (unsigned)(j * 128 + (32 * c + 8 * hh) * 2);      // byte offset of slot o = 0 of output column j inside a patch row of the stream tensors
-    const unsigned lane_ob8 = (unsigned)(j * 64 + 32 * c + 8 * hh);            // ... of the fp8 low-part tensors (64 bytes a pixel, channel ch at byte ch)
-    const float quarter = 4.0f;
-    auto cvt4 = [&](unsigned a0, unsigned a1, unsigned b0, unsigned b1, unsigned& p0, unsigned& p1) __attribute__((always_inline)) {      // (arsb_sq.hip: eight fp16 low parts -> eight e4m3 words of value / 4)
-        asm volatile("v_cvt_scalef32_pk_fp8_f16 %0, %2, %6\n\t"
-                     "v_cvt_scalef32_pk_fp8_f16 %1, %4, %6\n\t"
-                     "v_cvt_scalef32_pk_fp8_f16 %0, %3, %6 op_sel:[0,0,1]\n\t"
-                     "v_cvt_scalef32_pk_fp8_f16 %1, %5, %6 op_sel:[0,0,1]\n\t"
-                     "s_nop 0"
-                     : "=&v"(p0), "=&v"(p1) : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(quarter));
-    };
     unsigned slope2;
     {
         const half2_t s2 = {(half_t)a.slope, (half_t)a.slope};
@@ -305,23 +292,15 @@ __global__ __launch_bounds__(256) void arsb32c_kernel(ArsbArgs a)
 
     float16_t acc[4];
     half8_t fr[14];           // fragment f of row step t (0..6 conv_1, 7..13 conv_2) lives in fr[(f - t) mod 14]
-    typedef unsigned u2_t __attribute__((ext_vector_type(2)));
-    u4_t xlo[L8 ? 1 : 5][2], xhv[2];   // residual words in flight: x_lo of the five rows, x_hi of ONE row (slot o)
-    u2_t xl8[L8 ? 5 : 1][2];            // ... L8: the rows' fp8 low words
+    u4_t xlo[5][2], xhv[2];   // residual words in flight: x_lo of the five rows, x_hi of ONE row (slot o)
     unsigned sh[4], sl[4];
     // stream tensors: byte offset of (output row 5h, column x0) of the patch, the lane's column part; rows 3, 4 of the PREVIOUS patch (stored one patch late)
     unsigned so0 = 0, vo = kOOR, so3p = kOOR, so4p = kOOR, vop = kOOR, xprev = lds0;
-    unsigned vo8 = kOOR, vop8 = kOOR;   // (L8: the lane's column part in the 64-byte-a-pixel tensors)
-    auto half_off = [&](unsigned so) { return so == kOOR ? kOOR : so >> 1; };      // row offset in a 64-byte-a-pixel tensor (wave-uniform)
     int yrow0 = 0;
     {
         const u4_t z4 = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int o = 0; o < 2; ++o) {      // (the first patch runs the late epilogues of "the patch before" with their stores rejected)
-            xhv[o] = z4;
-            if (L8) { xl8[L8 ? 4 : 0][o] = u2_t{0u, 0u}; xl8[L8 ? 3 : 0][o] = u2_t{0u, 0u}; }
-            else { xlo[L8 ? 0 : 4][o] = z4; xlo[L8 ? 0 : 3][o] = z4; }
-        }
+        for (int o = 0; o < 2; ++o) { xhv[o] = z4; xlo[4][o] = z4; xlo[3][o] = z4; }      // (the first patch runs the late epilogues of "the patch before" with their stores rejected)
         acc[0] = zero16; acc[3] = zero16;
     }
     auto row_so = [&](int i) { return (yrow0 + i < a.H) ? so0 + (unsigned)(i * a.W * 128) : kOOR; };
@@ -359,7 +338,6 @@ __global__ __launch_bounds__(256) void arsb32c_kernel(ArsbArgs a)
         A32_STAMP(0)
         so0 = (unsigned)(((it.b * a.H + y0 + 5 * h) * a.W + x0) * 128);
         vo = ((j < TW) & (x0 + j < a.W)) ? lane_ob : kOOR;
-        vo8 = ((j < TW) & (x0 + j < a.W)) ? lane_ob8 : kOOR;
         yrow0 = y0 + 5 * h;
         unsigned hp[8];                                       // activated m row being written (packed halves: slot 0 | slot 1)
 
@@ -460,8 +438,7 @@ __global__ __launch_bounds__(256) void arsb32c_kernel(ArsbArgs a)
         };
         auto op_xlo = [&](auto I_, auto O_) __attribute__((always_inline)) {
             constexpr int i = decltype(I_)::value, o = decltype(O_)::value;
-            if constexpr (L8) xl8[i][o] = __builtin_amdgcn_raw_buffer_load_b64(rlo, vo8 + (unsigned)(o * 16), half_off(row_so(i)), 0);
-            else xlo[i][o] = __builtin_amdgcn_raw_buffer_load_b128(rlo, vo + (unsigned)(o * 32), row_so(i), 0);
+            xlo[i][o] = __builtin_amdgcn_raw_buffer_load_b128(rlo, vo + (unsigned)(o * 32), row_so(i), 0);
         };
         auto op_xhi = [&](auto I_, auto O_) __attribute__((always_inline)) {
             constexpr int i = decltype(I_)::value, o = decltype(O_)::value;
@@ -473,18 +450,14 @@ __global__ __launch_bounds__(256) void arsb32c_kernel(ArsbArgs a)
 #ifdef A32_NOEPI
 #pragma unroll
             for (int k = k0; k < k0 + 2; ++k) { sh[k] = __builtin_bit_cast(unsigned, acc[i & 3][8 * o + 2 * k]); sl[k] = __builtin_bit_cast(unsigned, acc[i & 3][8 * o + 2 * k + 1]); }
-            if constexpr (L8) asm volatile("" :: "v"(xhv[o]), "v"(xl8[i][o])); else asm volatile("" :: "v"(xhv[o]), "v"(xlo[L8 ? 0 : i][o]));
+            asm volatile("" :: "v"(xhv[o]), "v"(xlo[i][o]));
             return;
 #endif
 #pragma unroll
             for (int k = k0; k < k0 + 2; ++k) {
                 float v0 = acc[i & 3][8 * o + 2 * k], v1 = acc[i & 3][8 * o + 2 * k + 1];
                 v0 = mix_lo(xhv[o][k], 1.0f, v0); v1 = mix_hi(xhv[o][k], 1.0f, v1);
-                if constexpr (L8) {      // + x_lo8 2^-9 (the word holds lo / 4, lo in units of 2^-11: arsb_sq.hip's arithmetic)
-                    typedef float f2_t __attribute__((ext_vector_type(2)));
-                    const f2_t f = (k & 1) ? __builtin_amdgcn_cvt_pk_f32_fp8((int)xl8[i][o][k >> 1], true) : __builtin_amdgcn_cvt_pk_f32_fp8((int)xl8[i][o][k >> 1], false);
-                    v0 = __builtin_fmaf(f[0], 0.001953125f, v0); v1 = __builtin_fmaf(f[1], 0.001953125f, v1);
-                } else if (LO) { v0 = mix_lo(xlo[i][o][k], 0.00048828125f, v0); v1 = mix_hi(xlo[i][o][k], 0.00048828125f, v1); }
+                if (LO) { v0 = mix_lo(xlo[i][o][k], 0.00048828125f, v0); v1 = mix_hi(xlo[i][o][k], 0.00048828125f, v1); }
                 acc[i & 3][8 * o + 2 * k] = v0; acc[i & 3][8 * o + 2 * k + 1] = v1;
             }
             if (!LO) {
@@ -510,11 +483,7 @@ __global__ __launch_bounds__(256) void arsb32c_kernel(ArsbArgs a)
             const unsigned vv = (late ? vop : vo) + (unsigned)(o * 32);
             const u4_t dh = {sh[0], sh[1], sh[2], sh[3]};
             __builtin_amdgcn_raw_buffer_store_b128(dh, ryh, vv, so, 0);
-            if constexpr (L8) {
-                unsigned p0, p1;
-                cvt4(sl[0], sl[1], sl[2], sl[3], p0, p1);
-                __builtin_amdgcn_raw_buffer_store_b64(u2_t{p0, p1}, ryl, (late ? vop8 : vo8) + (unsigned)(o * 16), half_off(so), 0);
-            } else if (LO) {
+            if (LO) {
                 const u4_t dl = {sl[0], sl[1], sl[2], sl[3]};
                 __builtin_amdgcn_raw_buffer_store_b128(dl, ryl, vv, so, 0);
             }
@@ -668,7 +637,6 @@ __global__ __launch_bounds__(256) void arsb32c_kernel(ArsbArgs a)
         so3p = row_so(3);                                     // slot 1 of output row 3 and row 4 of the wave: their epilogues ride in the next patch's conv_1
         so4p = row_so(4);
         vop = vo;
-        vop8 = vo8;
         xprev = xcur;
         it_cur = itn;
         if (!has_next) run_ops(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
@@ -689,11 +657,10 @@ __global__ __launch_bounds__(256) void arsb32c_kernel(ArsbArgs a)
 hipError_t arsb32c_init()
 {
     hipError_t e;
-    if ((e = hipFuncSetAttribute((const void*)arsb32c_kernel<false, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + TRACE_LDS)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)arsb32c_kernel<true, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + TRACE_LDS)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)arsb32c_kernel<true, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + TRACE_LDS)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)arsb32c_kernel<false, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + TRACE_LDS)) != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)arsb32c_kernel<true, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + TRACE_LDS);
+    if ((e = hipFuncSetAttribute((const void*)arsb32c_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + TRACE_LDS)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)arsb32c_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + TRACE_LDS)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)arsb32c_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + TRACE_LDS)) != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)arsb32c_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + TRACE_LDS);
 }
 
 // w1 / w2: packed A fragments in the conv3x3_sp / pack_conv order (ConvLayer::w_hi).  false: the layer does not fit this kernel
@@ -709,12 +676,7 @@ bool launch_arsb32c(ArsbArgs a, int max_groups, hipStream_t s)
     const int G = (int)std::min<long long>(items, max_groups);
     if (a.cin != 0 && a.cin != 48 && a.cin != 64) return false;
     const bool k3 = a.cin == 48;               // the fourth 16-channel k-slice carries zeros only
-    if (a.lo8 && (k3 || !a.x_lo)) return false;                           // fp8 low parts: the 64-channel hi + lo stream only
-    if (a.x_lo) {
-        if (a.lo8) arsb32c_kernel<true, 4, true><<<dim3(G), dim3(256), LDS_BYTES + TRACE_LDS, s>>>(a);
-        else if (k3) arsb32c_kernel<true, 3, false><<<dim3(G), dim3(256), LDS_BYTES + TRACE_LDS, s>>>(a);
-        else arsb32c_kernel<true, 4, false><<<dim3(G), dim3(256), LDS_BYTES + TRACE_LDS, s>>>(a);
-    }
-    else { if (k3) arsb32c_kernel<false, 3, false><<<dim3(G), dim3(256), LDS_BYTES + TRACE_LDS, s>>>(a); else arsb32c_kernel<false, 4, false><<<dim3(G), dim3(256), LDS_BYTES + TRACE_LDS, s>>>(a); }
+    if (a.x_lo) { if (k3) arsb32c_kernel<true, 3><<<dim3(G), dim3(256), LDS_BYTES + TRACE_LDS, s>>>(a); else arsb32c_kernel<true, 4><<<dim3(G), dim3(256), LDS_BYTES + TRACE_LDS, s>>>(a); }
+    else { if (k3) arsb32c_kernel<false, 3><<<dim3(G), dim3(256), LDS_BYTES + TRACE_LDS, s>>>(a); else arsb32c_kernel<false, 4><<<dim3(G), dim3(256), LDS_BYTES + TRACE_LDS, s>>>(a); }
     return true;
 }

@@ -153,7 +153,6 @@ struct ArsbArgs {
     int B, H, W;
     int px, py;                               // set by the launcher
     int cin;                                  // channels that carry data (0 = 64): arsb32c leaves the fourth k-slice out for the 48-channel nets
-    int lo8;                                  // x_lo / y_lo hold fp8 e4m3 words of lo / 4, 64 bytes a pixel (the chain's form: Act::lo8) instead of fp16 low parts
     int drop_lo;                              // y_lo is never read: its stores are issued against an empty range (the last ARSB of an SR net)
     unsigned long long* trace;                // -DARSB_TRACE builds only: s_memtime stamps [workgroup < 8][patch < 16][wave 4][slot 40]
 };

@@ -98,10 +98,6 @@ struct NetOptions {
                               //             q8 (2: conv64_q8.hip, the two correction products on fp8 operands)
     int k48 = 1;              // k48         1 (default): kernels that can skip the zero k-slice of the 48-channel nets do | 0: they run all four (A/B)
     int s64 = 1;              // s64         1 (default): SEDN's fused block tail on conv64_s.hip (streamed, per-plane weights in registers) | 0: conv3x3_sp<6>
-    int stream8 = 0;          // stream8     0 (default): the single-pass ARSBs carry fp16 low parts | 1: behind a chain of split-operand layers (lo8) they keep the stream's low part as fp8
-                              //             words too (arsb32c<.., L8>: 430 instead of 558 bytes a pixel and block).  Measured (profiles/r05/c_stream8_ab.txt): the kernel looped by itself
-                              //             0.973 -> 0.939 ms per 96 planes (1.48 -> 1.66 GHz under the power cap), but inside the frame the trunk stays at 5.15 ms and the frame moves
-                              //             23.73 -> 23.65 ms, while the calibration error of a4 goes 6.7e-4 -> 7.2e-4: not worth 0.5e-4 of the 1e-3 budget, so opt-in
     int exact_fuse = 1;       // exact_fuse  1 (default): an exact ARSB of a chain runs as ONE launch (arsb_sq.hip: conv_1's rows stay in LDS) | 0: conv_1, conv_2 on conv64_sq / conv64_q8
     int q8_impl = 1;          // q8_impl     s (1, default: conv64_sq.hip, the chain layers streamed down a column by an fp16 wave + an fp8 wave) | p (0: conv64_q8.hip, 8 x 32 patches)
                               // (the one-launch ARSB of the single-pass blocks is arsb32c.hip.  Earlier generations -- arsb_fused.hip, arsb32.hip (history at 689845f) and the streamed
@@ -144,7 +140,6 @@ struct NetOptions {
         if (key == "k48") { const int t = onoff(v); if (t < 0) return false; k48 = t; return true; }
         if (key == "s64") { const int t = onoff(v); if (t < 0) return false; s64 = t; return true; }
         if (key == "auto_calibrate") { const int t = onoff(v); if (t < 0) return false; auto_calibrate = t; return true; }
-        if (key == "stream8") { const int t = onoff(v); if (t < 0) return false; stream8 = t; return true; }
         if (key == "exact_fuse") { const int t = onoff(v); if (t < 0) return false; exact_fuse = t; return true; }
         if (key == "q8_impl") { if (v && !strcmp(v, "s")) q8_impl = 1; else if (v && !strcmp(v, "p")) q8_impl = 0; else return false; return true; }
         if (key == "conv1x1") return flag(conv1x1);
@@ -168,7 +163,7 @@ struct NetOptions {
     void from_env()
     {
         static const char* const names[][2] = {{"MOE_CONV_IMPL", "conv_impl"}, {"MOE_SP_IMPL", "sp_impl"}, {"MOE_TAIL_SPLIT", "tail_split"}, {"MOE_TAIL_FORM", "tail_form"}, {"MOE_UP_IMPL", "up_impl"},
-                                               {"MOE_CONV1X1", "conv1x1"}, {"MOE_Q8_IMPL", "q8_impl"}, {"MOE_EXACT_FUSE", "exact_fuse"}, {"MOE_STREAM8", "stream8"}, {"MOE_AUTO_CALIBRATE", "auto_calibrate"}, {"MOE_S64", "s64"}, {"MOE_K48", "k48"}, {"MOE_X3_IMPL", "x3_impl"}, {"MOE_LO8", "lo8"}, {"MOE_X3_FUSE", "x3_fuse"}, {"MOE_ARSB_FUSE", "arsb_fuse"}, {"MOE_FUSE_TAIL", "fuse_tail"},
+                                               {"MOE_CONV1X1", "conv1x1"}, {"MOE_Q8_IMPL", "q8_impl"}, {"MOE_EXACT_FUSE", "exact_fuse"}, {"MOE_AUTO_CALIBRATE", "auto_calibrate"}, {"MOE_S64", "s64"}, {"MOE_K48", "k48"}, {"MOE_X3_IMPL", "x3_impl"}, {"MOE_LO8", "lo8"}, {"MOE_X3_FUSE", "x3_fuse"}, {"MOE_ARSB_FUSE", "arsb_fuse"}, {"MOE_FUSE_TAIL", "fuse_tail"},
                                                {"MOE_SEDN_FUSE", "sedn_fuse"}, {"MOE_POOL_FUSE", "pool_fuse"}, {"MOE_DBG", "dbg"}, {"MOE_TRACE_KEY", "trace_key"},
                                                {"MOE_TILES_PER_BATCH", "tiles_per_batch"}, {"MOE_MAX_GROUPS", "max_groups"}};
         for (const auto& nv : names)
@@ -1057,16 +1052,6 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
             for (int j = (i == 0 ? 2 : 1); chain8 && j <= 2; ++j)
                 chain8 = f.q8_capable(n.convs[n.conv_index.at(i == 0 ? std::string("input2") : "c" + std::to_string(j) + "_" + std::to_string(i))]);
         A.lo8 = Bb.lo8 = chain8;
-        // ... and the single-pass blocks behind the chain keep that form (arsb32c<.., L8>): the last exact block then writes fp8 words like the others.  Needs the one-launch
-        // ARSB for every single-pass block (the two-launch fallback reads fp16 low parts): its conditions are checked here, not discovered at launch.
-        bool stream8 = chain8 && n.opt.stream8 && n.opt.exact_fuse && n.opt.q8_impl == 1 && n.opt.arsb_fuse && !f.x3 && n.opt.conv_impl == 2 && nx < 6 &&
-                       (long long)B * h * w * 128 + (2ll * w + 2) * 128 < (1ll << 32) - 65536 && (long long)B * ((w + 29) / 30) * ((h + 9) / 10) < (1ll << 31) / 256;
-        for (int i = 1; stream8 && i <= 6; ++i) {
-            const ConvLayer& L1 = n.convs[n.conv_index.at("c1_" + std::to_string(i))];
-            const ConvLayer& L2 = n.convs[n.conv_index.at("c2_" + std::to_string(i))];
-            stream8 = i <= nx ? (L1.wq_hi8 && L2.wq_hi8 && !L1.has_bias && !L2.has_bias && L2.slope == 1.f && L1.slope <= 1.f)      // (arsb_sq's conditions: the chain must not fall back to two launches mid-way)
-                              : (L1.w_arsb != 0 && L1.slope <= 1.f && L1.cin == 64 && L2.cin == 64);
-        }
         stem(A);
         f.tap("stem", A, h, w, 64, n.C);
         if (int rc = trunk_conv("input2", A, Bb, nullptr, mixed)) return rc;
@@ -1095,7 +1080,6 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
                         ArsbArgs q2 = q;
                         q2.w1 = f.blob<half_t>(L1.w_hi); q2.w2 = f.blob<half_t>(L2.w_hi);      // (pack_conv order; conv_2's carry the ScaleLayer factor as well)
                         q2.cin = (L1.cin == 48 && L2.cin == 48 && n.opt.k48) ? 48 : 64;      // NetDN: channels 48..63 are zeros in activations and weights
-                        q2.lo8 = (mixed && cur.lo8) ? 1 : 0;                                   // the stream's low part arrives (and leaves) as fp8 words (stream8)
                         q2.drop_lo = (mixed && i == 6 && n.arch != MOE_ARCH_NETDN && !n.debug) ? 1 : 0;      // the upsamplers take the fp16 part: nobody reads block 6's low part
                         for (int rep = f.repeats("arsb" + std::to_string(i)); rep > 0; --rep)
                             done = launch_arsb32c(q2, n.max_groups, s);      // (false: the shape does not fit its 32-bit offsets -- the two-launch form below)
@@ -1109,14 +1093,7 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
                         (void)hipFree(q.trace);
                     }
                 }
-                if (done) {      // (the low part leaves in the form it came in; the scratch side's form is its next writer's)
-                    const bool l8 = mixed && cur.lo8;
-                    std::swap(cur, oth);
-                    cur.lo8 = l8; oth.lo8 = false;
-                    f.tap("arsb" + std::to_string(i), cur, h, w, 64, n.C);
-                    continue;
-                }
-                if (mixed && cur.lo8) return fail(MOE_EINVAL, "ARSB %d: the one-launch kernel rejected a block of the fp8-low-part stream (option stream8 = 0 runs it with fp16 low parts)", i);
+                if (done) { std::swap(cur, oth); cur.lo8 = oth.lo8 = false; f.tap("arsb" + std::to_string(i), cur, h, w, 64, n.C); continue; }      // (fp16 low parts out; the scratch side's form is its next writer's)
             }
             if (ex && chain8 && n.opt.exact_fuse && n.opt.q8_impl == 1 && cur.lo8 && cur.lo && oth.lo) {
                 // an exact block of the chain in ONE launch (arsb_sq.hip): x = cur (fp16 + fp8 low words) -> oth; the last exact block writes fp16 low parts (the
@@ -1130,7 +1107,7 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
                         q.x_hi = cur.hi; q.x_lo8 = (const unsigned char*)cur.lo; q.y_hi = oth.hi; q.y_lo = oth.lo;
                         q.w16[0] = f.blob<half_t>(L1.w_hi); q.wh8[0] = f.blob<unsigned char>(L1.wq_hi8); q.wl8[0] = f.blob<unsigned char>(L1.wq_lo8);
                         q.w16[1] = f.blob<half_t>(L2.w_hi); q.wh8[1] = f.blob<unsigned char>(L2.wq_hi8); q.wl8[1] = f.blob<unsigned char>(L2.wq_lo8);
-                        q.slope = L1.slope; q.B = B; q.H = h; q.W = w; q.out8 = i < nx || stream8;
+                        q.slope = L1.slope; q.B = B; q.H = h; q.W = w; q.out8 = i < nx;
                         const int rec = f.prof_begin("xpair" + std::to_string(i), 2.0 * 2.0 * 3.0 * (double)B * h * w * L1.cout * L1.cin * 9);
                         done = launch_arsb_sq(q, n.max_groups, s);
                         f.prof_end(rec);
@@ -1138,7 +1115,7 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
                 }
                 if (done) {
                     std::swap(cur, oth);
-                    cur.lo8 = i < nx || stream8;
+                    cur.lo8 = i < nx;
                     oth.lo8 = false;             // (scratch now: whoever writes it next decides its form)
                     f.tap("arsb" + std::to_string(i), cur, h, w, 64, n.C);
                     continue;
