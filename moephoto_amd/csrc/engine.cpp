@@ -98,6 +98,14 @@ struct NetOptions {
                               //             q8 (2: conv64_q8.hip, the two correction products on fp8 operands)
     int k48 = 1;              // k48         1 (default): kernels that can skip the zero k-slice of the 48-channel nets do | 0: they run all four (A/B)
     int s64 = 1;              // s64         1 (default): SEDN's fused block tail on conv64_s.hip (streamed, per-plane weights in registers) | 0: conv3x3_sp<6>
+    int branch_streams = 1;   // branch_streams  1 (default): small launch sets (the reference's own per-tile loop: 3 planes of <= 256 x 256 per forward) run the U branch on a second
+                              //             HIP stream beside the trunk + R branch -- a launch of a few planes leaves CUs idle at its tail (702 ARSB patches over 256 workgroups) and the
+                              //             other branch's workgroups take them; same kernels, same bits | 0: one stream
+    int branch_groups = 0;    // branch_groups   persistent workgroups of the side stream's launches in that mode (0: 5/16 of the CUs for the x4 nets, 3/16 for x2 / x3 -- about the U
+                              //             branch's share of the forward; a4: 29.0 / 27.4 / 27.9 / 28.4 ms per frame with 64 / 80 / 96 / 112, 34.1 with 48; a2: 20.1-20.2 with 24 .. 64,
+                              //             21.6 on one stream -- profiles/r05/g_branch_streams.txt); the trunk + R branch launch max_groups minus that many.  A launch of 3 planes scales badly over 256
+                              //             workgroups -- the per-tile loop takes 30.6 / 31.3 / 38.2 / 66.4 ms per frame with 256 / 192 / 128 / 64 (profiles/r05/f_small_launch_scaling.txt)
+                              //             -- so the two branches are given disjoint shares of the chip instead of each launch spreading over all of it
     int exact_fuse = 1;       // exact_fuse  1 (default): an exact ARSB of a chain runs as ONE launch (arsb_sq.hip: conv_1's rows stay in LDS) | 0: conv_1, conv_2 on conv64_sq / conv64_q8
     int q8_impl = 1;          // q8_impl     s (1, default: conv64_sq.hip, the chain layers streamed down a column by an fp16 wave + an fp8 wave) | p (0: conv64_q8.hip, 8 x 32 patches)
                               // (the one-launch ARSB of the single-pass blocks is arsb32c.hip.  Earlier generations -- arsb_fused.hip, arsb32.hip (history at 689845f) and the streamed
@@ -140,6 +148,8 @@ struct NetOptions {
         if (key == "k48") { const int t = onoff(v); if (t < 0) return false; k48 = t; return true; }
         if (key == "s64") { const int t = onoff(v); if (t < 0) return false; s64 = t; return true; }
         if (key == "auto_calibrate") { const int t = onoff(v); if (t < 0) return false; auto_calibrate = t; return true; }
+        if (key == "branch_groups") { branch_groups = atoi(v); return branch_groups >= 0; }
+        if (key == "branch_streams") { const int t = onoff(v); if (t < 0) return false; branch_streams = t; return true; }
         if (key == "exact_fuse") { const int t = onoff(v); if (t < 0) return false; exact_fuse = t; return true; }
         if (key == "q8_impl") { if (v && !strcmp(v, "s")) q8_impl = 1; else if (v && !strcmp(v, "p")) q8_impl = 0; else return false; return true; }
         if (key == "conv1x1") return flag(conv1x1);
@@ -163,7 +173,7 @@ struct NetOptions {
     void from_env()
     {
         static const char* const names[][2] = {{"MOE_CONV_IMPL", "conv_impl"}, {"MOE_SP_IMPL", "sp_impl"}, {"MOE_TAIL_SPLIT", "tail_split"}, {"MOE_TAIL_FORM", "tail_form"}, {"MOE_UP_IMPL", "up_impl"},
-                                               {"MOE_CONV1X1", "conv1x1"}, {"MOE_Q8_IMPL", "q8_impl"}, {"MOE_EXACT_FUSE", "exact_fuse"}, {"MOE_AUTO_CALIBRATE", "auto_calibrate"}, {"MOE_S64", "s64"}, {"MOE_K48", "k48"}, {"MOE_X3_IMPL", "x3_impl"}, {"MOE_LO8", "lo8"}, {"MOE_X3_FUSE", "x3_fuse"}, {"MOE_ARSB_FUSE", "arsb_fuse"}, {"MOE_FUSE_TAIL", "fuse_tail"},
+                                               {"MOE_CONV1X1", "conv1x1"}, {"MOE_Q8_IMPL", "q8_impl"}, {"MOE_EXACT_FUSE", "exact_fuse"}, {"MOE_BRANCH_STREAMS", "branch_streams"}, {"MOE_BRANCH_GROUPS", "branch_groups"}, {"MOE_AUTO_CALIBRATE", "auto_calibrate"}, {"MOE_S64", "s64"}, {"MOE_K48", "k48"}, {"MOE_X3_IMPL", "x3_impl"}, {"MOE_LO8", "lo8"}, {"MOE_X3_FUSE", "x3_fuse"}, {"MOE_ARSB_FUSE", "arsb_fuse"}, {"MOE_FUSE_TAIL", "fuse_tail"},
                                                {"MOE_SEDN_FUSE", "sedn_fuse"}, {"MOE_POOL_FUSE", "pool_fuse"}, {"MOE_DBG", "dbg"}, {"MOE_TRACE_KEY", "trace_key"},
                                                {"MOE_TILES_PER_BATCH", "tiles_per_batch"}, {"MOE_MAX_GROUPS", "max_groups"}};
         for (const auto& nv : names)
@@ -210,6 +220,9 @@ struct moe_net {
     struct OffSlot { long long* host = nullptr; long long* dev = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool used = false; };
     OffSlot off_ring[4];
     int off_next = 0;
+    // second stream of small launch sets (option branch_streams): the U branch forks behind the stem and joins in front of the branch sum
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // debug taps
     bool debug = false;
     struct Tap { float* dev = nullptr; int64_t shape[4] = {0, 0, 0, 0}; };
@@ -1054,6 +1067,104 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         A.lo8 = Bb.lo8 = chain8;
         stem(A);
         f.tap("stem", A, h, w, 64, n.C);
+        // ---- the two upsampler branches: R on the trunk output, U on the stem output (models.py:117-123) -- planned here, because a small launch set starts its U branch NOW, on a second stream ----
+        Act fin[2];
+        float* tp[2] = {nullptr, nullptr};
+        const bool sr = n.arch != MOE_ARCH_NETDN;
+        const bool fuse = sr && can_fuse_tail(n, f, B, h, w);      // last upsampler conv + 64->1 tail conv in one kernel
+        bool ps4 = false;
+        int H = h, W = w;
+        if (sr) {   // form of the fused tail's output: phase-class sums when the last stage is a x2 shuffle the register-weight kernel takes
+            int hl = h, wl = w;
+            for (int st = 0; st + 1 < n.stages; ++st) { hl *= n.r; wl *= n.r; }
+            bool ok = fuse && n.opt.tail_form == 1 && n.r == 2 && wl % 4 == 0 && tailsum_fits(B, hl, wl) &&
+                      2ll * B * hl * wl * 64 + 2ll * (wl + 1) * 64 < (1ll << 32) - 65536;
+            bool ps4_ok = true;
+            for (const char* br : {"u", "convt_R1"}) {
+                const auto it = n.conv_index.find(std::string(br) + ".up" + std::to_string(n.stages - 1));
+                ok = ok && it != n.conv_index.end() && n.convs[it->second].slope < 1.f;
+                ps4_ok = ps4_ok && it != n.conv_index.end() && ps4_tail_applicable(B, hl, wl, n.convs[it->second].slope);      // (the launcher's own predicate: common.h)
+            }
+            f.tail_form = ok ? 1 : 0;
+            // the same layer with all four phases in one workgroup (conv3x3_ps4.hip): one fp32 plane + column aprons per branch, added by tailadd
+            ps4 = ok && n.opt.up_impl == 1 && ps4_ok && (2 * wl) % 8 == 0;
+        }
+        float* ps_plane[2] = {nullptr, nullptr};
+        float* ps_apron[2] = {nullptr, nullptr};
+        auto run_branch = [&](int br, Act cur) -> int {      // launches go to f.s (the caller's stream, or the side stream while the U branch is forked)
+            if (f.mixed) { cur.lo = nullptr; cur.lo8 = false; }      // MIXED: the upsampler convs take the fp16 parts (FP16X3 keeps its pairs)
+            H = h; W = w;
+            for (int st = 0; st < n.stages; ++st) {
+                const std::string key = std::string(br == 0 ? "convt_R1" : "u") + ".up" + std::to_string(st);
+                if (ps4 && st == n.stages - 1) {
+                    ps_plane[br] = (float*)f.ar.take(ps4_plane_bytes(B, H, W) + 4096);
+                    ps_apron[br] = (float*)f.ar.take(ps4_apron_bytes(B, H, W) + 4096);
+                    if (!f.dry()) {
+                        const ConvLayer& L = n.convs[n.conv_index.at(key)];
+                        Ps4Args q{};
+                        q.in = cur.hi; q.wpk = f.blob<half_t>(L.w_hi); q.bias = L.has_bias ? f.blob<float>(L.bias) : f.small<float>("zero_bias");
+                        q.tail_w = f.small<half_t>(br == 0 ? "tail_r.frag" : "tail_u.frag");
+                        q.plane = ps_plane[br]; q.apron = ps_apron[br]; q.slope = L.slope; q.B = B; q.H = H; q.W = W;
+                        q.split = (f.mixed && f.tail_split_for(key)) ? 1 : 0;
+                        const int rec = f.prof_begin(key, 2.0 * (double)B * H * W * L.cout * L.cin * L.taps);
+                        bool done = false;
+                        for (int rep = f.repeats(key); rep > 0; --rep) done = launch_conv3x3_ps4(q, n.max_groups, f.s);
+                        f.prof_end(rec);
+                        if (!done) return fail(MOE_EINVAL, "fused tail kernel (ps4) rejected layer %s", key.c_str());
+                    }
+                    H *= n.r; W *= n.r;
+                    continue;
+                }
+                if (fuse && st == n.stages - 1) {
+                    tp[br] = (float*)f.ar.take(f.tail_form == 1 ? (size_t)tailsum_layout(B, H, W).total * 4 + 4096 : (size_t)9 * B * H * n.r * W * n.r * 4 + 4096);
+                    const half_t* frag = f.dry() ? nullptr : f.small<half_t>(br == 0 ? "tail_r.frag" : "tail_u.frag");
+                    if (!f.conv(key, cur, Act{}, nullptr, H, W, nullptr, nullptr, frag, f.dry() ? (float*)16 : tp[br]))
+                        return fail(MOE_EINVAL, "fused tail kernel rejected layer %s", key.c_str());
+                    H *= n.r; W *= n.r;
+                    continue;
+                }
+                Act nxt = f.act((long long)B * H * n.r * W * n.r);
+                f.conv(key, cur, nxt, nullptr, H, W);
+                H *= n.r; W *= n.r;
+                f.tap(std::string(br == 0 ? "r" : "u") + ".up" + std::to_string(st), nxt, H, W, 64, 64);
+                cur = nxt;
+            }
+            fin[br] = cur;
+            return (int)MOE_OK;
+        };
+        // Small launch sets (the reference's per-tile loop hands the net 3 planes of <= 256 x 256): a launch of a few planes leaves most CUs idle while its last workgroups
+        // finish (702 ARSB patches over 256 workgroups; 24 four-row blocks per ps4 workgroup, two of them recomputed), and the U branch does not depend on the trunk -- it
+        // forks here onto a second stream behind the stem and joins in front of the branch sum; its workgroups take the CUs the trunk's launches leave.  Same kernels, same
+        // bits (tests); the predicate is a function of the shape alone, so the workspace plan (dry run) allocates in the same order.
+        // (not under FP16X3: its three-launch fallback shares one side buffer between the layers)
+        const bool forked = sr && n.opt.branch_streams && !n.debug && !f.direct && !f.x3 && n.opt.conv_impl == 2 && (long long)B * h * w <= 8ll * 65536;
+        // ... each branch on its own share of the chip: side stream g_side persistent workgroups per launch, the caller's stream the rest (restored at scope exit)
+        struct GroupsGuard { moe_net& n; int all; ~GroupsGuard() { n.max_groups = all; } } groups_guard{n, n.max_groups};
+        int g_side = 0;
+        if (forked && n.max_groups >= 32) {
+            g_side = n.opt.branch_groups > 0 ? n.opt.branch_groups : (n.stages >= 2 ? 5 * n.max_groups / 16 : 3 * n.max_groups / 16);
+            g_side = std::max(8, std::min(g_side, n.max_groups - 8) / 8 * 8);
+        }
+        if (forked) {
+            if (g_side) n.max_groups = g_side;
+            if (!f.dry()) {
+                if (!n.side) {
+                    HIP_TRY(hipStreamCreateWithFlags(&n.side, hipStreamNonBlocking));
+                    HIP_TRY(hipEventCreateWithFlags(&n.ev_fork, hipEventDisableTiming));
+                    HIP_TRY(hipEventCreateWithFlags(&n.ev_join, hipEventDisableTiming));
+                }
+                HIP_TRY(hipEventRecord(n.ev_fork, s));
+                HIP_TRY(hipStreamWaitEvent(n.side, n.ev_fork, 0));      // behind the stem (and everything before it on the caller's stream: the previous forward's reads of the workspace)
+                f.s = n.side;
+            }
+            const int rc = run_branch(1, A);
+            if (g_side) n.max_groups = groups_guard.all - g_side;      // the trunk and the R branch: the other CUs
+            if (!f.dry()) {
+                f.s = s;
+                if (!rc) HIP_TRY(hipEventRecord(n.ev_join, n.side));
+            }
+            if (rc) return rc;
+        }
         if (int rc = trunk_conv("input2", A, Bb, nullptr, mixed)) return rc;
         f.tap("input2", Bb, h, w, 64, n.C);
         // single-pass ARSBs run as ONE kernel (arsb32c.hip: conv_1's output never leaves the CU) that streams cur -> oth;
@@ -1135,68 +1246,11 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         Bb = cur;
         if (n.arch == MOE_ARCH_NETDN) { tail(&Bb, &A, h, w, false); return MOE_OK; }
         if (mixed) { A.lo = nullptr; Bb.lo = nullptr; A.lo8 = Bb.lo8 = false; }      // the upsampler convs take the fp16 parts
-        // two upsampler branches: R on the trunk output, U on the stem output (models.py:117-123)
-        Act fin[2];
-        float* tp[2] = {nullptr, nullptr};
-        const bool fuse = can_fuse_tail(n, f, B, h, w);      // last upsampler conv + 64->1 tail conv in one kernel
-        bool ps4 = false;
-        int H = h, W = w;
-        {   // form of the fused tail's output: phase-class sums when the last stage is a x2 shuffle the register-weight kernel takes
-            int hl = h, wl = w;
-            for (int st = 0; st + 1 < n.stages; ++st) { hl *= n.r; wl *= n.r; }
-            bool ok = fuse && n.opt.tail_form == 1 && n.r == 2 && wl % 4 == 0 && tailsum_fits(B, hl, wl) &&
-                      2ll * B * hl * wl * 64 + 2ll * (wl + 1) * 64 < (1ll << 32) - 65536;
-            bool ps4_ok = true;
-            for (const char* br : {"u", "convt_R1"}) {
-                const auto it = n.conv_index.find(std::string(br) + ".up" + std::to_string(n.stages - 1));
-                ok = ok && it != n.conv_index.end() && n.convs[it->second].slope < 1.f;
-                ps4_ok = ps4_ok && it != n.conv_index.end() && ps4_tail_applicable(B, hl, wl, n.convs[it->second].slope);      // (the launcher's own predicate: common.h)
-            }
-            f.tail_form = ok ? 1 : 0;
-            // the same layer with all four phases in one workgroup (conv3x3_ps4.hip): one fp32 plane + column aprons per branch, added by tailadd
-            ps4 = ok && n.opt.up_impl == 1 && ps4_ok && (2 * wl) % 8 == 0;
-        }
-        float* ps_plane[2] = {nullptr, nullptr};
-        float* ps_apron[2] = {nullptr, nullptr};
-        for (int br = 0; br < 2; ++br) {
-            Act cur = br == 0 ? Bb : A;
-            H = h; W = w;
-            for (int st = 0; st < n.stages; ++st) {
-                const std::string key = std::string(br == 0 ? "convt_R1" : "u") + ".up" + std::to_string(st);
-                if (ps4 && st == n.stages - 1) {
-                    ps_plane[br] = (float*)f.ar.take(ps4_plane_bytes(B, H, W) + 4096);
-                    ps_apron[br] = (float*)f.ar.take(ps4_apron_bytes(B, H, W) + 4096);
-                    if (!f.dry()) {
-                        const ConvLayer& L = n.convs[n.conv_index.at(key)];
-                        Ps4Args q{};
-                        q.in = cur.hi; q.wpk = f.blob<half_t>(L.w_hi); q.bias = L.has_bias ? f.blob<float>(L.bias) : f.small<float>("zero_bias");
-                        q.tail_w = f.small<half_t>(br == 0 ? "tail_r.frag" : "tail_u.frag");
-                        q.plane = ps_plane[br]; q.apron = ps_apron[br]; q.slope = L.slope; q.B = B; q.H = H; q.W = W;
-                        q.split = (f.mixed && f.tail_split_for(key)) ? 1 : 0;
-                        const int rec = f.prof_begin(key, 2.0 * (double)B * H * W * L.cout * L.cin * L.taps);
-                        bool done = false;
-                        for (int rep = f.repeats(key); rep > 0; --rep) done = launch_conv3x3_ps4(q, n.max_groups, s);
-                        f.prof_end(rec);
-                        if (!done) return fail(MOE_EINVAL, "fused tail kernel (ps4) rejected layer %s", key.c_str());
-                    }
-                    H *= n.r; W *= n.r;
-                    continue;
-                }
-                if (fuse && st == n.stages - 1) {
-                    tp[br] = (float*)f.ar.take(f.tail_form == 1 ? (size_t)tailsum_layout(B, H, W).total * 4 + 4096 : (size_t)9 * B * H * n.r * W * n.r * 4 + 4096);
-                    const half_t* frag = f.dry() ? nullptr : f.small<half_t>(br == 0 ? "tail_r.frag" : "tail_u.frag");
-                    if (!f.conv(key, cur, Act{}, nullptr, H, W, nullptr, nullptr, frag, f.dry() ? (float*)16 : tp[br]))
-                        return fail(MOE_EINVAL, "fused tail kernel rejected layer %s", key.c_str());
-                    H *= n.r; W *= n.r;
-                    continue;
-                }
-                Act nxt = f.act((long long)B * H * n.r * W * n.r);
-                f.conv(key, cur, nxt, nullptr, H, W);
-                H *= n.r; W *= n.r;
-                f.tap(std::string(br == 0 ? "r" : "u") + ".up" + std::to_string(st), nxt, H, W, 64, 64);
-                cur = nxt;
-            }
-            fin[br] = cur;
+        if (!forked) { if (int rc = run_branch(0, Bb)) return rc; if (int rc = run_branch(1, A)) return rc; }
+        else {
+            if (int rc = run_branch(0, Bb)) return rc;
+            if (!f.dry()) HIP_TRY(hipStreamWaitEvent(s, n.ev_join, 0));      // the branch sum below reads both branches
+            n.max_groups = groups_guard.all;
         }
         if (ps4) {
             if (!f.dry()) {
@@ -1623,6 +1677,9 @@ void moe_net_destroy(moe_net* n)
     if (n->ws) (void)hipFree(n->ws);
     for (auto& t : n->taps) if (t.second.dev) (void)hipFree(t.second.dev);
     for (auto& ev : n->prof_ev) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); }
+    if (n->side) (void)hipStreamDestroy(n->side);
+    if (n->ev_fork) (void)hipEventDestroy(n->ev_fork);
+    if (n->ev_join) (void)hipEventDestroy(n->ev_join);
     for (auto& sl : n->off_ring) {
         if (sl.host) (void)hipHostFree(sl.host);
         if (sl.dev) (void)hipFree(sl.dev);

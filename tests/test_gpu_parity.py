@@ -1204,6 +1204,34 @@ def test_one_launch_arsb_does_not_depend_on_how_its_ranges_are_cut(dev):
             m.set_option('max_groups', 0)
 
 
+def test_small_launch_sets_fork_the_u_branch_onto_a_second_stream(dev):
+    """Option branch_streams (round 5, default on): a forward of a few planes (the reference's own per-tile loop: 3 planes of <= 256 x 256) runs its U branch on a second
+    HIP stream beside the trunk + R branch, forked behind the stem and joined in front of the branch sum.  Same kernels: the result must be the single-stream result bit
+    for bit -- on every SR family, fp16 and fp32 I/O, back to back with changing inputs (a missing fork / join edge shows up as one forward reading the other's buffers),
+    on the caller's non-default stream, and through the reference-style loop."""
+    side = torch.cuda.Stream()
+    for key, prec in (('a2', 'auto'), ('a3', 'auto'), ('a4', 'auto'), ('a4', 'fp16')):
+        m = module_for(key, prec)
+        try:
+            xs = [torch.from_numpy(gd.noise_image(40 + i, sh)[:, None]).to(dev) for i, sh in enumerate(((3, 64, 96), (3, 40, 72), (4, 88, 61), (3, 64, 96), (1, 8, 16), (3, 128, 128)))]
+            m.set_option('branch_streams', 0)
+            want = [m(x)[-1].clone() for x in xs]
+            m.set_option('branch_streams', 1)
+            for rep in range(3):
+                got = [m(x)[-1] for x in xs]                  # enqueued back to back, nothing synchronises in between
+                for i, (g, w) in enumerate(zip(got, want)):
+                    assert torch.equal(g, w), (key, prec, rep, i, float((g - w).abs().max()))
+            with torch.cuda.stream(side):
+                side.wait_stream(torch.cuda.current_stream())
+                got = [m(x.half())[-1] for x in xs]
+            side.synchronize()
+            m.set_option('branch_streams', 0)
+            for i, (g, x) in enumerate(zip(got, xs)):
+                assert torch.equal(g, m(x.half())[-1]), (key, prec, 'side stream', i)
+        finally:
+            m.set_option('branch_streams', 1)
+
+
 def test_wire_pack_unpack_kernels_vs_numpy_codec(dev):
     """moe_wire_pack / moe_wire_unpack (the 'f16s' wire format of dist.py: fp16 image + fp32 seam rows + fp32 seam columns per tile, strips as plain fp32)
     against tests/wire_codec.py, bit for bit, on the real seams of a plan plus synthetic records (odd sizes, empty ranges, one-range seams, a strip), and the

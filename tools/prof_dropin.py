@@ -29,7 +29,10 @@ config.deviceId, config.fp16, config.crop_sr = 0, True, 256
 wpath = '/tmp/moe_prof_dropin_a4.pth'
 save_state_dict_file(gd.synth_state_dict('a4', load_state_dict_file), wpath)
 runSR.mode_switch['a4'] = (wpath, runSR.mode_switch['a4'][1])
-opt = runSR.getOpt({'op': 'SR', 'model': 'a', 'scale': 4, 'ensemble': 0})
+SCALE = int(os.environ.get('DROPIN_SCALE', '4'))      # 4: a4 (synthetic weights); 2 / 3: a2 / a3 from the zoo fixtures
+if SCALE != 4:
+    config.modelRoot = gd.ZOO
+opt = runSR.getOpt({'op': 'SR', 'model': 'a', 'scale': SCALE, 'ensemble': 0})
 x = torch.from_numpy(gd.natural_image(1000, bench.FRAME)).to(dev).half()
 plan = ip._plan_for(opt, x.shape)
 ramp = torch.from_numpy(plan.ramp.copy()).to(dev).half()
