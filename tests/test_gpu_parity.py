@@ -712,6 +712,15 @@ def test_rccl_path_world1(dev):
         assert sorted(out) == [0, 1, 2]
         for f, y in out.items():
             assert torch.equal(y, ip.doCrop(opt, frames[f])), f
+        # ... and they really run BESIDE the next group's convolutions (RCCL refuses two ranks on one device -- test_dist_two_ranks_on_one_gpu_over_rccl
+        # records the refusal -- so one rank is where this can be observed): with frames large enough that a group computes for milliseconds, the host sees every group's
+        # exchange complete while an event behind the NEXT group's kernels is still pending
+        big = [torch.from_numpy(gd.natural_image(95 + f, (3, 600, 800))).to(dev).half() for f in range(4)]
+        probe = []
+        out = mdist.run_frames_overlapped(opt, big, out_dtype=torch.float16, probe=probe)
+        torch.cuda.synchronize()
+        assert len(probe) == 3 and all(p['exchange_done_while_computing'] for p in probe), probe
+        assert torch.equal(out[2], ip.doCrop(opt, big[2]))
     finally:
         mdist.FORCE_COLLECTIVE = False
         dist.destroy_process_group()
