@@ -975,6 +975,12 @@ long long sp_bytes_per_pixel(const moe_net& n)
 {
     long long per = 128;
     if (n.arch == MOE_ARCH_SEDN) per = 512;
+    if (n.arch == MOE_ARCH_LITE) {
+        // lite: stage k stores 128 B * 4^(k+1) per input pixel, the LAST stage (fused with the 48 -> 1 tail) stores two fp32 partial planes per branch instead -- so the largest
+        // tensor a 32-bit-offset kernel (conv1x1.hip) touches is the last stage's INPUT: 128 B * 4^(stages-1).  (Round 5's kernel census found lite8's x4 -> x8 stage on the
+        // generic 64-bit kernel at 27 ms a launch: 96 planes of 1024 x 1024 x 128 B overflow the offsets and nothing split the launch set.)
+        for (int st = 0; st + 1 < n.stages; ++st) per *= 4;
+    }
     if (n.arch == MOE_ARCH_NET2X || n.arch == MOE_ARCH_NET3X || n.arch == MOE_ARCH_NET4X) {
         long long rr = 1;
         for (int st = 0; st < n.stages; ++st) {
