@@ -108,7 +108,7 @@ int moe_net_resolved_precision(const moe_net* net, int precision);
  * python/imageProcess.py:319-334; its own dtype policy is castModel, :309-317).  Net2x/3x/4x and NetDN under MOE_PREC_MIXED run their first `blocks` ARSBs with
  * split operands; how many a checkpoint needs depends on how wide its trunk swings.  moe_net_calibrate measures it on the device: uniform uint8-noise tiles (2 x 3
  * planes of 192 x 192) through the exact arithmetic (FP16X3) and through MIXED with blocks = the architecture's default .. 6; *blocks = the smallest count whose
- * worst max-abs difference is <= target (target <= 0: 8.5e-4), *err = that difference; *blocks = -1 when six blocks do not reach it (*err = what they reach).
+ * worst max-abs difference is <= target (target <= 0: 7.5e-4), *err = that difference; *blocks = -1 when six blocks do not reach it (*err = what they reach).
  * The count is kept (moe_net_exact_blocks) until a parameter changes or moe_net_set_exact_blocks overrides it.  moe_net_finalize(MOE_PREC_AUTO) runs this by itself,
  * once per checkpoint, and finalizes in MOE_PREC_FP16X3 when no count reaches the target: a drop-in caller needs no extra line.  SEDN / lite: *blocks = 0, nothing
  * is measured (their AUTO arithmetic has no such knob).  Synchronises `stream`; ~0.1-0.3 s. */

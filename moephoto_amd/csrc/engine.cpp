@@ -1503,8 +1503,10 @@ int forward_dev_chunk(moe_net& n, const void* x, int x_dtype, int B, int h, int 
 // measured when it is loaded: two uniform uint8-noise tiles of 3 x 192 x 192 (the input class that spends the most: SURVEY.md appendix) go through the exact mode
 // (FP16X3: pinned to the fp32 oracle at 2e-5 by the tests) and through MIXED with n = default .. 6 blocks; the smallest n whose worst max-abs difference is within
 // `target` is kept, and when not even six blocks reach it the net runs in FP16X3.  ~0.1-0.3 s once per checkpoint and device.
-constexpr double kCalibTarget = 8.5e-4;       // leaves 1.5e-4 of the 1e-3 contract to tile-to-tile spread (all-tile sweeps: the worst tile of a 1080p noise frame is
-                                              // within 0.5e-4 of its median) and to the exact mode's own 2e-5
+constexpr double kCalibTarget = 7.5e-4;       // 2.5e-4 of the 1e-3 contract stay in hand: the worst tile of an all-tile sweep over 1080p noise frames lies ~1e-4 above these two
+                                              // calibration tiles (a4: 6.7e-4 here, 7.5-7.8e-4 there; profiles/r04/fullsize_report.json), the exact mode itself is pinned to the
+                                              // oracle at 2e-5.  Every zoo key keeps its architecture's default at this target (profiles/r05/a_calibration_report.txt: a4 6.7e-4,
+                                              // a2 5.6e-4, p2 7.1e-4, a3 4.5e-4, dn_lite5 7.4e-4, dn_lite10 / 15 4.0 / 3.4e-4)
 
 bool calibratable(const moe_net& n) { return n.arch == MOE_ARCH_NET2X || n.arch == MOE_ARCH_NET3X || n.arch == MOE_ARCH_NET4X || n.arch == MOE_ARCH_NETDN; }
 

@@ -178,7 +178,7 @@ class EngineModule(object):
     def calibrate(self, target=0.0):
         """Measure the number of split-operand ARSBs THESE weights need (moe_net_calibrate: uint8-noise tiles through the exact mode and through 'mixed' with
         n = default .. 6 blocks, on the device) and keep it.  Returns (n, worst error at n); n = -1 when six blocks do not reach `target` (<= 0: the library's
-        8.5e-4).  `.to(device)` with precision 'auto' already does this once per checkpoint (moe_net_finalize(MOE_PREC_AUTO)); this is the explicit call, e.g. with
+        7.5e-4).  `.to(device)` with precision 'auto' already does this once per checkpoint (moe_net_finalize(MOE_PREC_AUTO)); this is the explicit call, e.g. with
         another target.  None for families without the knob (SEDN, lite) or when the module runs in another arithmetic."""
         if self._device is None:
             raise _lib.EngineError('calibrate: move the module to its device first')

@@ -1149,7 +1149,7 @@ def test_calibrate_exact_blocks_for_other_weights(dev):
     m = build(1.0)
     assert m.exact_blocks() == 4 and m.resolved_precision() == 'mixed'
     n, err = m.calibrate()
-    assert n == 4 and err <= 8.5e-4, (n, err)
+    assert n == 4 and err <= 7.5e-4, (n, err)
     m = build(1.15)
     na = m.exact_blocks()
     assert na > 4 or m.resolved_precision() == 'fp16x3', na
