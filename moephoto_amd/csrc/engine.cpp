@@ -1143,7 +1143,9 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         // forks here onto a second stream behind the stem and joins in front of the branch sum; its workgroups take the CUs the trunk's launches leave.  Same kernels, same
         // bits (tests); the predicate is a function of the shape alone, so the workspace plan (dry run) allocates in the same order.
         // (not under FP16X3: its three-launch fallback shares one side buffer between the layers)
-        const bool forked = sr && n.opt.branch_streams && !n.debug && !f.direct && !f.x3 && n.opt.conv_impl == 2 && (long long)B * h * w <= 8ll * 65536;
+        const bool forked = sr && n.opt.branch_streams && !n.debug && !f.direct && !f.x3 && n.opt.conv_impl == 2 && (long long)B * h * w <= 4ll * 65536;      // (up to four planes of 256 x 256: the per-tile call
+                                                                                                                                          // with or without alpha; a ragged group of 21 planes of 88 x 256 inside a
+                                                                                                                                          // batched frame is NOT small: forked, the headline frame lost 0.5 ms)
         // ... each branch on its own share of the chip: side stream g_side persistent workgroups per launch, the caller's stream the rest (restored at scope exit)
         struct GroupsGuard { moe_net& n; int all; ~GroupsGuard() { n.max_groups = all; } } groups_guard{n, n.max_groups};
         int g_side = 0;
