@@ -299,6 +299,7 @@ struct SednFuseArgs {
     const half_t* x;          // [B][H][W][64] input of rblock.4
     float* partial;           // [B][nslab][5][64]: total, first row, last row, first column, last column sums
     const float* pooled; int pooled_slabs;   // optional: the totals, already formed by the producing conv ([B][pooled_slabs][64]); sedn_xsum then only visits the border pixels
+    int pooled_count;                        // ... of which the first pooled_count slabs of every plane are written by that conv (all of them, every launch: no memset)
     int nslab, B, H, W;
     const float* w256t;       // [576][256] fp32, k = tap*64 + ci   (rblock.4 weights, transposed)
     const float* w256;        // [256][576]

@@ -192,18 +192,23 @@ __global__ __launch_bounds__(256) void conv3x3_rw_kernel(ConvArgs a)
     const int G = a.G;
     if (g >= G) return;
     const int nitems = a.B * a.py * a.px;
-    const int K = (nitems - g + G - 1) / G;
+    // EPI 4 (pooled sums): the work items are PATCH ROWS -- workgroup g walks the patches of row g, g + G, ... of the (plane, patch row) sequence from left to right -- so that
+    // the plane changes once per row instead of once per patch: the flush of the per-lane sums (16 values x five cross-lane steps + the slab stores) ran after EVERY patch
+    // with the strided patch order below (one patch per plane and workgroup at 256 patches a plane: 158 against 121 us for SEDN's rblock.2, round 5).  A slab still holds
+    // a fixed set of patches summed in a fixed order whatever the launch's plane count (the engine picks G as a multiple or divisor of the rows per plane: pooled_groups).
+    const int nrows = a.B * a.py;
+    const int K = POOL ? ((nrows - g + G - 1) / G) * a.px : (nitems - g + G - 1) / G;
     if (K <= 0) return;
-    const int Gx = G % a.px, Gy = (G / a.px) % a.py, Gb = G / (a.px * a.py);
+    const int Gx = POOL ? 1 : G % a.px, Gy = POOL ? G % a.py : (G / a.px) % a.py, Gb = POOL ? G / a.py : G / (a.px * a.py);
     auto advance = [&](const Item& it) {
         Item n;
         int x = it.pxi + Gx;
         const int cx = x >= a.px;
         x -= cx ? a.px : 0;
-        int y = it.pyi + Gy + cx;
+        int y = it.pyi + (POOL ? (cx ? Gy : 0) : Gy + cx);
         const int cy = y >= a.py;
         y -= cy ? a.py : 0;
-        n.pxi = x; n.pyi = y; n.b = it.b + Gb + cy;
+        n.pxi = x; n.pyi = y; n.b = it.b + (POOL ? (cx ? Gb : 0) : Gb) + cy;
         return n;
     };
 
@@ -423,7 +428,9 @@ __global__ __launch_bounds__(256) void conv3x3_rw_kernel(ConvArgs a)
                 psum[e] = t;
             }
             if (j == 0) {
-                float* dst = a.pool + ((long long)pool_b * a.pool_slabs + 2 * g + h) * 64 + 32 * c + 8 * hh;
+                // slab = the plane-relative patch row(s) this workgroup sums, g % py: the same place in every plane whatever the launch's plane count, so that the consumer's
+                // fixed-order sum over the slabs associates the same way (G is a multiple or a divisor of py: pooled_groups)
+                float* dst = a.pool + ((long long)pool_b * a.pool_slabs + 2 * (g % a.py) + h) * 64 + 32 * c + 8 * hh;
 #pragma unroll
                 for (int gp = 0; gp < 2; ++gp) {
                     *(float4_t*)(dst + 16 * gp) = float4_t{psum[8 * gp], psum[8 * gp + 1], psum[8 * gp + 2], psum[8 * gp + 3]};
@@ -522,8 +529,8 @@ __global__ __launch_bounds__(256) void conv3x3_rw_kernel(ConvArgs a)
     // ===== prologue ====================================================================================================================
     Item it_cur{0, 0, 0};
     {
-        it_cur.pxi = g % a.px;
-        const int t = g / a.px;
+        it_cur.pxi = POOL ? 0 : g % a.px;
+        const int t = POOL ? g : g / a.px;
         it_cur.pyi = t % a.py;
         it_cur.b = t / a.py;
     }
@@ -800,7 +807,7 @@ bool launch_conv3x3_rw(const ConvArgs& a, hipStream_t s)
     if (2ll * a.B * a.H * a.W * a.in_cs + 2ll * (a.W + 1) * a.in_cs >= (1ll << 32) - 65536) return false;
     if (!tail && 2ll * a.B * a.H * a.r * a.W * a.r * a.out_cs >= (1ll << 32) - 65536) return false;
     const int blocks = a.nchunks * ((a.G + 7) / 8) * 8;
-    if (a.pool && (tail || a.nchunks != 1 || a.r != 1 || a.pool_slabs < 2 * a.G)) return false;
+    if (a.pool && (tail || a.nchunks != 1 || a.r != 1 || a.pool_slabs < 2 * std::min(a.G, a.py) || (a.G % a.py != 0 && a.py % a.G != 0))) return false;
     const bool ragged = a.H % kTileH != 0 || a.W % kTileW != 0;
     if (tail && a.tail_split) {
         if (ragged) conv3x3_rw_kernel<7, true><<<dim3(blocks), dim3(256), LDS_BYTES, s>>>(a);

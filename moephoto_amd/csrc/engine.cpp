@@ -783,9 +783,9 @@ struct Fwd {
         a.tail_w = tail_w; a.tplanes = tplanes; a.tail_form = tplanes ? tail_form : 0;
         a.tail_split = (tplanes && mixed && tail_split_for(key)) ? 1 : 0;
         a.tail1_w = tail1_w; a.tail1_out = tail1_out;
-        if (pool_out && !x3 && L.r == 1 && L.nchunks == 1 && !res && pooled_groups_ok((long long)a.px * a.py, items, n.max_groups)) {      // conv3x3_rw's pooled epilogue (SEDN rblock.2)
+        if (pool_out && !x3 && L.r == 1 && L.nchunks == 1 && !res && pooled_groups_ok((long long)a.py, (long long)B * a.py, n.max_groups)) {      // conv3x3_rw's pooled epilogue (SEDN rblock.2)
             a.pool = pool_out; a.pool_slabs = pool_slabs;
-            a.G = pooled_groups((long long)a.px * a.py, items, n.max_groups);      // slab contents independent of the launch's plane count (common.h)
+            a.G = pooled_groups((long long)a.py, (long long)B * a.py, n.max_groups);      // its work items are patch ROWS (conv3x3_rw.hip, EPI 4): slab contents independent of the launch's plane count (common.h)
         }
         // 3x3 / 64-input-channel layers with shared weights run on the software-pipelined kernel (conv3x3_sp.hip); everything else
         // (1x1 convs, SEDN's per-plane `trans`, epilogues that kernel does not compile, MOE_CONV_IMPL=v1) on the generic one
@@ -1309,17 +1309,18 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
             const std::string k = "b" + std::to_string(b);
             f.conv(k + ".rb0", A, Cc, nullptr, h, w);
             f.pool_done = false;
-            if (sfuse && spool && !f.dry()) {
-                (void)hipMemsetAsync(xpool, 0, (size_t)B * pslabs * 64 * 4, s);
-                f.pool_out = xpool; f.pool_slabs = pslabs;
-            }
+            if (sfuse && spool && !f.dry()) { f.pool_out = xpool; f.pool_slabs = pslabs; }      // (the conv writes the first 2 min(G, py) slabs of every plane, all of them: no memset)
             f.conv(k + ".rb2", Cc, Dd, nullptr, h, w);
             f.pool_out = nullptr;
             if (sfuse) {
                 if (!f.dry()) {
                     SednFuseArgs fa{};
                     fa.x = Dd.hi; fa.partial = xpart; fa.nslab = nslab; fa.B = B; fa.H = h; fa.W = w;
-                    if (f.pool_done) { fa.pooled = xpool; fa.pooled_slabs = pslabs; }
+                    if (f.pool_done) {
+                        const int py = (h + kTileH - 1) / kTileH;
+                        fa.pooled = xpool; fa.pooled_slabs = pslabs;
+                        fa.pooled_count = 2 * std::min(pooled_groups((long long)py, (long long)B * py, n.max_groups), py);      // conv3x3_rw EPI 4: slab 2 (g % py) + wave half
+                    }
                     fa.w256t = f.small<float>(k + ".w256t"); fa.w256 = f.small<float>(k + ".w256"); fa.wt = f.small<float>(k + ".wt");
                     fa.w_down = f.small<float>(k + ".down"); fa.w_up = f.small<float>(k + ".up");
                     fa.gate = fgate; fa.weff = weff;

@@ -626,7 +626,7 @@ __global__ __launch_bounds__(256) void sedn_fmean_kernel(SednFuseArgs a)
         float4_t v = {0.f, 0.f, 0.f, 0.f};
         const float4_t* src = (const float4_t*)(a.pooled + (long long)b * a.pooled_slabs * 64) + c4;
 #pragma unroll 8
-        for (int k = cls; k < a.pooled_slabs; k += 16) v = v + src[(long long)k * 16];
+        for (int k = cls; k < a.pooled_count; k += 16) v = v + src[(long long)k * 16];
         pred[cls][c4] = v;
         __syncthreads();
         if (t < 64) {
@@ -677,15 +677,15 @@ __global__ __launch_bounds__(256) void sedn_fmean_kernel(SednFuseArgs a)
     if (t < 64) a.gate[b * 256 + blockIdx.y * 64 + t] = ((red[0][t] + red[1][t]) + (red[2][t] + red[3][t])) / (float)HW;   // (the MEAN; the gate is formed in sedn_weff)
 }
 
-// W_eff[b][co][k] = sum_m (W_t[co][m] g[b][m]) W_256[m][k]: 64 x 576 x 256 per plane.  Block = 32 co x 64 k (one tap, half of
-// the output channels), 2 x 4 per thread; grid 9 x B x 2.
+// W_eff[b][co][k] = sum_m (W_t[co][m] g[b][m]) W_256[m][k]: 64 x 576 x 256 per plane.  Block = all 64 co x 64 k (one tap), 4 x 4 per thread: two 16-byte LDS reads per
+// 16 FMAs (round 4: 32 co x 64 k, 2 x 4 per thread, 24 bytes per 8 FMAs -- LDS-bound at 36 us a launch); grid 9 x B.
 __global__ __launch_bounds__(256) void sedn_weff_kernel(SednFuseArgs a)
 {
     constexpr int MC = 64;               // m per stage
-    __shared__ float As[MC][33];         // [m][co]
+    __shared__ __attribute__((aligned(16))) float As[MC][68];         // [m][co] (+4: rows stay 16-byte aligned, the transposing stores spread over the banks)
     __shared__ __attribute__((aligned(16))) float Bs[MC][64];         // [m][k]
     __shared__ float mean[256], part[256], hid[16], gate[256];
-    const int tap = blockIdx.x, b = blockIdx.y, co0 = blockIdx.z * 32;
+    const int tap = blockIdx.x, b = blockIdx.y;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     {   // squeeze-excite gate of this plane from its channel means (16 KFLOP: every block redoes it rather than wait for a launch)
         const int t = threadIdx.x;
@@ -712,32 +712,33 @@ __global__ __launch_bounds__(256) void sedn_weff_kernel(SednFuseArgs a)
         gate[t] = 1.f / (1.f + __expf(-u));
         __syncthreads();
     }
-    float acc[2][4] = {};
+    float acc[4][4] = {};
     for (int m0 = 0; m0 < 256; m0 += MC) {
-        for (int i = threadIdx.x; i < MC * 32; i += 256) {
+        for (int i = threadIdx.x; i < MC * 64; i += 256) {
             const int m = i % MC, co = i / MC;
-            As[m][co] = a.wt[(co0 + co) * 256 + m0 + m] * gate[m0 + m];
+            As[m][co] = a.wt[co * 256 + m0 + m] * gate[m0 + m];
         }
         for (int i = threadIdx.x; i < MC * 16; i += 256) {      // 16-byte loads: 16 per row of 64 k
             const int kq = i & 15, m = i >> 4;
             *(float4*)&Bs[m][kq * 4] = *(const float4*)(a.w256 + (long long)(m0 + m) * 576 + tap * 64 + kq * 4);
         }
         __syncthreads();
-#pragma unroll 16
-        for (int m = 0; m < MC; ++m) {
+#pragma unroll 8
+        for (int m = 0; m < MC; ++m) {      // (m ascending, one accumulator per output: the summation order of round 4's kernel -- the same bits)
             const float4 bv = *(const float4*)&Bs[m][tx * 4];
-            const float a0 = As[m][ty * 2], a1 = As[m][ty * 2 + 1];
-            acc[0][0] += a0 * bv.x; acc[0][1] += a0 * bv.y; acc[0][2] += a0 * bv.z; acc[0][3] += a0 * bv.w;
-            acc[1][0] += a1 * bv.x; acc[1][1] += a1 * bv.y; acc[1][2] += a1 * bv.z; acc[1][3] += a1 * bv.w;
+            const float4 av = *(const float4*)&As[m][ty * 4];
+            const float aa[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { acc[i][0] += aa[i] * bv.x; acc[i][1] += aa[i] * bv.y; acc[i][2] += aa[i] * bv.z; acc[i][3] += aa[i] * bv.w; }
         }
         __syncthreads();
     }
     // fragment f = (tap*4 + ks)*2 + nblk, lane l = 32*(ci%16/8) + co%32, element e = ci%8   (pack_conv's order)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int co = co0 + ty * 2 + i, ci = tx * 4 + j;
+            const int co = ty * 4 + i, ci = tx * 4 + j;
             const int f = (tap * 4 + (ci >> 4)) * 2 + (co >> 5), l = (((ci >> 3) & 1) << 5) + (co & 31), e = ci & 7;
             a.weff[(((long long)b * 72 + f) * 64 + l) * 8 + e] = (half_t)acc[i][j];
         }
@@ -1124,7 +1125,7 @@ void launch_sedn_fuse(const SednFuseArgs& a, hipStream_t s)
 {
     hipLaunchKernelGGL(sedn_xsum_kernel, dim3(a.nslab, a.B), dim3(256), 0, s, a);
     hipLaunchKernelGGL(sedn_fmean_kernel, dim3(a.B, kMeanSplit), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(sedn_weff_kernel, dim3(9, a.B, 2), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(sedn_weff_kernel, dim3(9, a.B), dim3(256), 0, s, a);
 }
 
 void launch_frm(const FrmArgs& a, hipStream_t s)
