@@ -10,7 +10,8 @@
 A step = one pass of the hot path (doCrop: tile gather -> Net4x on the MFMA kernels -> stitch) over one batch
 of N frames that are already resident in HBM.  N = 1: one frame.  N > 1: the N frames' tiles are sharded
 round-robin over the ranks, exchanged with one RCCL all-to-all, and rank f % N stitches frame f (weak scaling:
-every rank computes 40 tiles and stitches one frame per step).  `value` = input megapixels of all frames / s,
+every rank computes 40 tiles and stitches one frame per step); --strong: ONE frame per step, its 40 tiles over the
+N ranks, every rank folding its row band of the canvas ("scaling": "strong").  `value` = input megapixels of all frames / s,
 from EXACTLY --steps steps bracketed by barrier + synchronize, max over ranks.
 
 Arithmetic: the product default ('auto' -> 'mixed' for Net4x: fp16 MFMA operands, fp32 accumulate, hi+lo trunk stream,
@@ -27,13 +28,20 @@ Extra objects on the JSON line:
                     epilogues -- and the one-launch ARSBs).  `achieved` / `frac` use ALGORITHMIC FLOPs (the frame's pixels,
                     no tile overlap); `achieved_executed` / `frac_executed` count the overlapping tile pixels the kernels really compute.
                     `peak` = compute units x 4 SIMDs x 1024 FLOP/clk x max engine clock, all read from the device (moe_device_info).
-                    `traffic` = HBM bytes per launch from the committed PMC passes of THIS command's launch shapes (profiles/pmc_bench.json).
+                    `traffic` = HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE) from rocprofv3 --pmc passes over a 2-frame child of THIS run on
+                    THIS box (`traffic_source: "this run"`: three counter-only passes, ~45 s) when rocprofv3 is present, else from the committed,
+                    digest-gated profiles/pmc_bench.json (`"committed"`); --no-pmc skips the child.
   roofline_kernels  every bracketed group, dominant first
+  roofline_split_operand   the split-operand layers (conv_input2 + ARSB 1: conv64_sq / arsb_sq), bound "mfma": fp16-equivalent EXECUTED product-times over the
+                    fp16 MFMA peak (round 4 labelled them "hbm": they stopped being held by bytes when conv_1's rows stayed in LDS); `hbm_side` keeps the bytes view
+  configs           BASELINE's configs 3, 4, 5 -- one timed step each of `python bench.py --config N`, run as children of this command so that the
+                    driver's default run times them: ms_per_step, value, parity_max_abs_vs_oracle, roofline (--no-configs skips them)
   clock             shader clock / package power sampled with rocm-smi during the sustained leg (the part is power-capped), and
                     `frac_at_clock` = roofline.frac rescaled to the peak at the sampled clock
   sustained         a >= --sustain second leg after the timed steps
   dropin_loop       the reference's own per-tile loop (python/imageProcess.py:157-172: slice view -> model(x) -> torch blends ->
-                    slice assign) around the drop-in module, i.e. what a maintainer gets by swapping the class in runSR.mode_switch only
+                    slice assign) around the drop-in module, i.e. what a maintainer gets by swapping the class in runSR.mode_switch only;
+                    `breakdown` (the 40 forwards alone / the torch blends alone) and `with_moe_blend_tile` (the two blend calls + the assign as one kernel)
   cpu_baseline      the oracle (a port of the reference's PyTorch-CPU fp32 path, proven equal to it on the goldens) timed on
                     this host with one socket's physical cores on a full tile row (8 tiles) + the ragged corner of the same
                     frame, and on BASELINE config 1 (256x256, a2) in full; rank 0 only.

@@ -51,6 +51,18 @@ def test_headline_line_follows_the_contract():
     assert cb['kind'] in ('reference', 'port') and cb['unit'] == r['unit'] and cb['cores'] >= 1
     par = r['config'].get('parity_max_abs_vs_oracle')
     assert par is not None and par <= r['config']['parity_tolerance'] == 1e-3 and r['config']['parity_ok'] is True
+    # round 5: the other BASELINE configs ride on the default command's line (children of it), the split-operand layers are an MFMA object, the drop-in loop is taken apart
+    if 'configs' in r:
+        for c in (3, 4, 5):
+            e = r['configs']['config%d' % c]
+            assert 'error' not in e, e
+            assert e['ms_per_step'] > 0 and e['value'] > 0 and e['parity_ok'] is True and e['parity_max_abs_vs_oracle'] <= 1e-3
+            assert 'configs[%d]' % (c - 1) in e['workload']
+        so = r['roofline_split_operand']
+        assert so['bound'] == 'mfma' and so['unit'] == 'TFLOP/s' and abs(so['frac'] - so['achieved'] / so['peak']) < 1e-3
+        assert rf.get('traffic_source') in (None, 'this run', 'committed')
+        d = r['dropin_loop']
+        assert d['breakdown']['engine_forwards_only_ms'] > 0 and d['with_moe_blend_tile']['ms_per_step'] <= d['ms_per_step'] * 1.02
 
 
 @pytest.mark.parametrize('cfg', [3, 4, 5])
