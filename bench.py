@@ -654,7 +654,7 @@ def _other_configs(args):
             cmd = [sys.executable, os.path.abspath(__file__), '--config', str(cfg), '--steps', '1', '--warmup', '1']
             if args.no_cpu_baseline:
                 cmd.append('--no-cpu-baseline')
-            p = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=150)      # (12-14 s when healthy)
             line = next((l for l in reversed(p.stdout.strip().splitlines()) if l.startswith('{')), None)
             if p.returncode != 0 or line is None:
                 out['config%d' % cfg] = {'error': 'rc {}: {}'.format(p.returncode, (p.stderr or p.stdout)[-300:]), 'parity_ok': False if 'parity gate failed' in (p.stderr or '') else None}
@@ -695,7 +695,7 @@ def _pmc_live():
         for name, counters in (('fetch', ['FETCH_SIZE']), ('grbm', ['WRITE_SIZE', 'GRBM_GUI_ACTIVE']),
                                ('sq', ['SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_INSTS_MFMA', 'SQ_LDS_BANK_CONFLICT'])):
             cmd = [exe, '--pmc'] + counters + ['--kernel-include-regex', regex, '-d', os.path.join(out, 'pmc_' + name), '-o', 'pmc', '-f', 'csv', '--'] + child
-            p = subprocess.run(cmd, capture_output=True, text=True, timeout=150, env=env, cwd='/tmp')
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=90, env=env, cwd='/tmp')      # (~15 s a pass when healthy)
             if p.returncode != 0:
                 return None
         p = subprocess.run([sys.executable, collect, out, str(steps + warm)], capture_output=True, text=True, timeout=60)
