@@ -1805,7 +1805,7 @@ int moe_net_calibrate(moe_net* n, double target, int* blocks, double* err, void*
     if (!calibratable(*n)) { if (blocks) *blocks = 0; if (err) *err = 0.0; return MOE_OK; }      // SEDN / lite: no such knob (their AUTO arithmetic has no split-block count)
     if (n->precision != MOE_PREC_MIXED && n->precision != MOE_PREC_FP16X3) return fail(MOE_ESTATE, "moe_net_calibrate: finalize with MOE_PREC_AUTO or MOE_PREC_MIXED first");
     const int rc = calibrate_blocks(*n, target, (hipStream_t)stream);
-    if (rc) return rc;
+    if (rc) { n->finalized = false; return rc; }      // (a failure half-way may have left the other arithmetic's weights on the device: finalize again)
     if (blocks) *blocks = n->calib_blocks;
     if (err) *err = n->calib_err;
     return MOE_OK;

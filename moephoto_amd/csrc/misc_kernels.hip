@@ -17,9 +17,10 @@ __device__ __forceinline__ float ld1(const void* p, long long i) { return (float
 // ---------------------------------------------------------------------------------------------------
 // Stem: PReLU(conv 1->64) (models.py:112,117 conv_input+relu; SEDN :219,223; lite 1x1 MoeNet_lite2.py:28,40).
 // fp32 weights and arithmetic (the stem's weights are the single most sensitive ones to fp16 rounding).
-// One thread = 8 channels x 4 consecutive pixels of a row: its 72 weights sit in registers, the 3 x 6 input window is loaded
-// once (18 loads for 288 FMAs), and it issues four 16-byte stores; 8 consecutive threads (the 8 channel groups of the same
-// pixels) write whole 128-B lines.  The kernel is VALU-bound otherwise (one pixel per thread: ~200 instructions for 72 FMAs).
+// One thread = 8 channels x PX consecutive pixels of a row: its 72 weights sit in registers, the 3 x (PX + 2) input window is loaded
+// once, and it issues PX 16-byte stores; 8 consecutive threads (the 8 channel groups of the same pixels) write whole 128-B lines.
+// The kernel is VALU-bound otherwise (one pixel per thread: ~200 instructions for 72 FMAs).  PX = 8 since round 5 (4 before: 18 LDS
+// reads of weights + 18 input loads per 4 pixels -- the launch ran at 2.6 TB/s of stores); per pixel the same taps in the same order.
 // ---------------------------------------------------------------------------------------------------
 template <typename TIN, int TAPS>
 __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
@@ -29,7 +30,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
     __syncthreads();
     // fp8 low parts: MODE.FP16_OVFL makes the conversion saturate (+-448) instead of producing NaN (conv64_q8.hip runs the same way)
     if (a.out_lo8) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1\n\ts_nop 3" ::: "memory");
-    constexpr int PX = 4;
+    constexpr int PX = 8;
     const int nq = (a.W + PX - 1) / PX;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long q = idx >> 3;                        // (b, y, x-quad)
@@ -1069,7 +1070,7 @@ __global__ void nhwc_to_nchw_kernel(const half_t* in, const half_t* in_lo, float
 
 void launch_stem(const StemArgs& a, hipStream_t s)
 {
-    const long long n = (long long)a.B * a.H * ((a.W + 3) / 4) * 8;
+    const long long n = (long long)a.B * a.H * ((a.W + 7) / 8) * 8;      // (b, y, x-octet, channel group): stem_kernel's PX
     const int blocks = (int)((n + 255) / 256);
     if (a.taps == 9) {
         if (a.x_dtype == MOE_F16) hipLaunchKernelGGL((stem_kernel<half_t, 9>), dim3(blocks), dim3(256), 0, s, a);
