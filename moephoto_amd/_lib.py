@@ -33,6 +33,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise EngineError('{} not found: build it with `python -m moephoto_amd.build` (hipcc, gfx950). '
                           'moephoto_amd has no CPU path.'.format(LIB_PATH))
+    # torch first: its wheel bundles its own libamdhip64 (+ HSA runtime).  Loaded AFTER this library -- which then has pulled in the system ROCm's copy under the same
+    # soname -- torch binds to that copy and finds "No HIP GPUs" (seen with `python __graft_entry__.py smoke`: build() loads the library, then smoke() imports torch).
+    # One process, one HIP runtime: whichever torch ships.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     c_int, c_i64, c_vp, c_dbl = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_double
     P = ctypes.POINTER
