@@ -276,3 +276,63 @@ def test_wire_format_seams_keep_fp16_canvases_bit_identical(case):
         crude = ostitch.fold_stitch([t.astype(np.float16).astype(np.float32) for t in tiles], opl, sc)
         assert not np.array_equal(crude.astype(np.float16), want.astype(np.float16))
     assert wpos * 4 < 0.95 * buf.nbytes or min(d[1] for d in dims) < 6 * case['pad'] * sc
+
+
+# ---- which kernel instantiation does each (zoo key, precision, shape class) resolve to? ------------------------------------------------
+# tests/golden/kernel_resolution.json is generated on the GPU (tools/kernel_table.sh: one short process per case under rocprofv3 --kernel-trace).  Here, on the CPU, the
+# library's compiled instantiations (its host launch stubs: nm -C) are held against it: every one of them is either launched by a case of the table or listed below WITH
+# the reason it exists -- a new instantiation that nothing resolves to, or one that lost its last user, fails this test instead of riding along in the build.
+NOT_IN_THE_TABLE = {
+    # reached by the defaults on other shapes than the table's small cases (profiles/r05/h_kernel_census_defaults.txt: the 1080p frame)
+    'conv3x3_ps4_kernel<0, true>': 'store form of the x2 stages: launches with >= 32 four-row blocks per workgroup (a 1080p frame of a4)',
+    # option forms the form-vs-form GPU tests compare, and fallbacks for shapes the fast kernels refuse (profiles/r05/h_kernel_census_gpu_test_suite.txt: all launched by the GPU suite)
+    'conv3x3_rw_kernel<3, false>': 'phase-class-sums fused tail on patch-aligned images: option up_impl = rw (A/B of conv3x3_ps4)',
+    'conv3x3_rw_kernel<7, false>': 'the same with split tail activations',
+    'conv3x3_sp_kernel<1>': 'PReLU epilogue with the weights in LDS: option sp_impl = sp',
+    'conv3x3_sp_kernel<5>': 'split-precision pass of the three-launch form: x3_fuse = 0',
+    'conv3x3_sp_kernel<6>': "SEDN's fused block tail with the weights in LDS: option s64 = 0",
+    'conv64_q8_kernel<0, false, false>': 'patch form of the split-operand layers: option q8_impl = p / shapes conv64_sq refuses; lo8 = off',
+    'conv64_q8_kernel<0, false, true>': 'patch form, conv_input2 behind an fp16 low part writing fp8 (no caller in the current chains: the stem writes fp8 itself)',
+    'conv64_q8_kernel<0, true, true>': 'patch form, conv_input2 of the fp8 chain',
+    'conv64_q8_kernel<1, false, false>': 'patch form, conv_1, lo8 = off',
+    'conv64_q8_kernel<1, true, true>': 'patch form, conv_1 of the fp8 chain',
+    'conv64_q8_kernel<2, false, false>': 'patch form, conv_2 + residual, lo8 = off',
+    'conv64_q8_kernel<2, true, false>': 'patch form, last conv_2 of the fp8 chain (fp16 low part out)',
+    'conv64_q8_kernel<2, true, true>': 'patch form, conv_2 inside the fp8 chain',
+    'conv64_sq_kernel<1, true>': 'conv_1 of an exact ARSB as its own launch: option exact_fuse = 0 (A/B of arsb_sq)',
+    'conv64_sq_kernel<2, false>': 'conv_2 of the last exact ARSB as its own launch',
+    'conv64_sq_kernel<2, true>': 'conv_2 of an exact ARSB inside the chain as its own launch',
+    'conv_direct_kernel': "precision 'debug_direct': the scalar device convolution (kernel debugging)",
+    'conv_mfma_kernel<1, 1>': 'generic 1x1 conv: option conv1x1 = 0, SEDN unfused trans',
+    'conv_mfma_kernel<1, 3>': 'generic 1x1 conv with split operands: shapes beyond conv1x1.hip (32-bit offsets)',
+    'conv_mfma_kernel<9, 1>': 'generic 3x3 conv: conv_impl = v1 and 64-bit shapes',
+    'nhwc_to_nchw_kernel': 'debug taps (moe_net_debug_tap)',
+    'stitch_kernel': 'stitch fallback for canvases the vector forms do not take',
+    'tail_kernel<1>': 'unfused 1x1 tail (lite with fuse_tail = 0)',
+    'tail_kernel<9>': 'first-generation 3x3 tail: MOE_TAIL_V1',
+    'tailadd_kernel<false>': 'branch sum into output planes that are not 16-byte aligned',
+    'tapsum2_kernel': 'nine-plane fused tail of x2 nets: tail_form = planes',
+    'tapsum4_kernel<false>': 'phase-class sums into unaligned output planes',
+    'tapsum_kernel<2>': 'nine-plane fused tail, scalar form',
+}
+NOT_THE_NET = ('blend_tile_kernel', 'resize_kernel', 'to_float', 'to_output', 'wire_kernel', 'stitch')      # edges / callers of the path: exercised by their own tests, not by a forward
+
+
+def test_every_compiled_kernel_instantiation_has_a_user():
+    import subprocess
+    table = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'kernel_resolution.json')))
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import kernel_census
+    compiled = kernel_census.compiled()
+    assert len(compiled) >= 90, 'nm -C found no launch stubs in the library?'
+    launched = set(table['launched'])
+    assert launched <= compiled, 'the table names instantiations the library no longer has (regenerate it: tools/kernel_table.sh): {}'.format(sorted(launched - compiled))
+    for case, ks in table['cases'].items():      # every default-arithmetic case of the table resolves its layers to library kernels, and the families to their own trunk kernel
+        assert ks, case
+    assert 'arsb32c_kernel<true, 4>' in table['cases']['a4/auto/frame'] and 'conv3x3_ps4_kernel<2, false>' in table['cases']['a4/auto/frame']
+    assert 'arsb32c_kernel<true, 3>' in table['cases']['dn_lite5/auto/frame'] and 'conv64_s_kernel<6>' in table['cases']['l25/auto/frame']
+    assert 'conv1x1_kernel<true, 4, true>' in table['cases']['lite4/auto/frame'] and not any('conv_mfma' in k for k in table['cases']['lite8/auto/frame'])      # (round 5: lite8 off the generic kernel)
+    orphans = sorted(k for k in compiled - launched if k not in NOT_IN_THE_TABLE and not k.startswith(NOT_THE_NET))
+    assert not orphans, 'compiled, launched by no case of tests/golden/kernel_resolution.json and not explained in NOT_IN_THE_TABLE: {}'.format(orphans)
+    stale = sorted(k for k in NOT_IN_THE_TABLE if k not in compiled)
+    assert not stale, 'NOT_IN_THE_TABLE explains instantiations that are no longer compiled: {}'.format(stale)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, call C: the fp8 low-part stream in the single-pass ARSBs (option stream8) -- parity subset, calibration errors with and without, A/B of the frame inside one call
+# round 5, call C (HISTORICAL: option stream8 / MOE_STREAM8 existed at commit 0486050 only -- measured, then dropped; profiles/r05/c_stream8_ab.txt): the fp8 low-part stream in the single-pass ARSBs -- parity subset, calibration errors with and without, A/B of the frame inside one call
 set -u
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
