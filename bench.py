@@ -684,6 +684,8 @@ def _pmc_live():
     collect = os.path.join(ROOT, 'tools', 'pmc_collect.py')
     if not exe or not os.path.exists(collect):
         return None
+    if os.environ.get('HSA_TOOLS_LIB') or any(k.startswith(('ROCPROF', 'ROCP_', 'ROCTRACER')) for k in os.environ):
+        return None      # this very run is being profiled: a profiler inside a profiled process tree is asking for trouble -- the committed table serves
     out = tempfile.mkdtemp(prefix='moe_pmc_', dir='/tmp')
     steps, warm = 1, 1
     child = [sys.executable, os.path.abspath(__file__), '--steps', str(steps), '--warmup', str(warm), '--no-cpu-baseline', '--sustain', '0', '--no-noise-input', '--no-dropin-loop',
