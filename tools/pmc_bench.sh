@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out/${PMC_TAG:-pmc}
 mkdir -p $OUT
 STEPS=${PMC_STEPS:-2}
-CMD="python bench.py --steps $STEPS --warmup 1 --no-cpu-baseline --sustain 0 --no-noise-input --no-dropin-loop --no-extras"
+CMD="python bench.py --steps $STEPS --warmup 1 --no-cpu-baseline --sustain 0 --no-noise-input --no-dropin-loop --no-extras --no-configs --no-pmc"
 RE='conv3x3|arsb_fused|arsb32|arsb_sq|conv64_x3|conv64_q8|conv64_sq|tapsum|tailadd|stitch|stem_kernel'
 pass() {  # name, counters...
   name=$1; shift
