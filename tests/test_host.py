@@ -336,3 +336,29 @@ def test_every_compiled_kernel_instantiation_has_a_user():
     assert not orphans, 'compiled, launched by no case of tests/golden/kernel_resolution.json and not explained in NOT_IN_THE_TABLE: {}'.format(orphans)
     stale = sorted(k for k in NOT_IN_THE_TABLE if k not in compiled)
     assert not stale, 'NOT_IN_THE_TABLE explains instantiations that are no longer compiled: {}'.format(stale)
+
+
+def test_round5_entry_points_validate_their_arguments_without_a_device():
+    """moe_blend_tile and moe_net_calibrate / moe_net_exact_blocks (ABI version 3): argument errors are reported before anything touches a device -- the reference's callers
+    get an exception with a message (python/worker.py:52-74), not a launch on bad pointers."""
+    L = _lib.lib()
+    buf = (ctypes.c_float * 16)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    blend = lambda *a: L.moe_blend_tile(*a)
+    assert blend(None, 0, 0, p, 0, 0, _lib.F32, 1, 0, 0, 4, 4, 0, 0, 2, p, None) == _lib.EINVAL and b'NULL' in L.moe_last_error()
+    assert blend(p, 16, 4, p, 16, 4, _lib.U8, 1, 0, 0, 4, 4, 0, 0, 2, p, None) == _lib.EINVAL and b'dtype' in L.moe_last_error()
+    assert blend(p, 16, 4, p, 16, 4, _lib.F32, 1, 4, 0, 4, 4, 0, 0, 2, p, None) == _lib.EINVAL and b'window' in L.moe_last_error()          # empty window (top_sc == bsc)
+    assert blend(p, 16, 4, p, 16, 4, _lib.F32, 1, 0, 0, 4, 4, 1, 0, 2, p, None) == _lib.EINVAL and b'band' in L.moe_last_error()            # first new row 1, two ramp rows in front of it: outside
+    assert blend(p, 16, 4, p, 16, 4, _lib.F32, 1, 0, 0, 4, 4, 2, 0, 2, None, None) == _lib.EINVAL and b'ramp' in L.moe_last_error()
+    h = ctypes.c_void_p()
+    _lib.check(L.moe_net_create(_lib.ARCH_NET2X, 2, ctypes.byref(h)))
+    try:
+        n, e = ctypes.c_int(), ctypes.c_double()
+        assert L.moe_net_calibrate(h, 0.0, ctypes.byref(n), ctypes.byref(e), None) == _lib.ESTATE and b'finalized' in L.moe_last_error()
+        assert L.moe_net_calibrate(None, 0.0, ctypes.byref(n), ctypes.byref(e), None) == _lib.EINVAL
+        assert L.moe_net_exact_blocks(h) == 0                          # (not in MOE_PREC_MIXED yet)
+        assert L.moe_net_set_option(h, b'branch_streams', b'0') == 0 and L.moe_net_set_option(h, b'branch_groups', b'64') == 0 and L.moe_net_set_option(h, b'auto_calibrate', b'off') == 0
+        assert L.moe_net_set_option(h, b'repeat', b'arsb3:20') == 0 and L.moe_net_set_option(h, b'repeat', b'0') == 0 and L.moe_net_set_option(h, b'repeat', b'arsb3:0') == _lib.EINVAL
+        assert L.moe_net_set_option(h, b'arsb_impl', b's') == _lib.EINVAL       # (the streamed ARSB left the build in round 5)
+    finally:
+        L.moe_net_destroy(h)
