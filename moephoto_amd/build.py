@@ -41,12 +41,26 @@ def source_digest():
     return h.hexdigest()
 
 
+def _compile_cmd(src, extra=()):
+    """(command line, its digest) of one source: the digest is what an object's .o.cmd tag must equal for the object to be reused."""
+    obj = os.path.join(HERE, '_obj', os.path.splitext(src)[0] + '.o')
+    cmd = [hipcc(), '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-x', 'hip', '-c', os.path.join(CSRC, src), '-o', obj]
+    # -cuid: hipcc derives a compilation-unit id from the PATHS of source and output by default and plants it in symbol names (__hip_cuid_<hash>): the same tree built in
+    # another directory gave a different binary (VERDICT r04: "the build is not bit-reproducible").  A fixed id per source makes libmoephoto_amd.so a function of the sources
+    # and flags alone: `git archive HEAD` built anywhere with this hipcc reproduces the shipped library byte for byte (profiles/r05/summary.md).
+    cmd += ['-cuid=moe_' + os.path.splitext(src)[0]]
+    cmd += EXTRA_FLAGS.get(src, []) + list(extra)
+    return cmd, hashlib.sha256('\0'.join(cmd[1:]).encode()).hexdigest()
+
+
 def stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    if any(not os.path.exists(os.path.join(HERE, '_obj', os.path.splitext(src)[0] + '.o.cmd')) for src in SOURCES):
-        return True                      # (objects of an unknown command line: build_lib decides per object)
+    for src in SOURCES:                  # an object compiled by another command line (other flags, an experiment's -D): build_lib rebuilds it
+        tag = os.path.join(HERE, '_obj', os.path.splitext(src)[0] + '.o.cmd')
+        if not os.path.exists(tag) or open(tag).read().strip() != _compile_cmd(src)[1]:
+            return True
     return os.environ.get('MOE_HIPCC_FLAGS') is not None or any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
@@ -66,11 +80,10 @@ def build_lib(force=False, verbose=False):
     for src in SOURCES:
         obj = os.path.join(HERE, '_obj', os.path.splitext(src)[0] + '.o')
         objs.append(obj)
-        cmd = [hipcc(), '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-x', 'hip', '-c', os.path.join(CSRC, src), '-o', obj]
-        cmd += EXTRA_FLAGS.get(src, []) + extra
+        cmd, want = _compile_cmd(src, extra)
         # an object is reused only when it is newer than its source and headers AND was compiled by this very command line: an object left behind by an experiment
         # (MOE_HIPCC_FLAGS=-DPS4_ABL ...: results wrong by design) or by other EXTRA_FLAGS must not be linked into a later plain build
-        tag, want = obj + '.cmd', hashlib.sha256('\0'.join(cmd[1:]).encode()).hexdigest()
+        tag = obj + '.cmd'
         have = open(tag).read().strip() if os.path.exists(tag) else ''
         if not force and have == want and os.path.exists(obj) and os.path.getmtime(obj) > max(hdr_t, os.path.getmtime(os.path.join(CSRC, src))):
             continue
