@@ -50,7 +50,8 @@ def _compile_cmd(src, extra=()):
     # and flags alone: `git archive HEAD` built anywhere with this hipcc reproduces the shipped library byte for byte (profiles/r05/summary.md).
     cmd += ['-cuid=moe_' + os.path.splitext(src)[0]]
     cmd += EXTRA_FLAGS.get(src, []) + list(extra)
-    return cmd, hashlib.sha256('\0'.join(cmd[1:]).encode()).hexdigest()
+    rel = [c.replace(CSRC, '<csrc>').replace(HERE, '<pkg>') for c in cmd[1:]]      # (the tag must not depend on where the tree lies: the GPU box sees it under another path)
+    return cmd, hashlib.sha256('\0'.join(rel).encode()).hexdigest()
 
 
 def stale():
