@@ -106,12 +106,14 @@ int moe_net_finalize(moe_net* net, int device, int precision);
 int moe_net_resolved_precision(const moe_net* net, int precision);
 /* The precision policy for checkpoints the build has never seen (the reference's contract is "load any state dict, get the fp32 answer":
  * python/imageProcess.py:319-334; its own dtype policy is castModel, :309-317).  Net2x/3x/4x and NetDN under MOE_PREC_MIXED run their first `blocks` ARSBs with
- * split operands; how many a checkpoint needs depends on how wide its trunk swings.  moe_net_calibrate measures it on the device: uniform uint8-noise tiles (2 x 3
- * planes of 192 x 192) through the exact arithmetic (FP16X3) and through MIXED with blocks = the architecture's default .. 6; *blocks = the smallest count whose
- * worst max-abs difference is <= target (target <= 0: 7.5e-4), *err = that difference; *blocks = -1 when six blocks do not reach it (*err = what they reach).
+ * split operands; how many a checkpoint needs depends on how wide its trunk swings.  moe_net_calibrate measures it on the device: uniform uint8-noise tiles (3 seeds
+ * x 3 planes of 256 x 256, the tile size that ships) through the exact arithmetic (FP16X3) and through MIXED with blocks = the architecture's default .. 6.  The worst
+ * max-abs difference of that sample times 1.10 -- the inflation observed between such a sample and the worst tile of full frames -- is the PREDICTED worst tile of a
+ * full frame; *blocks = the smallest count whose prediction is <= target (target <= 0: 8.25e-4; the architecture's default count is kept up to 5 % above it, so that a
+ * zoo key next to the target does not flip with the device or driver), *err = that prediction; *blocks = -1 when six blocks do not reach it (*err = what they reach).
  * The count is kept (moe_net_exact_blocks) until a parameter changes or moe_net_set_exact_blocks overrides it.  moe_net_finalize(MOE_PREC_AUTO) runs this by itself,
  * once per checkpoint, and finalizes in MOE_PREC_FP16X3 when no count reaches the target: a drop-in caller needs no extra line.  SEDN / lite: *blocks = 0, nothing
- * is measured (their AUTO arithmetic has no such knob).  Synchronises `stream`; ~0.1-0.3 s. */
+ * is measured (their AUTO arithmetic has no such knob).  Synchronises `stream`; ~0.2-0.4 s.  (moe_net_finalize runs its measurement on a private non-blocking stream.) */
 int moe_net_calibrate(moe_net* net, double target, int* blocks, double* err, void* stream);
 /* the count of split-operand ARSBs the next forward runs with (0 when the net is not in MOE_PREC_MIXED) */
 int moe_net_exact_blocks(const moe_net* net);

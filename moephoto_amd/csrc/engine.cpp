@@ -114,6 +114,7 @@ struct NetOptions {
     bool fuse_tail = true;    // fuse_tail   last upsampler conv + 64->1 / 48->1 tail conv in one kernel
     bool sedn_fuse = true;    // sedn_fuse   SEDN's fused block tail
     bool pool_fuse = true;    // pool_fuse   SE / FRM channel sums out of the producing conv's epilogue
+    int calib_log = 0;        // calib_log   1: moe_net_calibrate prints every count's measured and predicted error to stderr (tools/calib_report.py)
     int auto_calibrate = 1;   // auto_calibrate  1 (default): moe_net_finalize(MOE_PREC_AUTO) measures the count of split-operand ARSBs on the loaded weights | 0: per-architecture defaults
     int exact_blocks_env = -1;   // MOE_EXACT_BLOCKS (moe_net_set_exact_blocks overrides)
     int tiles_per_batch = 0;  // tiles_per_batch   tiles of 256^2 pixels per launch set when the caller passes 0 (0: 32)
@@ -148,6 +149,7 @@ struct NetOptions {
         if (key == "k48") { const int t = onoff(v); if (t < 0) return false; k48 = t; return true; }
         if (key == "s64") { const int t = onoff(v); if (t < 0) return false; s64 = t; return true; }
         if (key == "auto_calibrate") { const int t = onoff(v); if (t < 0) return false; auto_calibrate = t; return true; }
+        if (key == "calib_log") { const int t = onoff(v); if (t < 0) return false; calib_log = t; return true; }
         if (key == "branch_groups") { branch_groups = atoi(v); return branch_groups >= 0; }
         if (key == "branch_streams") { const int t = onoff(v); if (t < 0) return false; branch_streams = t; return true; }
         if (key == "exact_fuse") { const int t = onoff(v); if (t < 0) return false; exact_fuse = t; return true; }
@@ -163,10 +165,18 @@ struct NetOptions {
         if (key == "max_groups") { max_groups = atoi(v); return max_groups >= 0; }
         if (key == "trace_key") { trace_key = v; return true; }
         if (key == "repeat") {
+            // parsed into locals first: a refused value ("up1:0", "k:-3", "nonsense") must leave the option as it was -- a stored count of zero would issue no launch at all
+            // for the matching layers
             const char* c = strrchr(v, ':');
-            if (!c) { repeat_key.clear(); repeat_n = 1; return !*v || !strcmp(v, "0"); }
-            repeat_key.assign(v, c - v); repeat_n = atoi(c + 1);
-            return repeat_n >= 1;
+            if (!c) {
+                if (*v && strcmp(v, "0")) return false;
+                repeat_key.clear(); repeat_n = 1;
+                return true;
+            }
+            const int cnt = atoi(c + 1);
+            if (cnt < 1 || c == v) return false;
+            repeat_key.assign(v, c - v); repeat_n = cnt;
+            return true;
         }
         return false;
     }
@@ -1148,6 +1158,17 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
                                                                                                                                           // batched frame is NOT small: forked, the headline frame lost 0.5 ms)
         // ... each branch on its own share of the chip: side stream g_side persistent workgroups per launch, the caller's stream the rest (restored at scope exit)
         struct GroupsGuard { moe_net& n; int all; ~GroupsGuard() { n.max_groups = all; } } groups_guard{n, n.max_groups};
+        // every exit behind the fork joins the side stream back into the caller's: an early return (a refused layer, a failed HIP call) must not leave kernels in flight on
+        // n.side that the caller's stream never waits for -- the caller may synchronize its own stream and reuse or free the workspace (forward_dev_chunk's regrow does), and
+        // an unjoined fork makes hipStreamEndCapture fail.  Disarmed by the regular join in front of the branch sum.
+        struct ForkGuard {
+            moe_net& n; hipStream_t s; bool armed = false;
+            ~ForkGuard()
+            {
+                if (!armed) return;
+                if (hipEventRecord(n.ev_join, n.side) != hipSuccess || hipStreamWaitEvent(s, n.ev_join, 0) != hipSuccess) (void)hipStreamSynchronize(n.side);
+            }
+        } fork_guard{n, s};
         int g_side = 0;
         if (forked && n.max_groups >= 32) {
             g_side = n.opt.branch_groups > 0 ? n.opt.branch_groups : (n.stages >= 2 ? 5 * n.max_groups / 16 : 3 * n.max_groups / 16);
@@ -1164,6 +1185,7 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
                 HIP_TRY(hipEventRecord(n.ev_fork, s));
                 HIP_TRY(hipStreamWaitEvent(n.side, n.ev_fork, 0));      // behind the stem (and everything before it on the caller's stream: the previous forward's reads of the workspace)
                 f.s = n.side;
+                fork_guard.armed = true;
             }
             const int rc = run_branch(1, A);
             if (g_side) n.max_groups = groups_guard.all - g_side;      // the trunk and the R branch: the other CUs
@@ -1257,7 +1279,7 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         if (!forked) { if (int rc = run_branch(0, Bb)) return rc; if (int rc = run_branch(1, A)) return rc; }
         else {
             if (int rc = run_branch(0, Bb)) return rc;
-            if (!f.dry()) HIP_TRY(hipStreamWaitEvent(s, n.ev_join, 0));      // the branch sum below reads both branches
+            if (!f.dry()) { HIP_TRY(hipStreamWaitEvent(s, n.ev_join, 0)); fork_guard.armed = false; }      // the branch sum below reads both branches
             n.max_groups = groups_guard.all;
         }
         if (ps4) {
@@ -1503,27 +1525,38 @@ int forward_dev_chunk(moe_net& n, const void* x, int x_dtype, int B, int h, int 
 // The per-architecture counts of split-operand ARSBs were chosen on the zoo's weights with ~2e-4 of the 1e-3 budget to spare on uint8 noise; a checkpoint
 // whose trunk swings wider spends more (profiles/r04/n_margin_sweep_and_fuzz_final_tree.txt: the trunk's weights x 1.15 -> 1.3e-3 / 1.8e-3 with the defaults).
 // The reference's contract is "load any state dict, get the fp32 answer" (python/imageProcess.py:319-334), so the count is a property of the CHECKPOINT and is
-// measured when it is loaded: two uniform uint8-noise tiles of 3 x 192 x 192 (the input class that spends the most: SURVEY.md appendix) go through the exact mode
-// (FP16X3: pinned to the fp32 oracle at 2e-5 by the tests) and through MIXED with n = default .. 6 blocks; the smallest n whose worst max-abs difference is within
-// `target` is kept, and when not even six blocks reach it the net runs in FP16X3.  ~0.1-0.3 s once per checkpoint and device.
-constexpr double kCalibTarget = 7.5e-4;       // 2.5e-4 of the 1e-3 contract stay in hand: the worst tile of an all-tile sweep over 1080p noise frames lies ~1e-4 above these two
-                                              // calibration tiles (a4: 6.7e-4 here, 7.5-7.8e-4 there; profiles/r04/fullsize_report.json), the exact mode itself is pinned to the
-                                              // oracle at 2e-5.  Every zoo key keeps its architecture's default at this target (profiles/r05/a_calibration_report.txt: a4 6.7e-4,
-                                              // a2 5.6e-4, p2 7.1e-4, a3 4.5e-4, dn_lite5 7.4e-4, dn_lite10 / 15 4.0 / 3.4e-4)
+// measured when it is loaded: uniform uint8-noise tiles (the input class that spends the most: SURVEY.md appendix) go through the exact mode (FP16X3: pinned to the
+// fp32 oracle at 2e-5 by the tests) and through MIXED with n = default .. 6 blocks; the smallest n whose PREDICTED worst tile of a full frame is within `target`
+// is kept, and when not even six blocks reach it the net runs in FP16X3.  ~0.2-0.4 s once per checkpoint and device.
+//
+// Round 6: the measurement is conservative by construction.  Rounds 4-5 measured two tiles of 3 x 192 x 192 from one seed and compared the value
+// itself with 7.5e-4; the worst tile of an all-tile sweep over full frames lies 1.05-1.20x above such a sample (a maximum over 20x more values: a4 as shipped 6.7e-4
+// here, 7.4e-4 there; perturbed checkpoints reached 8.3e-4 although the calibration had passed -- profiles/r05/margin_sweep.txt).  Now: THREE seeds, tiles of
+// 3 x 256 x 256 (the tile size that ships), and the comparison is  measured x kCalibInflate <= target  with the inflation observed between this sample and full-frame
+// sweeps (profiles/r06/calibration_vs_frames.txt).  `err` reports the predicted (inflated) figure.  Hysteresis: the ARCHITECTURE'S DEFAULT count is kept while its
+// prediction is within 5 % above the target -- a zoo key that sits next to the target must not flip between n and n + 1 (and change its bits and speed) with the driver,
+// the device or the launch geometry; every larger count must be strictly within the target.
+constexpr double kCalibTarget = 8.25e-4;      // predicted worst tile of a full frame; 1.75e-4 of the 1e-3 contract stay in hand (the exact mode itself is pinned to the oracle at 2e-5,
+                                              // an fp16 result adds half an ulp of the value)
+constexpr double kCalibInflate = 1.10;        // full-frame worst tile / this sample's worst value
+constexpr double kCalibHysteresis = 1.05;     // the default count only
+constexpr int kCalibTiles = 3;                // noise seeds = tiles of 3 planes
 
 bool calibratable(const moe_net& n) { return n.arch == MOE_ARCH_NET2X || n.arch == MOE_ARCH_NET3X || n.arch == MOE_ARCH_NET4X || n.arch == MOE_ARCH_NETDN; }
 
 int calibrate_blocks(moe_net& n, double target, hipStream_t s)
 {
     if (!(target > 0)) target = kCalibTarget;
-    const int B = 6, h = 192, w = 192, sc = n.scale;
-    const size_t nin = (size_t)B * h * w, nout = nin * sc * sc;
+    const int B = 3 * kCalibTiles, h = 256, w = 256, sc = n.scale;
+    const size_t nin = (size_t)B * h * w, nout = nin * sc * sc, per_seed = (size_t)3 * h * w;
     std::vector<float> x(nin), ref(nout), got(nout);
-    unsigned long long st = 0x9E3779B97F4A7C15ull;             // splitmix64 -> bytes -> / 255: the uint8 noise of SURVEY 8(d), from a fixed seed
-    for (size_t i = 0; i < nin; i += 8) {
-        unsigned long long z = (st += 0x9E3779B97F4A7C15ull);
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
-        for (size_t k = 0; k < 8 && i + k < nin; ++k) x[i + k] = (float)((z >> (8 * k)) & 255) / 255.f;
+    for (int t = 0; t < kCalibTiles; ++t) {
+        unsigned long long st = 0x9E3779B97F4A7C15ull * (unsigned long long)(2 * t + 1);      // splitmix64 -> bytes -> / 255: the uint8 noise of SURVEY 8(d), one fixed seed per tile
+        for (size_t i = 0; i < per_seed; i += 8) {
+            unsigned long long z = (st += 0x9E3779B97F4A7C15ull);
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+            for (size_t k = 0; k < 8 && i + k < per_seed; ++k) x[t * per_seed + i + k] = (float)((z >> (8 * k)) & 255) / 255.f;
+        }
     }
     float *xd = nullptr, *yd = nullptr;
     HIP_TRY(hipSetDevice(n.device));
@@ -1551,13 +1584,15 @@ int calibrate_blocks(moe_net& n, double target, hipStream_t s)
     n.calib_valid = false; n.calib_blocks = -1; n.calib_err = 0.0;
     int best = -1;
     double err = 0.0;
-    for (int nb = default_exact_blocks(n.arch); nb <= 6; ++nb) {
+    const int nb0 = default_exact_blocks(n.arch);
+    for (int nb = nb0; nb <= 6; ++nb) {
         n.exact_blocks = nb;
         if ((rc = run(got))) break;
         double e = 0.0;
         for (size_t i = 0; i < nout; ++i) { const double d = std::fabs((double)got[i] - (double)ref[i]); if (!(d <= e)) e = d; }      // (a NaN counts as a failure)
-        err = e;
-        if (e <= target) { best = nb; break; }
+        err = e * kCalibInflate;                                  // the predicted worst tile of a full frame
+        if (n.opt.calib_log) fprintf(stderr, "moe_net_calibrate: %d split blocks: measured %.3e on %d noise tiles of 3 x %d x %d, predicted %.3e (target %.3e)\n", nb, e, kCalibTiles, h, w, err, target);
+        if (err <= (nb == nb0 ? target * kCalibHysteresis : target)) { best = nb; break; }
     }
     if (!rc) { n.calib_valid = true; n.calib_blocks = best; n.calib_err = err; }
     if (prec0 != MOE_PREC_MIXED) { n.precision = prec0; const int rc2 = build_device_weights(n, prec0); if (!rc) rc = rc2; }
@@ -1769,6 +1804,27 @@ int moe_net_finalize(moe_net* n, int device, int precision)
     int cnt = 0;
     if (hipGetDeviceCount(&cnt) != hipSuccess || cnt < 1) { (void)hipGetLastError(); return fail(MOE_EHIP, "no HIP device available (this engine has no CPU path)"); }
     if (device < 0 || device >= cnt) return fail(MOE_EINVAL, "device %d out of range (%d visible)", device, cnt);
+    if (n->device >= 0 && n->device != device) {
+        // the net moves to another device: its streams, events and workspace belong to the old one (the side stream of small launch sets was created once and
+        // would have been used on the new device's forwards); the weight blob is rebuilt below
+        (void)hipSetDevice(n->device);
+        if (n->side) { (void)hipStreamSynchronize(n->side); (void)hipStreamDestroy(n->side); n->side = nullptr; }
+        if (n->ev_fork) { (void)hipEventDestroy(n->ev_fork); n->ev_fork = nullptr; }
+        if (n->ev_join) { (void)hipEventDestroy(n->ev_join); n->ev_join = nullptr; }
+        if (n->ws) { (void)hipDeviceSynchronize(); (void)hipFree(n->ws); n->ws = nullptr; n->ws_bytes = 0; }
+        if (n->blob) { (void)hipFree(n->blob); n->blob = nullptr; n->blob_bytes = 0; }
+        for (auto& ev : n->prof_ev) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); }
+        n->prof_ev.clear(); n->prof_used = 0;
+        for (auto& sl : n->off_ring) {
+            if (sl.host) (void)hipHostFree(sl.host);
+            if (sl.dev) (void)hipFree(sl.dev);
+            if (sl.done) (void)hipEventDestroy(sl.done);
+            sl = moe_net::OffSlot{};
+        }
+        for (auto& t : n->taps) if (t.second.dev) (void)hipFree(t.second.dev);
+        n->taps.clear();
+        n->calib_valid = false;      // (measured on the other device: the arithmetic is the same, but the rule is one measurement per checkpoint AND device)
+    }
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(conv_mfma_init());
     n->max_groups = conv_mfma_max_groups();
@@ -1784,7 +1840,13 @@ int moe_net_finalize(moe_net* n, int device, int precision)
         // An explicit moe_net_set_exact_blocks / MOE_EXACT_BLOCKS or option auto_calibrate = 0 leaves the per-architecture default in force.
         if (precision == MOE_PREC_MIXED && calibratable(*n) && n->opt.auto_calibrate && n->exact_blocks < 0 && n->opt.exact_blocks_env < 0) {
             if (!n->calib_valid) {
-                rc = calibrate_blocks(*n, 0.0, nullptr);
+                // the measurement's device work (three weight rebuilds, up to seven forwards) runs on a stream of its own: the legacy NULL stream would serialise against
+                // every blocking stream of the process and is illegal while another stream captures; callers with a stream of theirs use moe_net_calibrate
+                hipStream_t cs = nullptr;
+                HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+                rc = calibrate_blocks(*n, 0.0, cs);
+                (void)hipStreamSynchronize(cs);
+                (void)hipStreamDestroy(cs);
                 if (rc) { n->finalized = false; return rc; }
             }
             if (n->calib_blocks < 0) {

@@ -296,8 +296,20 @@ def blendTile(r, canvas, tile, sc, padSc, ramp):
     r: (C, h, w) tile result (rows / columns beyond the window are ignored: opt.unpad); canvas: (C, H, W); ramp: opt.blend (padSc values); all three of one
     dtype (fp16 / fp32), on the device, unit stride along the last axis.  The canvas receives the bits the reference's torch expression produces."""
     top, bottom, left, right, topT, leftT, bsc, rsc = [int(v) for v in tile]
-    if r.dim() == 4:
+    canvas_in = canvas
+    # moe_blend_tile takes raw pointers and (plane, row) strides: this wrapper is the only guard against a canvas / tile of another rank (the reference's
+    # tmp_image is (1, C, H, W) when opt.oShape is set; a (C, 1, H, W) result is the net's own output shape).  Singleton leading / second axes are dropped, anything
+    # else is refused -- stride(1) of a 4-D tensor is NOT the row stride (ADVICE r05)
+    if r.dim() == 4 and r.shape[1] == 1:
         r = r.squeeze(1)
+    while r.dim() > 3 and r.shape[0] == 1:
+        r = r[0]
+    while canvas.dim() > 3 and canvas.shape[0] == 1:
+        canvas = canvas[0]
+    if canvas.dim() == 4 and canvas.shape[1] == 1:
+        canvas = canvas[:, 0]
+    if r.dim() != 3 or canvas.dim() != 3:
+        raise ValueError('blendTile: a (C, h, w) tile result and a (C, H, W) canvas expected, got {} and {}'.format(tuple(r.shape), tuple(canvas.shape)))
     if not (r.dtype == canvas.dtype and (ramp is None or ramp.dtype == canvas.dtype)) or r.dtype not in _DT:
         raise TypeError('blendTile: tile, canvas and ramp must share one dtype (fp16 or fp32)')
     if r.stride(-1) != 1 or canvas.stride(-1) != 1 or r.device != canvas.device or r.shape[0] != canvas.shape[0]:
@@ -308,9 +320,9 @@ def blendTile(r, canvas, tile, sc, padSc, ramp):
     if rp is not None and (rp.numel() < padSc or rp.stride(0) != 1):
         raise ValueError('blendTile: ramp must hold padSc contiguous values')
     stream = torch.cuda.current_stream(canvas.device).cuda_stream
-    _lib.check(_lib.lib().moe_blend_tile(r.data_ptr(), r.stride(0), r.stride(1), canvas.data_ptr(), canvas.stride(0), canvas.stride(1), _DT[canvas.dtype], int(canvas.shape[0]),
+    _lib.check(_lib.lib().moe_blend_tile(r.data_ptr(), r.stride(-3), r.stride(-2), canvas.data_ptr(), canvas.stride(-3), canvas.stride(-2), _DT[canvas.dtype], int(canvas.shape[0]),
                                          int(top * sc), int(left * sc), bsc, rsc, topT, leftT, int(padSc), rp.data_ptr() if rp is not None else None, stream))
-    return canvas
+    return canvas_in
 
 
 def resizeByTorch(x, width, height, mode='bilinear'):

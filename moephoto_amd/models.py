@@ -177,8 +177,9 @@ class EngineModule(object):
 
     def calibrate(self, target=0.0):
         """Measure the number of split-operand ARSBs THESE weights need (moe_net_calibrate: uint8-noise tiles through the exact mode and through 'mixed' with
-        n = default .. 6 blocks, on the device) and keep it.  Returns (n, worst error at n); n = -1 when six blocks do not reach `target` (<= 0: the library's
-        7.5e-4).  `.to(device)` with precision 'auto' already does this once per checkpoint (moe_net_finalize(MOE_PREC_AUTO)); this is the explicit call, e.g. with
+        n = default .. 6 blocks, on the device) and keep it.  Returns (n, predicted worst-tile error of a full frame at n); n = -1 when six blocks do not reach `target`
+        (<= 0: the library's default).  With precision 'auto' the module is finalized again on the result (n blocks, or 'fp16x3' when n = -1); with an explicit 'mixed' the
+        count applies (exact_blocks()) and n = -1 leaves the architecture's count in force.  `.to(device)` with precision 'auto' already does this once per checkpoint (moe_net_finalize(MOE_PREC_AUTO)); this is the explicit call, e.g. with
         another target.  None for families without the knob (SEDN, lite) or when the module runs in another arithmetic."""
         if self._device is None:
             raise _lib.EngineError('calibrate: move the module to its device first')
@@ -186,7 +187,17 @@ class EngineModule(object):
             return None
         n, err = ctypes.c_int(), ctypes.c_double()
         stream = torch.cuda.current_stream(self._device).cuda_stream
-        _lib.check(_lib.lib().moe_net_calibrate(self._h, float(target), ctypes.byref(n), ctypes.byref(err), stream))
+        try:
+            _lib.check(_lib.lib().moe_net_calibrate(self._h, float(target), ctypes.byref(n), ctypes.byref(err), stream))
+        except Exception:
+            self._finalized_key = None      # the C side un-finalizes the net on a failed measurement: the next .to() / forward must finalize again, not report 'not finalized' for ever
+            raise
+        if self.precision == 'auto':
+            # the measurement is what moe_net_finalize(MOE_PREC_AUTO) decides on: finalize again so that the arithmetic (mixed with n blocks, or fp16x3 when n = -1) and
+            # exact_blocks() follow THIS result -- otherwise a net that had resolved to fp16x3 would stay there with n >= 0, and one that got n = -1 would keep running
+            # 'mixed' with the architecture's count
+            self._finalized_key = None
+            self._finalize()
         return n.value, err.value
 
     def exact_blocks(self):

@@ -443,7 +443,10 @@ def test_blend_tile_kernel_equals_the_reference_blend_expression(dev):
                 q, _ = blend(q, t2, lt, pl.pad_sc, -1, ramp)
                 hh, ww = q.shape[-2:]
                 want[..., bsc - hh:bsc, rsc - ww:rsc] = q
-                ip.blendTile(r, got, (top, bottom, left, right, tt, lt, bsc, rsc), sc, pl.pad_sc, ramp)
+                # the forms the reference's loop hands over: (C, h, w) into (C, H, W); the net's own (C, 1, h, w) result; tmp_image as (1, C, H, W) (opt.oShape) -- ADVICE r05:
+                # singleton axes are dropped by the wrapper, the kernel always sees (plane, row) strides
+                form = len(pl.tiles) % 3
+                ip.blendTile(r.unsqueeze(1) if form == 1 else r, got.unsqueeze(0) if form == 2 else got, (top, bottom, left, right, tt, lt, bsc, rsc), sc, pl.pad_sc, ramp)
             assert torch.equal(got, want), (shape, dt, float((got.float() - want.float()).abs().max()))
     # the loop of test_dropin_protocol_reference_loop with the fused kernel in place of the two blends
     from moephoto_amd.imageProcess import Option, initModel
@@ -1149,7 +1152,7 @@ def test_calibrate_exact_blocks_for_other_weights(dev):
     m = build(1.0)
     assert m.exact_blocks() == 4 and m.resolved_precision() == 'mixed'
     n, err = m.calibrate()
-    assert n == 4 and err <= 7.5e-4, (n, err)
+    assert n == 4 and err <= 8.25e-4 * 1.05, (n, err)      # (err: the predicted worst tile of a full frame = measured x 1.10; the default count is kept up to 5 % above the target)
     m = build(1.15)
     na = m.exact_blocks()
     assert na > 4 or m.resolved_precision() == 'fp16x3', na

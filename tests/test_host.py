@@ -360,5 +360,25 @@ def test_round5_entry_points_validate_their_arguments_without_a_device():
         assert L.moe_net_set_option(h, b'branch_streams', b'0') == 0 and L.moe_net_set_option(h, b'branch_groups', b'64') == 0 and L.moe_net_set_option(h, b'auto_calibrate', b'off') == 0
         assert L.moe_net_set_option(h, b'repeat', b'arsb3:20') == 0 and L.moe_net_set_option(h, b'repeat', b'0') == 0 and L.moe_net_set_option(h, b'repeat', b'arsb3:0') == _lib.EINVAL
         assert L.moe_net_set_option(h, b'arsb_impl', b's') == _lib.EINVAL       # (the streamed ARSB left the build in round 5)
+        # a refused `repeat` value leaves the option as it was ("up1:0" used to store a count of zero and then report EINVAL -- the next forward issued no launch
+        # for the matching layers); the state is visible through what the next valid / invalid calls return
+        assert L.moe_net_set_option(h, b'repeat', b'up1:3') == 0
+        for bad in (b'up1:0', b'k:-3', b'nonsense', b':4'):
+            assert L.moe_net_set_option(h, b'repeat', bad) == _lib.EINVAL, bad
+        assert L.moe_net_set_option(h, b'repeat', b'') == 0 and L.moe_net_set_option(h, b'calib_log', b'1') == 0 and L.moe_net_set_option(h, b'calib_log', b'x') == _lib.EINVAL
     finally:
         L.moe_net_destroy(h)
+
+
+def test_blend_tile_wrapper_refuses_tensors_of_another_rank():
+    """imageProcess.blendTile is the only guard in front of moe_blend_tile's raw pointers: a canvas or tile result whose extra axes are not singletons must be
+    refused before strides of the wrong axes reach the kernel; singleton axes -- the reference's (1, C, H, W) tmp_image with opt.oShape, the net's (C, 1, h, w) result --
+    are dropped (the accepted forms run in tests/test_gpu_parity.py)."""
+    import torch
+    from moephoto_amd import imageProcess as ip
+    tile = (0, 8, 0, 8, 0, 0, 16, 16)
+    ramp = torch.zeros(4)
+    for r, canvas in ((torch.zeros(3, 16, 16), torch.zeros(3, 2, 16, 16)), (torch.zeros(3, 2, 16, 16), torch.zeros(3, 16, 16)),
+                      (torch.zeros(2, 3, 16, 16), torch.zeros(3, 16, 16)), (torch.zeros(16, 16), torch.zeros(3, 16, 16))):
+        with pytest.raises(ValueError, match='expected'):
+            ip.blendTile(r, canvas, tile, 2, 4, ramp)
