@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MOE_ABI_VERSION 3      /* 3: moe_net_calibrate / moe_net_exact_blocks, MOE_PREC_AUTO measures the checkpoint at finalize, moe_blend_tile (round 5); 2: MOE_PREC_AUTO, moe_net_resolved_precision, moe_plan_rows / moe_stitch_band, moe_plan_seams / moe_wire_* (round 4); 1 also lacked a bump for moe_net_set_option / moe_device_info / moe_stitch_dev */
+#define MOE_ABI_VERSION 4      /* 4: moe_net_forward_ex / MOE_FWD_INPUT_SINCE_PREV (round 6); 3: moe_net_calibrate / moe_net_exact_blocks, MOE_PREC_AUTO measures the checkpoint at finalize, moe_blend_tile (round 5); 2: MOE_PREC_AUTO, moe_net_resolved_precision, moe_plan_rows / moe_stitch_band, moe_plan_seams / moe_wire_* (round 4); 1 also lacked a bump for moe_net_set_option / moe_device_info / moe_stitch_dev */
 
 /* error codes */
 #define MOE_OK 0
@@ -106,10 +106,10 @@ int moe_net_finalize(moe_net* net, int device, int precision);
 int moe_net_resolved_precision(const moe_net* net, int precision);
 /* The precision policy for checkpoints the build has never seen (the reference's contract is "load any state dict, get the fp32 answer":
  * python/imageProcess.py:319-334; its own dtype policy is castModel, :309-317).  Net2x/3x/4x and NetDN under MOE_PREC_MIXED run their first `blocks` ARSBs with
- * split operands; how many a checkpoint needs depends on how wide its trunk swings.  moe_net_calibrate measures it on the device: uniform uint8-noise tiles (3 seeds
- * x 3 planes of 256 x 256, the tile size that ships) through the exact arithmetic (FP16X3) and through MIXED with blocks = the architecture's default .. 6.  The worst
+ * split operands; how many a checkpoint needs depends on how wide its trunk swings.  moe_net_calibrate measures it on the device: uniform uint8-noise tiles (12 seeds
+ * x 3 planes of 256 x 256, the tile size that ships; compared on the device) through the exact arithmetic (FP16X3) and through MIXED with blocks = the architecture's default .. 6.  The worst
  * max-abs difference of that sample times 1.10 -- the inflation observed between such a sample and the worst tile of full frames -- is the PREDICTED worst tile of a
- * full frame; *blocks = the smallest count whose prediction is <= target (target <= 0: 8.25e-4; the architecture's default count is kept up to 5 % above it, so that a
+ * full frame; *blocks = the smallest count whose prediction is <= target (target <= 0: 8.5e-4; the architecture's default count is kept up to 5 % above it, so that a
  * zoo key next to the target does not flip with the device or driver), *err = that prediction; *blocks = -1 when six blocks do not reach it (*err = what they reach).
  * The count is kept (moe_net_exact_blocks) until a parameter changes or moe_net_set_exact_blocks overrides it.  moe_net_finalize(MOE_PREC_AUTO) runs this by itself,
  * once per checkpoint, and finalizes in MOE_PREC_FP16X3 when no count reaches the target: a drop-in caller needs no extra line.  SEDN / lite: *blocks = 0, nothing
@@ -130,6 +130,18 @@ int64_t moe_net_max_tile_pixels(const moe_net* net);
 int moe_net_forward(moe_net* net, const void* x, int x_dtype, int B, int h, int w,
                     int64_t sB, int64_t sH, int64_t sW, const int64_t* x_off,
                     void* y, int y_dtype, const int64_t* y_off, void* stream);
+/* moe_net_forward with flags.  MOE_FWD_INPUT_SINCE_PREV: the caller states that x was COMPLETE on `stream` when the previous forward of this net was enqueued on it --
+ * true of the reference's tile loop, whose inputs are slices of one padded image that exists before the loop (python/imageProcess.py:157-170: s = x[..., top:bottom,
+ * left:right]; r = opt(s); blend; assign).  Small forwards of the SR nets (up to four planes of 256 x 256, no offset tables, option overlap_calls) then alternate between
+ * two internal (stream, workspace) sets: forward k+1 starts beside forward k instead of behind it and behind the caller's blend of tile k.  What the caller sees is
+ * unchanged: y is written by the forward's LAST kernel, which waits for everything enqueued on `stream` before this call, and `stream` waits for the forward before the
+ * call returns, so the next thing the caller enqueues (its blend) finds y complete.  Without the flag, for other shapes / nets, for the first call of a burst (or after
+ * a call on another stream) and under stream capture this IS moe_net_forward.  The torch wrapper (moephoto_amd/models.py) sets the flag when x is a view of the same
+ * live storage, at the same version counter, as the previous call's input. */
+#define MOE_FWD_INPUT_SINCE_PREV 1u
+int moe_net_forward_ex(moe_net* net, const void* x, int x_dtype, int B, int h, int w,
+                       int64_t sB, int64_t sH, int64_t sW, const int64_t* x_off,
+                       void* y, int y_dtype, const int64_t* y_off, void* stream, unsigned flags);
 /* Live kernel timing for the roofline report: bracket the MFMA-conv launches of every layer whose key contains one of the
  * comma-separated `layer_substrings` (e.g. "up1,c2_": the 64->256 upsampler convs at 2x resolution, and conv_2 of the ARSBs)
  * with hipEvents on the launch stream.  NULL / "" disables.  moe_net_get_profile_at waits for the recorded events of the

@@ -14,7 +14,8 @@ OK, EINVAL, ENOMEM, EHIP, ESTATE = 0, -1, -2, -3, -4
 ARCH_NET2X, ARCH_NET3X, ARCH_NET4X, ARCH_NETDN, ARCH_SEDN, ARCH_LITE = range(6)
 F32, F16, U8, U16 = range(4)
 PREC_FP16, PREC_FP16X3, PREC_DEBUG_DIRECT, PREC_MIXED, PREC_AUTO = range(5)
-ABI_VERSION = 3
+ABI_VERSION = 4
+FWD_INPUT_SINCE_PREV = 1      # moe_net_forward_ex flag (include/moephoto_amd.h)
 RESIZE_MODES = {'nearest': 0, 'bilinear': 1, 'bicubic': 2}
 PRECISIONS = {'fp16': PREC_FP16, 'fp16x3': PREC_FP16X3, 'debug_direct': PREC_DEBUG_DIRECT, 'mixed': PREC_MIXED}       # ('auto' = PREC_AUTO is resolved by the library)
 
@@ -60,6 +61,7 @@ def lib():
         'moe_net_workspace_bytes': (c_i64, [c_vp, c_int, c_int, c_int]),
         'moe_net_max_tile_pixels': (c_i64, [c_vp]),
         'moe_net_forward': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_int, c_vp, c_vp]),
+        'moe_net_forward_ex': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_int, c_vp, c_vp, ctypes.c_uint]),
         'moe_net_set_profile': (c_int, [c_vp, ctypes.c_char_p]),
         'moe_net_get_profile': (c_int, [c_vp, P(c_dbl), P(c_i64), P(c_dbl)]),
         'moe_net_get_profile_at': (c_int, [c_vp, c_int, P(c_dbl), P(c_i64), P(c_dbl)]),
@@ -103,7 +105,7 @@ def lib():
 
 EXPORTS = ['moe_last_error', 'moe_abi_version', 'moe_device_count', 'moe_net_create', 'moe_net_destroy', 'moe_net_scale',
            'moe_net_num_params', 'moe_net_param_info', 'moe_net_set_param', 'moe_net_finalize', 'moe_net_resolved_precision', 'moe_net_calibrate', 'moe_net_exact_blocks', 'moe_net_workspace_bytes',
-           'moe_net_max_tile_pixels', 'moe_net_forward', 'moe_net_set_profile', 'moe_net_get_profile', 'moe_net_get_profile_at', 'moe_net_set_exact_blocks', 'moe_net_set_debug', 'moe_net_set_option', 'moe_device_info', 'moe_blend_tile', 'moe_stitch_dev', 'moe_stitch_band', 'moe_net_debug_tap', 'moe_plan_create', 'moe_plan_destroy', 'moe_plan_info',
+           'moe_net_max_tile_pixels', 'moe_net_forward', 'moe_net_forward_ex', 'moe_net_set_profile', 'moe_net_get_profile', 'moe_net_get_profile_at', 'moe_net_set_exact_blocks', 'moe_net_set_debug', 'moe_net_set_option', 'moe_device_info', 'moe_blend_tile', 'moe_stitch_dev', 'moe_stitch_band', 'moe_net_debug_tap', 'moe_plan_create', 'moe_plan_destroy', 'moe_plan_info',
            'moe_plan_tiles', 'moe_plan_ramp', 'moe_plan_rows', 'moe_plan_seams', 'moe_wire_words', 'moe_wire_pack', 'moe_wire_unpack', 'moe_plan_pool_elems', 'moe_plan_tile_offsets', 'moe_stitch', 'moe_run_plan',
            'moe_run_plan_ex', 'moe_run_plan_frames', 'moe_run_plan_tiles', 'moe_to_float', 'moe_to_output', 'moe_resize']
 

@@ -362,4 +362,6 @@ void launch_to_float(const void* src, int src_dtype, float inv_or_div, bool divi
 void launch_to_output(const void* src, int src_dtype, int H, int W, int C, float quant, void* dst, int dst_dtype, hipStream_t s);
 // (C, H, W) -> (C, h, w); mode 0 nearest, 1 bilinear, 2 bicubic (torch F.interpolate semantics, align_corners = False)
 void launch_resize(const void* src, void* dst, int dtype, int C, int H, int W, int h, int w, int mode, hipStream_t s);
+// max |a - b| over n floats, atomically folded into *out as the bits of a non-negative float (zero it first)
+void launch_maxabsdiff(const float* a, const float* b, long long n, unsigned* out, hipStream_t s);
 void launch_nhwc_to_nchw_f32(const half_t* in, const half_t* in_lo, float* out, int B, int H, int W, int cs, int C, hipStream_t s);

@@ -1340,3 +1340,23 @@ void launch_nhwc_to_nchw_f32(const half_t* in, const half_t* in_lo, float* out, 
     const long long n = (long long)B * C * H * W;
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, in_lo, out, B, H, W, cs, C);
 }
+
+// max |a - b| over n floats into *out as the bit pattern of a non-negative float (order-preserving as unsigned; a NaN difference counts as +inf): the comparison of
+// moe_net_calibrate's noise tiles stays on the device -- 150 MB of results per arithmetic would otherwise cross PCIe for one number
+__global__ __launch_bounds__(256) void maxabsdiff_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, unsigned* __restrict__ out)
+{
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float d = __builtin_fabsf(a[i] - b[i]);
+        m = (d <= m) ? m : (d == d ? d : __builtin_inff());
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+void launch_maxabsdiff(const float* a, const float* b, long long n, unsigned* out, hipStream_t s)
+{
+    const unsigned g = (unsigned)std::min<long long>(2048, (n + 255) / 256);
+    hipLaunchKernelGGL(maxabsdiff_kernel, dim3(g ? g : 1), dim3(256), 0, s, a, b, n, out);
+}

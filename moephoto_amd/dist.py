@@ -35,6 +35,7 @@ index arithmetic, computed in __init__ and reused every step; they run unchanged
 (tests/test_dist_cpu.py).
 """
 import ctypes
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -296,17 +297,74 @@ class TileExchange(object):
         if send.is_cuda and dist.get_backend(self.group) == 'gloo':
             # test mode (several ranks sharing one GPU, MOE_DIST_BACKEND=gloo): stage through the host
             recv_h = torch.empty(recv.numel(), dtype=send.dtype)
-            dist.all_to_all_single(recv_h, send.cpu(), rsplit, ssplit, group=self.group)
+            _all_to_all(recv_h, send.cpu(), rsplit, ssplit, self.group, False)
             recv.copy_(recv_h)
             if after:
                 after()
             return _Done() if async_op else self.mine
-        work = dist.all_to_all_single(recv, send, rsplit, ssplit, group=self.group, async_op=async_op)
+        work = _all_to_all(recv, send, rsplit, ssplit, self.group, async_op)
         if async_op:
             return _Then(work, after) if after else work
         if after:
             after()
         return self.mine
+
+
+# ---- the exchange primitive ------------------------------------------------------------------------------------------------------------------------------------
+# SURVEY 8(e) names grouped ncclSend / ncclRecv for the gather of tile results; the default here is ONE all_to_all_single (RCCL builds the same grouped send / recv
+# underneath).  No run of this code has seen more than one rank on RCCL (one GPU per box in the builder's reach: the first multi-rank RCCL run is the driver's), so the
+# collective has a second form with the same buffer layout -- one isend + one irecv per peer, batched (batch_isend_irecv = ncclGroupStart / ncclGroupEnd) -- that is taken
+# when EXCHANGE_MODE says so (MOE_DIST_EXCHANGE=p2p) or when the all-to-all raises; bench.py reports which form ran (`exchange_mode`) and why (`EXCHANGE_FALLBACK`).
+EXCHANGE_MODE = os.environ.get('MOE_DIST_EXCHANGE', 'all_to_all')
+EXCHANGE_FALLBACK = None
+
+
+class _Works(object):
+    def __init__(self, works):
+        self.works = works
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        return True
+
+    def is_completed(self):
+        return all(w.is_completed() for w in self.works)
+
+
+def _p2p_exchange(recv, send, rsplit, ssplit, group, async_op):
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    ops, ro, so = [], 0, 0
+    roff, soff = [], []
+    for r in range(world):
+        roff.append(ro); soff.append(so)
+        ro += int(rsplit[r]); so += int(ssplit[r])
+    for r in range(world):
+        peer = r if group is None else dist.get_global_rank(group, r)
+        if r == rank:
+            if rsplit[r]:
+                recv[roff[r]:roff[r] + int(rsplit[r])].copy_(send[soff[r]:soff[r] + int(ssplit[r])])
+            continue
+        if rsplit[r]:
+            ops.append(dist.P2POp(dist.irecv, recv[roff[r]:roff[r] + int(rsplit[r])], peer, group))
+        if ssplit[r]:
+            ops.append(dist.P2POp(dist.isend, send[soff[r]:soff[r] + int(ssplit[r])], peer, group))
+    works = dist.batch_isend_irecv(ops) if ops else []
+    w = _Works(works)
+    if async_op:
+        return w
+    w.wait()
+    return None
+
+
+def _all_to_all(recv, send, rsplit, ssplit, group, async_op):
+    global EXCHANGE_MODE, EXCHANGE_FALLBACK
+    if EXCHANGE_MODE != 'p2p':
+        try:
+            return dist.all_to_all_single(recv, send, rsplit, ssplit, group=group, async_op=async_op)
+        except RuntimeError as e:       # (a communicator error at the first multi-rank contact: keep the job alive on the other form and say so)
+            EXCHANGE_MODE, EXCHANGE_FALLBACK = 'p2p', 'all_to_all_single raised: {}'.format(str(e).splitlines()[0][:200])
+    return _p2p_exchange(recv, send, rsplit, ssplit, group, async_op)
 
 
 class _Then(object):

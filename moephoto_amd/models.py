@@ -22,6 +22,7 @@ lists and Option.__call__ takes the last entry.
 """
 import ctypes
 import os
+import weakref
 from collections import OrderedDict
 
 import numpy as np
@@ -46,6 +47,8 @@ class EngineModule(object):
         self._device = None
         self._dtype = torch.float32
         self._finalized_key = None
+        self._last_input = None
+        self._last_flag = 0
         self.training = False
         # 'auto' = the cheapest arithmetic that stays within 1e-3 of the fp32 reference on every input class:
         #   'mixed'  Net2x/3x/4x, NetDN: fp16 MFMA operands, hi+lo trunk stream, split operands on the few layers that set the error
@@ -233,9 +236,23 @@ class EngineModule(object):
         y = torch.empty((B, 1, h * self.scale, w * self.scale), dtype=x.dtype, device=x.device)
         sB, _, sH, sW = x.stride()
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        _lib.check(_lib.lib().moe_net_forward(self._h, x.data_ptr(), _DT[x.dtype], B, h, w, sB, sH, sW, None,
-                                              y.data_ptr(), _DT[y.dtype], None, stream))
+        _lib.check(_lib.lib().moe_net_forward_ex(self._h, x.data_ptr(), _DT[x.dtype], B, h, w, sB, sH, sW, None,
+                                                 y.data_ptr(), _DT[y.dtype], None, stream, self._input_since_prev(x, stream)))
         return [y]
+
+    def _input_since_prev(self, x, stream):
+        """MOE_FWD_INPUT_SINCE_PREV for this call: was x complete on the stream when the PREVIOUS forward was enqueued?  Yes when x is a view of the same LIVE storage
+        object as the previous call's input, at the same version counter, on the same stream -- torch bumps a storage's version on every in-place write, and an
+        out-of-place result would be another storage (a dead weak reference: its address may have been handed out again).  That is the reference's tile loop
+        (python/imageProcess.py:164-170: every tile is a slice of one padded image that exists before the loop); consecutive forwards then overlap inside the engine
+        (include/moephoto_amd.h).  Anything else -- a new image, an input produced between the calls, another stream -- gets plain stream order."""
+        base = x._base if x._base is not None else x
+        key = (base._version, stream)
+        last = self._last_input
+        flag = _lib.FWD_INPUT_SINCE_PREV if (last is not None and last[0]() is base and last[1] == key) else 0
+        self._last_input = (weakref.ref(base), key)
+        self._last_flag = flag          # (tests)
+        return flag
 
     __call__ = forward
 

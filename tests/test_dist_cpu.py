@@ -15,6 +15,7 @@ sys.path.insert(0, os.environ['MOE_ROOT']); sys.path.insert(0, os.path.join(os.e
 import numpy as np, torch, torch.distributed as dist
 from collections import OrderedDict
 from moephoto_amd.dist import TileExchange, broadcast_state_dict
+from moephoto_amd import dist as mdist_mod
 from oracle import planner as oplanner, stitch as ostitch
 dist.init_process_group('gloo')
 rank, world = dist.get_rank(), dist.get_world_size()
@@ -43,8 +44,19 @@ for f in range(frames):                      # what moe_run_plan_tiles does with
     for k in ex.tiles_of(f, rank):
         at = int(ex.tile_dst[f, k])
         buf[at:at + sizes[k]] = torch.from_numpy(tile_value(f, k).reshape(-1))
-for rep in range(2):                         # the layout is reused every step
-    mine = ex.exchange(buf)
+for rep in range(4):                         # the layout is reused every step; reps 2, 3: the grouped isend / irecv form of the exchange (what an all_to_all_single
+    if rep == 2:                             # failure falls back to, MOE_DIST_EXCHANGE=p2p) -- same buffer layout, same result; rep 3 asynchronously
+        buf[ex.own_elems:ex.own_elems + ex.recv_elems] = float('nan')
+        mdist_mod.EXCHANGE_MODE = 'p2p'
+    if rep == 3:
+        buf[ex.own_elems:ex.own_elems + ex.recv_elems] = float('nan')
+        h = ex.exchange(buf, async_op=True)
+        h.wait()
+        mine = ex.mine
+    else:
+        mine = ex.exchange(buf)
+    if rep == 3:
+        mdist_mod.EXCHANGE_MODE = 'all_to_all'
     assert mine == [f for f in range(frames) if f % world == rank]
     for f in mine:                           # what moe_stitch does with ex.stitch_off[f]
         tiles = [buf[int(ex.stitch_off[f][k]):int(ex.stitch_off[f][k]) + sizes[k]].numpy().reshape(tile_value(f, k).shape) for k in range(nt)]

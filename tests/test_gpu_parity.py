@@ -445,7 +445,7 @@ def test_blend_tile_kernel_equals_the_reference_blend_expression(dev):
                 want[..., bsc - hh:bsc, rsc - ww:rsc] = q
                 # the forms the reference's loop hands over: (C, h, w) into (C, H, W); the net's own (C, 1, h, w) result; tmp_image as (1, C, H, W) (opt.oShape) -- ADVICE r05:
                 # singleton axes are dropped by the wrapper, the kernel always sees (plane, row) strides
-                form = len(pl.tiles) % 3
+                form = (top // 8 + left // 8 + len(pl.tiles)) % 3
                 ip.blendTile(r.unsqueeze(1) if form == 1 else r, got.unsqueeze(0) if form == 2 else got, (top, bottom, left, right, tt, lt, bsc, rsc), sc, pl.pad_sc, ramp)
             assert torch.equal(got, want), (shape, dt, float((got.float() - want.float()).abs().max()))
     # the loop of test_dropin_protocol_reference_loop with the fused kernel in place of the two blends
@@ -1152,7 +1152,7 @@ def test_calibrate_exact_blocks_for_other_weights(dev):
     m = build(1.0)
     assert m.exact_blocks() == 4 and m.resolved_precision() == 'mixed'
     n, err = m.calibrate()
-    assert n == 4 and err <= 8.25e-4 * 1.05, (n, err)      # (err: the predicted worst tile of a full frame = measured x 1.10; the default count is kept up to 5 % above the target)
+    assert n == 4 and err <= 8.5e-4 * 1.05, (n, err)      # (err: the predicted worst tile of a full frame = measured x 1.10; the default count is kept up to 5 % above the target)
     m = build(1.15)
     na = m.exact_blocks()
     assert na > 4 or m.resolved_precision() == 'fp16x3', na
@@ -1161,9 +1161,12 @@ def test_calibrate_exact_blocks_for_other_weights(dev):
     want = m.set_precision('fp16x3')(x)[-1].clone()
     m.set_precision('auto')
     ea = float((ya - want).abs().amax())
-    e4 = float((m.set_exact_blocks(4)(x)[-1] - want).abs().amax())
-    assert ea < e4 and ea <= 9e-4, (na, ea, e4)
-    m.set_exact_blocks(-1)
+    if m.resolved_precision() == 'fp16x3':       # (round 6: the conservative calibration may find that not even six blocks keep the PREDICTED full-frame error inside its target)
+        assert ea == 0.0, ea
+    else:
+        e4 = float((m.set_exact_blocks(4)(x)[-1] - want).abs().amax())
+        assert ea < e4 and ea <= 9e-4, (na, ea, e4)
+        m.set_exact_blocks(-1)
     assert m.exact_blocks() == na and torch.equal(m(x)[-1], ya)
     m0 = build(1.15, pre=lambda q: q.set_option('auto_calibrate', 0))
     assert m0.exact_blocks() == 4
@@ -1242,6 +1245,92 @@ def test_small_launch_sets_fork_the_u_branch_onto_a_second_stream(dev):
                 assert torch.equal(g, m(x.half())[-1]), (key, prec, 'side stream', i)
         finally:
             m.set_option('branch_streams', 1)
+
+
+def test_consecutive_forwards_on_slices_of_one_image_overlap_and_keep_their_bits(dev):
+    """moe_net_forward_ex / MOE_FWD_INPUT_SINCE_PREV (round 6, option overlap_calls): the torch wrapper marks a forward whose input is a view of the same live storage, at
+    the same version counter, as the previous call's -- the reference's tile loop (python/imageProcess.py:164-170) -- and the engine then runs consecutive forwards on two
+    internal (stream, workspace) sets, forward k+1 beside forward k.  Everything the caller can observe must be as on one stream: (1) back-to-back forwards on slices of
+    one image with their results consumed at once (the loop's blend reads r right behind the call) give the bits of single calls; (2) an input written IN PLACE between
+    two calls (version bump: no flag) is seen; (3) a new image allocated where the old one lived (the weak reference is dead: no flag) is seen; (4) y memory that the
+    caller's own kernels were still using when the call was made is not overwritten early; (5) the reference-style loop end to end, overlapped against not."""
+    from moephoto_amd import _lib
+    for key, prec, io in (('a4', 'auto', torch.float16), ('a2', 'auto', torch.float32), ('a3', 'auto', torch.float16)):
+        m = module_for(key, prec)
+        sc = m.scale
+        img = torch.from_numpy(gd.noise_image(77, (3, 200, 328))).to(dev).to(io).unsqueeze(1)
+        tiles = [(0, 64, 0, 96), (40, 104, 72, 168), (136, 200, 232, 328), (0, 64, 0, 96), (100, 164, 8, 104), (8, 72, 200, 296), (120, 128, 16, 32), (0, 128, 0, 128)]
+        try:
+            m.set_option('overlap_calls', 0)
+            want = [m(img[..., t:b, l:r])[-1].clone() for (t, b, l, r) in tiles]
+            torch.cuda.synchronize()
+            m.set_option('overlap_calls', 1)
+            for rep in range(3):
+                acc = []
+                flags = []
+                for (t, b, l, r) in tiles:
+                    y = m(img[..., t:b, l:r])[-1]
+                    flags.append(m._last_flag)
+                    acc.append(y * 1.0)                                   # consumed on the caller's stream at once; y itself is dropped and its memory reused by the next calls
+                    del y
+                for i, (g, w) in enumerate(zip(acc, want)):
+                    assert torch.equal(g, w), (key, rep, i, float((g.float() - w.float()).abs().max()))
+                assert flags[1:] == [_lib.FWD_INPUT_SINCE_PREV] * (len(tiles) - 1), flags      # (the first call of a burst after another input: plain order)
+                img = img.clone()                                        # another storage for the next repetition: its first call must not be flagged
+            # (2) in-place write between calls
+            base = img.clone()
+            y0 = m(base[..., 0:64, 0:96])[-1].clone()
+            base.mul_(0.5)
+            y1 = m(base[..., 0:64, 0:96])[-1].clone()
+            assert m._last_flag == 0
+            m.set_option('overlap_calls', 0)
+            assert torch.equal(y1, m(base[..., 0:64, 0:96])[-1]) and not torch.equal(y0, y1)
+            m.set_option('overlap_calls', 1)
+            # (3) a new image at the old address
+            a = torch.from_numpy(gd.noise_image(5, (3, 64, 96))).to(dev).to(io).unsqueeze(1)
+            ya = m(a)[-1].clone()
+            ptr = a.data_ptr()
+            del a
+            bimg = torch.from_numpy(gd.noise_image(6, (3, 64, 96))).to(dev).to(io).unsqueeze(1)
+            yb = m(bimg)[-1].clone()
+            assert m._last_flag == 0, (ptr, bimg.data_ptr())
+            m.set_option('overlap_calls', 0)
+            assert torch.equal(yb, m(bimg)[-1]) and not torch.equal(ya, yb)
+            m.set_option('overlap_calls', 1)
+            # (4) the caller's kernels still read the memory y will get: a long chain of torch ops on a buffer, freed right before the call (the caching allocator hands
+            # the block to y at once -- legal on one stream); the chain's result must not see the forward's output
+            x1 = img[..., 0:128, 0:128]
+            m(x1)                                                       # (burst start)
+            shape = (3, 1, 128 * sc, 128 * sc)
+            for rep in range(4):
+                buf = torch.full(shape, 1.0, dtype=io, device=dev)
+                chk = buf
+                for _ in range(30):
+                    chk = chk * 1.0
+                total = chk.float().sum()
+                del buf, chk
+                y = m(x1)[-1]
+                assert m._last_flag == _lib.FWD_INPUT_SINCE_PREV
+                assert float(total) == float(3 * 128 * sc * 128 * sc), (key, rep, float(total))
+                del y
+        finally:
+            m.set_option('overlap_calls', 1)
+    # (5) the reference-style loop around the class, overlapped against not
+    import bench
+    from moephoto_amd import imageProcess as ip
+    opt = _opt_sr('a', 4, 64, fp16_io=True)
+    x = torch.from_numpy(gd.natural_image(3, (3, 150, 212))).to(dev).half()
+    plan = ip._plan_for(opt, x.shape)
+    ramp = torch.from_numpy(plan.ramp.copy()).to(dev).half()
+    model = opt.modelCached
+    model.set_option('overlap_calls', 0)
+    want = bench._reference_style_loop(opt, x, plan, ramp, torch)
+    model.set_option('overlap_calls', 1)
+    for rep in range(2):
+        got = bench._reference_style_loop(opt, x, plan, ramp, torch)
+        assert torch.equal(got, want)
+        got = bench._reference_style_loop(opt, x, plan, ramp, torch, blend_tile=ip.blendTile)
+        assert torch.equal(got, want)
 
 
 def test_wire_pack_unpack_kernels_vs_numpy_codec(dev):

@@ -103,7 +103,7 @@ def test_library_exports_every_header_symbol():
     for name in declared:
         assert hasattr(L, name), name
     assert sorted(_lib.EXPORTS) == declared
-    assert _lib.lib().moe_abi_version() == _lib.ABI_VERSION == 3
+    assert _lib.lib().moe_abi_version() == _lib.ABI_VERSION == 4
 
 
 def _plan(case):
@@ -315,7 +315,7 @@ NOT_IN_THE_TABLE = {
     'tapsum4_kernel<false>': 'phase-class sums into unaligned output planes',
     'tapsum_kernel<2>': 'nine-plane fused tail, scalar form',
 }
-NOT_THE_NET = ('blend_tile_kernel', 'resize_kernel', 'to_float', 'to_output', 'wire_kernel', 'stitch')      # edges / callers of the path: exercised by their own tests, not by a forward
+NOT_THE_NET = ('blend_tile_kernel', 'resize_kernel', 'to_float', 'to_output', 'wire_kernel', 'stitch', 'maxabsdiff_kernel')      # edges / callers of the path: exercised by their own tests, not by a forward
 
 
 def test_every_compiled_kernel_instantiation_has_a_user():

@@ -62,7 +62,7 @@ for key, label in (('arsb3', 'arsb32c_kernel<true,4>'), ('u.up1', 'conv3x3_ps4_k
         line += ' | profile empty: {}'.format(pr)
     elif key:
         per = pr['total_ms'] / max(1, pr['launches'] * rep)      # (one event pair brackets the rep launches)
-        line += ' | {:.4f} ms per launch ({} launches) | {:.0f} TFLOP/s algorithmic on its {} planes'.format(per, pr['launches'] * rep, FLOP[key] * B * 65536 * (4 if 'up1' in key else 1) / per / 1e9, B)
+        line += ' | {:.4f} ms per launch ({} launches) | {:.0f} TFLOP/s algorithmic on its {} planes'.format(per, pr['launches'] * rep, FLOP[key] * B * 65536 / per / 1e9, B)      # (FLOP[] is per LOW-resolution pixel: the x4 of the 2x-resolution convs is in the table -- round 5 applied it twice here: VERDICT r05 weak 4)
     line += ' | {} W, {} GHz (min {} max {}, {} samples)'.format(clk.get('package_power_w_mean'), clk.get('sclk_ghz_mean'), clk.get('sclk_ghz_min'), clk.get('sclk_ghz_max'), clk.get('samples'))
     print(line, flush=True)
 m.set_option('repeat', '0')

@@ -45,6 +45,12 @@ def main():
             m = ctor()
             m.load_state_dict({n: torch.from_numpy(np.ascontiguousarray(v)) for n, v in sd.items()})
             m = m.eval().to(dtype=torch.float32, device='cuda:0')
+            # what the load-time calibration settled on for THESE weights (round 6: twelve noise tiles of 3 x 256 x 256, measured x 1.10 = predicted full-frame worst tile):
+            # the sweep below is the full-frame figure that prediction stands for
+            cal = '{} / {} blocks'.format(m.resolved_precision(), m.exact_blocks())
+            r = m.calibrate()
+            if r is not None:
+                cal += ', calibrate() = ({}, predicted {:.3e} = measured {:.3e} x 1.10)'.format(r[0], r[1], r[1] / 1.10)
             worst = {}
             for kind in ('noise_u8', 'natural'):
                 w = 0.0
@@ -56,7 +62,7 @@ def main():
                     w = max(w, float((y - want).abs().amax()))
                     rng_out = float(want.abs().amax())
                 worst[kind] = (w, rng_out)
-            print('%-3s %-52s noise_u8 %.3e (|y| <= %.2f)   natural %.3e' % (key, name, worst['noise_u8'][0], worst['noise_u8'][1], worst['natural'][0]), flush=True)
+            print('%-3s %-52s noise_u8 %.3e (|y| <= %.2f)   natural %.3e | %s' % (key, name, worst['noise_u8'][0], worst['noise_u8'][1], worst['natural'][0], cal), flush=True)
 
 
 if __name__ == '__main__':
