@@ -425,6 +425,13 @@ def main():
         dtl = timed(None, n_l, loop)
         ms_l = dtl / n_l * 1e3
         ms_f = timed(None, n_l, loop_fused) / n_l * 1e3
+        # round 6: the wrapper marks forwards on slices of one image (moe_net_forward_ex, MOE_FWD_INPUT_SINCE_PREV) and the engine overlaps them; the same loop with the
+        # option off is what rounds 4-5 measured
+        model.set_option('overlap_calls', 0)
+        y_plain = loop(None)
+        ms_l0 = timed(None, n_l, loop) / n_l * 1e3
+        ms_f0 = timed(None, n_l, loop_fused) / n_l * 1e3
+        model.set_option('overlap_calls', 1)
         # where the loop's time goes: the 40 forwards alone (results dropped), and the blends + assigns alone (on kept tile results)
         xb_ = plan.padImage(xin).unsqueeze(1)
 
@@ -459,6 +466,10 @@ def main():
                                             'note': 'host-inclusive wall per frame, synchronised at both ends; engine_forwards_only = the 40 per-tile calls of 3 planes each with '
                                                     'the results dropped: what separates it from the headline is launch geometry (3 planes per launch set instead of up to 96); '
                                                     'rocprofv3 kernel trace of the loop: profiles/r05/'},
+                              'without_overlap_calls': {'ms_per_step': round(ms_l0, 3), 'ratio_to_value': round(ms_per_step / ms_l0, 3), 'with_moe_blend_tile_ms': round(ms_f0, 3),
+                                                        'bit_identical_to_overlapped': bool(torch.equal(y_plain, y_loop)),
+                                                        'what': 'option overlap_calls = 0: every forward on the caller\'s stream, behind the previous tile\'s blend (rounds 4-5); default since round 6: '
+                                                                'consecutive forwards on slices of one image run on two internal stream + workspace sets (moe_net_forward_ex)'},
                               'with_moe_blend_tile': {'value': round(FRAME[1] * FRAME[2] / 1e6 / (ms_f / 1e3), 3), 'ms_per_step': round(ms_f, 3), 'ratio_to_value': round(ms_per_step / ms_f, 3),
                                                       'blend_tile_only_ms': round(ms_bf, 3),
                                                       'max_abs_vs_device_docrop': float('{:.3e}'.format(float((y_fused.float() - y_dev.float()).abs().max()))),
@@ -566,7 +577,7 @@ def main():
             'value_floor_ms': {k: v['ms_per_step'] for k, v in (res['config'].get('value_floor') or {}).items() if isinstance(v, dict)},
             'kernels_ms_per_frame_and_frac': {k: [v['ms_per_frame'], v['frac']] for k, v in rk.items()},
             'split_operand_ms': (res.get('roofline_split_operand') or {}).get('ms_per_frame'),
-            'dropin_ratio': dl.get('ratio_to_value'), 'dropin_overlap_ratio': (dl.get('with_overlap_calls') or {}).get('ratio_to_value'),
+            'dropin_ratio': dl.get('ratio_to_value'), 'dropin_ratio_without_overlap_calls': (dl.get('without_overlap_calls') or {}).get('ratio_to_value'),
             'dropin_blend_tile_ratio': (dl.get('with_moe_blend_tile') or {}).get('ratio_to_value'),
             'configs_ms': {k: v.get('ms_per_step') for k, v in (res.get('configs') or {}).items() if isinstance(v, dict)},
             'parity_max_abs_vs_oracle': res['config'].get('parity_max_abs_vs_oracle'), 'sustained_ms': (res.get('sustained') or {}).get('ms_per_step'),

@@ -119,7 +119,13 @@ struct NetOptions {
                               //             ONE padded image, python/imageProcess.py:164-170) alternate between two internal (stream, workspace) sets: forward k+1 starts beside forward k
                               //             instead of behind it and the caller's blend; only its LAST kernel (the one that writes y) waits for the caller's stream | 0: every forward on
                               //             the caller's stream
-    int overlap_groups = 0;   // overlap_groups  persistent workgroups per launch of such a forward (0: all of them; e.g. 128: two forwards in flight on half the chip each)
+    int overlap_fork = 0;     // overlap_fork   0 (default): such a forward does not fork its U branch onto a side stream as well -- two forwards in flight ARE the second stream | 1: it does
+    int overlap_groups = 0;   // overlap_groups  persistent workgroups per launch of such a forward; 0 (default): half of the CUs -- two forwards in flight on half the chip each.
+                              //             Measured on the reference-style loop of bench.py (profiles/r06/d_dropin_overlap_queues.txt; option off: 29.4 ms = 0.86 of the headline):
+                              //             fork 0 / 128 groups 28.5 ms (0.89; 27.6 = 0.92 with moe_blend_tile), fork 1 / all groups 28.4 (0.89; 28.1), fork 0 / all groups 29.4,
+                              //             fork 1 / 128 groups 35.8; GPU_MAX_HW_QUEUES = 8 or 16 instead of HIP's 4: 36-39 ms.  The chip is saturated either way: what separates the
+                              //             loop from the device-resident path is the fixed cost of forty 3-plane launch sets (weight preloads, ramp-up and tail of every kernel), which
+                              //             two forwards in flight hide only in part
     int calib_log = 0;        // calib_log   1: moe_net_calibrate prints every count's measured and predicted error to stderr (tools/calib_report.py)
     int auto_calibrate = 1;   // auto_calibrate  1 (default): moe_net_finalize(MOE_PREC_AUTO) measures the count of split-operand ARSBs on the loaded weights | 0: per-architecture defaults
     int exact_blocks_env = -1;   // MOE_EXACT_BLOCKS (moe_net_set_exact_blocks overrides)
@@ -156,6 +162,7 @@ struct NetOptions {
         if (key == "s64") { const int t = onoff(v); if (t < 0) return false; s64 = t; return true; }
         if (key == "auto_calibrate") { const int t = onoff(v); if (t < 0) return false; auto_calibrate = t; return true; }
         if (key == "overlap_calls") { const int t = onoff(v); if (t < 0) return false; overlap_calls = t; return true; }
+        if (key == "overlap_fork") { const int t = onoff(v); if (t < 0) return false; overlap_fork = t; return true; }
         if (key == "overlap_groups") { const int t = atoi(v); if (t < 0) return false; overlap_groups = t; return true; }
         if (key == "calib_log") { const int t = onoff(v); if (t < 0) return false; calib_log = t; return true; }
         if (key == "branch_groups") { branch_groups = atoi(v); return branch_groups >= 0; }
@@ -191,7 +198,7 @@ struct NetOptions {
     void from_env()
     {
         static const char* const names[][2] = {{"MOE_CONV_IMPL", "conv_impl"}, {"MOE_SP_IMPL", "sp_impl"}, {"MOE_TAIL_SPLIT", "tail_split"}, {"MOE_TAIL_FORM", "tail_form"}, {"MOE_UP_IMPL", "up_impl"},
-                                               {"MOE_CONV1X1", "conv1x1"}, {"MOE_Q8_IMPL", "q8_impl"}, {"MOE_EXACT_FUSE", "exact_fuse"}, {"MOE_BRANCH_STREAMS", "branch_streams"}, {"MOE_BRANCH_GROUPS", "branch_groups"}, {"MOE_AUTO_CALIBRATE", "auto_calibrate"}, {"MOE_OVERLAP_CALLS", "overlap_calls"}, {"MOE_OVERLAP_GROUPS", "overlap_groups"}, {"MOE_S64", "s64"}, {"MOE_K48", "k48"}, {"MOE_X3_IMPL", "x3_impl"}, {"MOE_LO8", "lo8"}, {"MOE_X3_FUSE", "x3_fuse"}, {"MOE_ARSB_FUSE", "arsb_fuse"}, {"MOE_FUSE_TAIL", "fuse_tail"},
+                                               {"MOE_CONV1X1", "conv1x1"}, {"MOE_Q8_IMPL", "q8_impl"}, {"MOE_EXACT_FUSE", "exact_fuse"}, {"MOE_BRANCH_STREAMS", "branch_streams"}, {"MOE_BRANCH_GROUPS", "branch_groups"}, {"MOE_AUTO_CALIBRATE", "auto_calibrate"}, {"MOE_OVERLAP_CALLS", "overlap_calls"}, {"MOE_OVERLAP_GROUPS", "overlap_groups"}, {"MOE_OVERLAP_FORK", "overlap_fork"}, {"MOE_S64", "s64"}, {"MOE_K48", "k48"}, {"MOE_X3_IMPL", "x3_impl"}, {"MOE_LO8", "lo8"}, {"MOE_X3_FUSE", "x3_fuse"}, {"MOE_ARSB_FUSE", "arsb_fuse"}, {"MOE_FUSE_TAIL", "fuse_tail"},
                                                {"MOE_SEDN_FUSE", "sedn_fuse"}, {"MOE_POOL_FUSE", "pool_fuse"}, {"MOE_DBG", "dbg"}, {"MOE_TRACE_KEY", "trace_key"},
                                                {"MOE_TILES_PER_BATCH", "tiles_per_batch"}, {"MOE_MAX_GROUPS", "max_groups"}};
         for (const auto& nv : names)
@@ -1971,9 +1978,12 @@ static int forward_pipelined(moe_net* n, const void* x, int x_dtype, int B, int 
     auto swap_set = [&]() { std::swap(n->ws, ps.ws); std::swap(n->ws_bytes, ps.ws_bytes); std::swap(n->side, ps.side); std::swap(n->ev_fork, ps.ev_fork); std::swap(n->ev_join, ps.ev_join); };
     swap_set();
     const int groups0 = n->max_groups;
-    if (n->opt.overlap_groups > 0) n->max_groups = std::max(16, std::min(n->opt.overlap_groups, groups0));
+    n->max_groups = n->opt.overlap_groups > 0 ? std::max(16, std::min(n->opt.overlap_groups, groups0)) : std::max(16, groups0 / 2);
     n->out_gate = since_prev ? ps.entry : nullptr;
+    const int fork0 = n->opt.branch_streams;
+    if (!n->opt.overlap_fork) n->opt.branch_streams = 0;
     const int rc = forward_dev(*n, x, x_dtype, B, h, w, sB, sH, sW, nullptr, y, y_dtype, nullptr, ps.main, true);
+    n->opt.branch_streams = fork0;
     n->out_gate = nullptr;
     n->max_groups = groups0;
     swap_set();

@@ -68,6 +68,13 @@ def wino_conv(v, w, b, mode='v1'):
     `v` is expected to hold fp16 values already.  mode 'v1': V formed in fp32, one rounding; 'v2': two 1-D passes in fp16 arithmetic (a rounding after
     each); 'v32': nothing rounded (checks the transform itself)."""
     Bn, C, H, W = v.shape
+    if mode == 'x1':        # F(2, 3) along x only, the three rows of the kernel as direct taps (round 6 study: 1.5x fewer MFMAs, one 1-D transform each side)
+        d = F.pad(v, (1, 1, 1, 1)).unfold(3, 4, 2)                      # (B, C, H + 2, W/2, 4)
+        V = r16(torch.einsum('bchwk,lk->bchwl', d, _WBT))               # (B, C, H + 2, W/2, 4 positions)
+        U = r16(torch.einsum('ocjk,lk->ocjl', w, _WG))                  # (O, C, 3 rows, 4 positions)
+        M = sum(torch.einsum('ocl,bchwl->bohwl', U[:, :, dy], V[:, :, dy:dy + H]) for dy in range(3))
+        Y = torch.einsum('bohwk,lk->bohwl', M, _WAT).reshape(Bn, w.shape[0], H, W)
+        return Y if b is None else Y + b.view(1, -1, 1, 1)
     d = F.pad(v, (1, 1, 1, 1)).unfold(2, 4, 2).unfold(3, 4, 2)          # (B, C, H/2, W/2, 4, 4)
     if mode == 'v2':
         V = r16(torch.einsum('bchwik,lk->bchwil', r16(torch.einsum('ij,bchwjk->bchwik', _WBT, d)), _WBT))
@@ -271,6 +278,25 @@ def main(argv):
     cmd = argv[1] if len(argv) > 1 else 'budget'
     if cmd == 'lite':
         lite_budget(tuple(argv[2:]) or ('lite2', 'lite4', 'lite8'))
+        return
+    if cmd == 'wino1d':     # the same study for F(2, 3) along x only (wino_conv mode 'x1')
+        for key in (argv[2:] or ['a4']):
+            arch, sd = gd.MODELS[key][0], _load(key)
+            ups = [l for l in layer_names(arch) if '.up' in l]
+            for kind, shape, seed in (('noise-u8', (3, 256, 256), 0), ('noise-u8', (3, 256, 256), 1), ('noise-u8', (3, 256, 256), 2), ('natural', (3, 40, 264), 5)):
+                x = gd.natural_image(seed, shape) if kind == 'natural' else gd.noise_u8(seed, shape).astype(np.float32) / 255.0
+                x = x[:, None]
+                with torch.no_grad():
+                    want = forward(arch, sd, x)
+                    n = DEFAULT_EXACT[arch]
+                    ex = ['input2'] + ['c%d_%d' % (j, i) for i in range(1, n + 1) for j in (1, 2)]
+                    w16, a16, s16 = mode_sets(arch, 'mixed', n)
+                    line = '%-4s %-8s seed %d n=%d: direct %.3e' % (key, kind, seed, n, float((forward(arch, sd, x, w16, a16, s16, corr8=ex, lo8=True) - want).abs().max()))
+                    for tag, ws in (('R up1', ['r.up1']), ('U up1', ['u.up1']), ('U up0 + up1', [u for u in ups if u.startswith('u.')]), ('R + U up1', ['r.up1', 'u.up1']), ('all four', ups)):
+                        ws = [u for u in ws if u in ups]
+                        e = float((forward(arch, sd, x, w16, a16, s16, corr8=ex, lo8=True, wino=ws, wino_mode='x1') - want).abs().max())
+                        line += ' | 1-D Winograd on %s %.3e' % (tag, e)
+                    print(line, flush=True)
         return
     if cmd == 'wino':       # the upsampler convs as Winograd F(2x2, 3x3) with fp16 U and V (2.25x fewer MFMAs): what would it cost in precision, per branch?
         for key in (argv[2:] or ['a4']):

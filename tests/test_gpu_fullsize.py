@@ -201,6 +201,83 @@ def _time_ms(fn, reps=3):
     return e0.elapsed_time(e1) / reps
 
 
+def test_perturbed_checkpoints_hold_the_contract_against_the_oracle(dev):
+    """VERDICT r05 item 5b.  The checkpoints of tools/margin_sweep.py that came closest to the contract -- every conv weight of a4 / a2 plus Gaussian noise of 10 % of its
+    tensor's rms, seed 2: 8.3-8.8e-4 against the engine's exact mode on full frames, with a calibration that had aimed at 7.5e-4 on two small tiles -- through the documented
+    path (load_state_dict, .to(device): moe_net_finalize(MOE_PREC_AUTO) calibrates on twelve 256 x 256 noise tiles and keeps a count whose PREDICTED full-frame error is
+    inside its target), held against the fp32 ORACLE on four full-size uint8-noise tiles each: worst <= 1e-3.  The prediction itself is recorded beside the result."""
+    from moephoto_amd import models
+    res = {}
+    for key, ctor, oname, seeds in (('a4', models.Net4x, 'net4x', (0, 1, 2, 3)), ('a2', models.Net2x, 'net2x', (0, 1, 2, 3))):
+        sd0 = gd.state_dict_for(key, load_state_dict_file)
+        rng = np.random.default_rng(2)
+        sd = dict(sd0)
+        for k in sd0:                                    # (the variant generator of tools/margin_sweep.py, seed 2)
+            if sd0[k].ndim == 4:
+                sd[k] = (sd0[k] + rng.standard_normal(sd0[k].shape).astype(np.float32) * np.float32(0.1 * np.sqrt(np.mean(sd0[k] ** 2)))).astype(np.float32)
+        m = ctor()
+        m.load_state_dict({n: torch.from_numpy(np.ascontiguousarray(v)) for n, v in sd.items()})
+        m = m.eval().to(dtype=torch.float32, device=dev)
+        cal = m.calibrate()
+        errs = []
+        for seed in seeds:
+            x = gd.noise_u8(seed, (3, 256, 256)).astype(np.float32)[:, None] / np.float32(255)
+            y = m(torch.from_numpy(x).to(dev))[-1].cpu().numpy()
+            want = onets.forward(oname, sd, x).numpy()
+            errs.append(float(np.abs(y - want).max()))
+        res[key] = {'precision': m.resolved_precision(), 'exact_blocks': m.exact_blocks(), 'calibrate': cal, 'max_abs_vs_oracle_per_tile': [float('{:.3e}'.format(e)) for e in errs]}
+        assert max(errs) <= TOL, (key, res[key])
+    _report('perturbed_checkpoints_vs_oracle', res)
+
+
+# ---- timing floors: a regression of a family's frame time fails a test instead of waiting for a census (VERDICT r05 item 6: lite8's 3x slow-down shipped with green tests) ----
+# ms per 1080p frame (256-px tiles, fp16 I/O, default arithmetic) measured on the round's boxes, x 1.5: boxes differ by 5-8 %, the kernels run at the package power cap
+FRAME_MS_CEILING = {'SR a2': 13.8 * 1.5, 'SR a3': 20.0 * 1.5, 'SR a4': 24.6 * 1.5, 'SR lite2': 12.8 * 1.5, 'SR lite4': 21.6 * 1.5, 'SR lite8': 57.0 * 1.5, 'DN lite5': 9.7 * 1.5, 'DN lite10': 9.7 * 1.5,
+                    'DN l25': 31.4 * 1.5}
+
+
+def test_frame_time_floors_per_family(dev):
+    """One 1080p frame per model family through doCrop (the plugin tables, 256-px tiles, fp16 I/O, default arithmetic), timed: at most 1.5x the round's measured figure.
+    Generous on purpose -- it is there to catch a family falling onto a fallback kernel (round 5: lite8's last stages on the generic 64-bit kernel, 27 ms a launch)."""
+    from moephoto_amd import imageProcess as ip, runDN, runSR
+    from moephoto_amd.config import config
+    config.deviceId, config.fp16, config.crop_sr, config.crop_dn, config.crop_dns, config.modelRoot = 0, True, 256, 256, 256, gd.ZOO
+    for key in ('a4', 'a3'):
+        path = '/tmp/moe_tf_{}.pth'.format(key)
+        save_state_dict_file(gd.synth_state_dict(key, load_state_dict_file), path)
+        runSR.mode_switch[key] = (path, runSR.mode_switch[key][1])
+    path = '/tmp/moe_tf_l25.pth'
+    save_state_dict_file(gd.synth_state_dict('l25', load_state_dict_file), path)
+    dn25 = runDN.mode_switch['25']
+    runDN.mode_switch['25'] = (path,) + tuple(dn25[1:])
+    x = torch.from_numpy(gd.natural_image(1000, (3, 1080, 1920))).to(dev).half()
+    cases = [('SR a2', lambda: runSR.getOpt({'model': 'a', 'scale': 2})), ('SR a3', lambda: runSR.getOpt({'model': 'a', 'scale': 3})),
+             ('SR a4', lambda: runSR.getOpt({'model': 'a', 'scale': 4})), ('SR lite2', lambda: runSR.getOpt({'model': 'lite', 'scale': 2})),
+             ('SR lite4', lambda: runSR.getOpt({'model': 'lite', 'scale': 4})), ('SR lite8', lambda: runSR.getOpt({'model': 'lite', 'scale': 8})),
+             ('DN lite5', lambda: runDN.getOpt({'model': 'lite5'})), ('DN lite10', lambda: runDN.getOpt({'model': 'lite10'})), ('DN l25', lambda: runDN.getOpt({'model': '25'}))]
+    got = {}
+    try:
+        for name, mk in cases:
+            ip.modelCache.clear()
+            opt = mk()
+            for _ in range(2):
+                ip.doCrop(opt, x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                ip.doCrop(opt, x)
+            torch.cuda.synchronize()
+            got[name] = (time.perf_counter() - t0) / 3 * 1e3
+            del opt
+            torch.cuda.empty_cache()
+    finally:
+        runDN.mode_switch['25'] = dn25
+        ip.modelCache.clear()
+    _report('frame_ms_per_family', {k: round(v, 2) for k, v in got.items()})
+    slow = {k: (round(v, 2), round(FRAME_MS_CEILING[k], 1)) for k, v in got.items() if v > FRAME_MS_CEILING[k]}
+    assert not slow, 'frame time above 1.5x the measured figure (ms, ceiling): {}'.format(slow)
+
+
 def test_config3_full_size_dn_l25_then_sr_a2(dev):
     """BASELINE config 3 as written: 3840x2160 RGB, [{'op':'DN','model':'25'}, {'op':'SR','model':'a','scale':2}], 256-px tiles:
     144 tiles (pad 7) then 144 tiles (pad 5) -> 7680x4320."""
