@@ -115,6 +115,7 @@ def main():
                     'the north star\'s "tiles of a frame across the GPUs") instead of N frames per step (weak scaling, the default)')
     ap.add_argument('--no-extras', action='store_true', help='config 2: skip the roofline objects of the HBM-bound members and the I/O edges')
     ap.add_argument('--no-configs', action='store_true', help="config 2: skip the short legs of BASELINE's configs 3, 4, 5 (object `configs`: one timed step each, in child processes)")
+    ap.add_argument('--no-floor', action='store_true', help='config 2: skip the value_floor legs (the same frame with six split-operand blocks / in fp16x3)')
     ap.add_argument('--no-pmc', action='store_true', help='config 2: do not try the rocprofv3 --pmc passes over a short child of this command (`traffic` then comes from the committed, '
                     'digest-gated profiles/pmc_bench.json)')
     args = ap.parse_args()
@@ -280,7 +281,7 @@ def main():
     # `value` is the speed of a4-synth with the block count the calibration gives ITS weights (config.exact_blocks); the zoo's real a4 is absent from the mount
     # (.MISSING_LARGE_BLOBS).  moe_net_calibrate moves a checkpoint whose trunk swings wider to more blocks (a 15 % wider trunk: six) and to fp16x3 when six do
     # not reach the target: the same frame timed in those two arithmetics is the floor of what such weights get.
-    if precision == 'mixed' and args.precision == 'auto':
+    if precision == 'mixed' and args.precision == 'auto' and not args.no_floor:
         floor = {}
         for tag, setup in (('exact_blocks_6', lambda: model.set_exact_blocks(6)), ('fp16x3', lambda: model.set_precision('fp16x3'))):
             setup()
@@ -745,7 +746,7 @@ def _other_configs(args):
                                      'child_wall_s': round(time.perf_counter() - t0, 1)}
         except Exception as e:
             out['config%d' % cfg] = {'error': repr(e)[:300]}
-    out['note'] = 'one timed step each (after one warm-up step) of `python bench.py --config 3 | 4 | 5`, run as children of this command; full lines: profiles/r05/bench_c{3,4,5}.json'
+    out['note'] = 'one timed step each (after one warm-up step) of `python bench.py --config 3 | 4 | 5`, run as children of this command; full lines: profiles/r06/bench_c{3,4,5}.json'
     return out
 
 
@@ -764,7 +765,7 @@ def _pmc_live():
     out = tempfile.mkdtemp(prefix='moe_pmc_', dir='/tmp')
     steps, warm = 1, 1
     child = [sys.executable, os.path.abspath(__file__), '--steps', str(steps), '--warmup', str(warm), '--no-cpu-baseline', '--sustain', '0', '--no-noise-input', '--no-dropin-loop',
-             '--no-extras', '--no-configs', '--no-pmc']
+             '--no-extras', '--no-configs', '--no-pmc', '--no-floor']
     regex = 'conv3x3_ps4|arsb32c|arsb_sq|conv64_sq|conv64_q8|conv64_x3'
     env = dict(os.environ, TMPDIR='/tmp')
     t0 = time.perf_counter()

@@ -419,6 +419,28 @@ def broadcast_state_dict(sd, src=0, device=None, group=None):
     return out
 
 
+def agree_arithmetic(model, group=None):
+    """Every rank runs the arithmetic rank 0 settled on.  moe_net_finalize(MOE_PREC_AUTO) calibrates per process (moe_net_calibrate: the count of split-operand ARSBs, or the
+    exact mode); the measurement is deterministic for equal weights and kernels, but ranks that disagreed -- another driver, another device generation in one job -- would
+    compute the tiles of ONE frame with different bits (ADVICE r05).  Rank 0's resolved precision and block count are broadcast and imposed (set_precision / set_exact_blocks);
+    returns (precision, blocks).  Called once per finalized model by run_frames / run_frames_overlapped (a collective: every rank calls it at the same place)."""
+    key = (id(group), getattr(model, '_finalized_key', None))
+    if getattr(model, '_dist_agreed', None) == key:
+        return model._dist_agreed_value
+    mine = [model.resolved_precision(), model.exact_blocks()]
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        box = [mine if dist.get_rank(group) == 0 else None]
+        dist.broadcast_object_list(box, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
+        want = box[0]
+        if want[0] != mine[0]:
+            model.set_precision(want[0])
+        if want[0] == 'mixed' and model.exact_blocks() != want[1]:
+            model.set_exact_blocks(want[1])
+        mine = [model.resolved_precision(), model.exact_blocks()]
+    model._dist_agreed, model._dist_agreed_value = (id(group), getattr(model, '_finalized_key', None)), tuple(mine)
+    return tuple(mine)
+
+
 DIST_PLAN_CACHE = 8
 
 
@@ -514,6 +536,8 @@ def run_frames_overlapped(opt, frames, group=None, out_dtype=None, max_tiles_per
 def _layout(opt, frames, group, dev, rank, world, C, bands, nbuf=1, wire=None):
     """(plan, exchange layout, its buffer(s), the padded frames, their stride): cached on the Option per (shape, frame count, rank, world, C, mode)."""
     x0 = frames[0]
+    if hasattr(opt.modelCached, 'exact_blocks'):
+        agree_arithmetic(opt.modelCached, group)
     plan = _agreed_plan(opt, x0.shape, group, dev)
     cache = opt.__dict__.setdefault('_exchanges', {})
     if wire not in (None, 'f32', 'f16s'):

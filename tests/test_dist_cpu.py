@@ -63,6 +63,17 @@ for rep in range(4):                         # the layout is reused every step; 
         assert not any(np.isnan(t).any() for t in tiles)
         want = ostitch.fold_stitch([tile_value(f, k) for k in range(nt)], pl, sc)
         assert np.array_equal(ostitch.fold_stitch(tiles, pl, sc), want)
+# ---- agree_arithmetic: rank 0's calibration result is imposed on every rank (a stub with the module's methods: ranks that calibrated differently) ------------
+class _M(object):
+    def __init__(self, prec, blocks): self.p, self.b, self._finalized_key = prec, blocks, (0, 'auto')
+    def resolved_precision(self): return self.p
+    def exact_blocks(self): return self.b if self.p == 'mixed' else 0
+    def set_precision(self, p): self.p = p; return self
+    def set_exact_blocks(self, b): self.b = b; return self
+for r0, rest, want in ((('mixed', 2), ('mixed', 1), ('mixed', 2)), (('fp16x3', 0), ('mixed', 4), ('fp16x3', 0)), (('mixed', 5), ('fp16x3', 0), ('mixed', 5))):
+    mm = _M(*(r0 if rank == 0 else rest))
+    assert mdist_mod.agree_arithmetic(mm) == want and (mm.resolved_precision(), mm.exact_blocks()) == want, (rank, mm.p, mm.b)
+    assert mdist_mod.agree_arithmetic(mm) == want          # (cached: no second collective)
 # ---- wire format 'f16s' (fp16 values + fp32 seam rows / columns on the links): same layout, fp16 canvases bit-identical ---------------------------
 import wire_codec
 from moephoto_amd import dist as mdist

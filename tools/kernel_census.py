@@ -4,7 +4,7 @@
     rocprofv3 --kernel-trace --stats -d OUT -o census -f csv -- <workload>;  python tools/kernel_census.py OUT/census_kernel_stats.csv [label]
 
 Compiled = the host launch stubs of libmoephoto_amd.so (nm -C: one per template instantiation).  Prints the instantiations the workload launched (calls, total ms) and the
-ones it never did.  Workloads of tools/r05_census.sh: (a) every zoo key in its default arithmetic over a 1080p frame + the per-tile loop + the I/O edges + resize -- the
+ones it never did.  Workloads of tools/history/r05_census.sh: (a) every zoo key in its default arithmetic over a 1080p frame + the per-tile loop + the I/O edges + resize -- the
 DEFAULTS; (b) the whole GPU test suite -- everything any test reaches (options, fallbacks, debug paths)."""
 import csv
 import os

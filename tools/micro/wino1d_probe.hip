@@ -34,6 +34,12 @@ typedef const __attribute__((address_space(3))) half8_t* lds_h8_t;
 #ifndef WP_FILL
 #define WP_FILL 5          // VALU / SALU instructions pinned behind each MFMA
 #endif
+#ifndef WP_XCD
+#define WP_XCD 1
+#endif
+#ifndef WP_EVEN
+#define WP_EVEN 1          // 1: the micro-ops dealt evenly over a row's twelve groups of four MFMAs | 0: front-loaded (the first v2 run)
+#endif
 #ifndef WP_AHEAD
 #define WP_AHEAD 3         // B fragments read this many MFMA slots ahead
 #endif
@@ -68,7 +74,15 @@ __global__ __launch_bounds__(256) void wino_kernel(Args a)
     const int n = lane & 31, hh = lane >> 5;
     const int H = a.H, W = a.W;
     const int px = W / 64;
+#if WP_XCD
+    // the two workgroups of a strip (channel halves) on ONE XCD -- workgroups go round-robin over the 8 XCDs, so blocks b and b + 8 share an L2: the partner's read of the
+    // same input rows hits it instead of going out to memory a second time
+    const int ch = (blockIdx.x >> 3) & 1;
+    const int pair = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7);       // 0 .. grid / 2 - 1
+#else
     const int ch = blockIdx.x & 1;
+    const int pair = blockIdx.x >> 1;
+#endif
     const int cb = ch * 4 + w4;                                 // this wave's block of 32 output channels
     constexpr unsigned kOOR = 0xFFFF0000u;
 
@@ -128,7 +142,7 @@ __global__ __launch_bounds__(256) void wino_kernel(Args a)
     };
     float chk = 0.f;
 
-    for (int item = blockIdx.x >> 1; item < a.B * px; item += gridDim.x >> 1) {
+    for (int item = pair; item < a.B * px; item += gridDim.x >> 1) {
         const int b = item / px, x0 = (item - b * px) * 64;
         piece_offsets(x0);
         // raw block k = input rows 2k, 2k + 1 (columns x0 - 1 .. x0 + 64) into raw slot (k + 3) % 3; blocks / columns outside the image: zeros
@@ -233,6 +247,26 @@ __global__ __launch_bounds__(256) void wino_kernel(Args a)
                 }
                 // ---- what rides behind these four MFMAs ---------------------------------------------------------------------------------------------------------------------
                 const int oprev = 2 * d - 2 + rh;                               // the row whose chains closed last
+#if WP_EVEN
+                // (one unit of ~16 VALU instructions behind each group of four MFMAs)
+                if (ql == 0) { Y0 = T[0] + T[1]; }
+                if (ql == 1) { Y0 = Y0 + T[2]; }
+                if (ql == 2) { Y1 = T[1] - T[2]; }
+                if (ql == 3) { Y1 = Y1 - T[3]; }
+                if (ql == 4) op_e(oprev, ic<0>{}, ic<0>{});
+                if (ql == 5) op_e(oprev, ic<0>{}, ic<1>{});
+                if (ql == 6) op_e(oprev, ic<1>{}, ic<0>{});
+                if (ql == 7) op_e(oprev, ic<1>{}, ic<1>{});
+                if (ql == 8) x_load((u + 1) % 3, rh);                           // raw row 2d + 2 + rh = block d + 1, row rh
+                if (ql == 9) x_put((2 * u + 2 + rh + 6) % 6);
+                if (rh == 0 && ql >= 7) {                                       // block d + 2 into the raw slot of block d - 1 (transformed in double-step d - 2)
+                    if (ql == 7) dma_piece(d + 2, ic<0>{});
+                    if (ql == 8) dma_piece(d + 2, ic<1>{});
+                    if (ql == 9) dma_piece(d + 2, ic<2>{});
+                    if (ql == 10) dma_piece(d + 2, ic<3>{});
+                    if (ql == 11) dma_piece(d + 2, ic<4>{});
+                }
+#else
                 if (ql == 0) { Y0 = (T[0] + T[1]) + T[2]; }
                 if (ql == 1) { Y1 = (T[1] - T[2]) - T[3]; }
                 if (ql == 2) op_e(oprev, ic<0>{}, ic<0>{});
@@ -248,6 +282,7 @@ __global__ __launch_bounds__(256) void wino_kernel(Args a)
                     if (ql == 3) dma_piece(d + 2, ic<3>{});
                     if (ql == 4) dma_piece(d + 2, ic<4>{});
                 }
+#endif
                 if (ql == 11) { T[0] = acc[0]; T[1] = acc[1]; T[2] = acc[2]; T[3] = acc[3]; }
 #if WP_PIN
 #pragma unroll
@@ -324,7 +359,7 @@ int main(int argc, char** argv)
         hipMemcpy(d_x, x.data(), x.size() * 2, hipMemcpyHostToDevice);
         hipMemset(d_o, 0, (size_t)vB * vH * vW * 256 * 2);
         Args a{d_x, d_w, d_bias, d_tw, d_o, nullptr, slope, vB, vH, vW};
-        wino_kernel<1><<<dim3(8), dim3(256), LDS_BYTES>>>(a);
+        wino_kernel<1><<<dim3(16), dim3(256), LDS_BYTES>>>(a);
         if (hipDeviceSynchronize() != hipSuccess) { fprintf(stderr, "validation launch failed: %s\n", hipGetErrorString(hipGetLastError())); return 1; }
         std::vector<half_t> o((size_t)vB * vH * vW * 256);
         hipMemcpy(o.data(), d_o, o.size() * 2, hipMemcpyDeviceToHost);

@@ -9,8 +9,8 @@ export TMPDIR=/tmp
 OUT=gpurun_out/${PMC_TAG:-pmc}
 mkdir -p $OUT
 STEPS=${PMC_STEPS:-2}
-CMD="python bench.py --steps $STEPS --warmup 1 --no-cpu-baseline --sustain 0 --no-noise-input --no-dropin-loop --no-extras --no-configs --no-pmc"
-RE='conv3x3|arsb_fused|arsb32|arsb_sq|conv64_x3|conv64_q8|conv64_sq|tapsum|tailadd|stitch|stem_kernel'
+CMD="python bench.py --steps $STEPS --warmup 1 --no-cpu-baseline --sustain 0 --no-noise-input --no-dropin-loop --no-extras --no-configs --no-pmc --no-floor"
+RE='conv3x3|arsb32c|arsb_sq|conv64_x3|conv64_q8|conv64_sq|conv64_s|tapsum|tailadd|stitch|stem_kernel'
 pass() {  # name, counters...
   name=$1; shift
   timeout 420 rocprofv3 --pmc "$@" --kernel-include-regex "$RE" -d $OUT/pmc_$name -o pmc -f csv -- $CMD > $OUT/pmc_$name.log 2>&1

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Instruction mix per MFMA of the bench's MFMA kernels from the rocprofv3 PMC passes of tools/r05_a.sh (pmc_mix / pmc_act / pmc_lds / pmc_grbm): per kernel the
+"""Instruction mix per MFMA of the bench's MFMA kernels from the rocprofv3 PMC passes of tools/history/r05_a.sh (pmc_mix / pmc_act / pmc_lds / pmc_grbm): per kernel the
 counters summed over its dispatches, normalised by SQ_INSTS_MFMA (pass mix) or by SQ_WAVE_CYCLES where that pass has it -- where a kernel's issue slots (and joules)
 go besides the matrix pipe.  Counters a pass failed on (unknown on this rocprofv3) are simply absent.
 
