@@ -485,6 +485,20 @@ def test_bench_gpus2_strong_scaling_one_frame_over_the_ranks(dev):
     assert res['n_gpus'] == 2 and res['scaling'] == 'strong' and res['config']['frames_per_step'] == 1
     assert abs(res['value'] - 1920 * 1080 / 1e6 / (res['ms_per_step'] / 1e3)) / res['value'] < 2e-3
     assert res['config']['parity_ok'] is True
+    # first contact (round 6): every rank held its row band against its own single-rank doCrop before anything was timed
+    fc = res['first_contact']
+    assert fc['ranks_seen'] == 2 and fc['bit_identical'] is True and fc['parity_vs_single_gpu_max_abs'] == 0.0 and res['config']['ranks_seen'] == 2
+
+
+def test_bench_gpus3_on_grouped_isend_irecv(dev):
+    """The exchange's second form (dist._p2p_exchange: one isend + one irecv per peer, batched -- what an all_to_all_single failure falls back to) under `bench.py --gpus 3`
+    in shared-GPU mode, MOE_DIST_EXCHANGE=p2p: the line says which form ran, and the first-contact comparison holds every rank's frames bit for bit against single-rank doCrop."""
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '3', '--steps', '2', '--warmup', '1', '--sustain', '0', '--no-cpu-baseline', '--no-noise-input']
+    p = subprocess.run(cmd, cwd=ROOT, env=dict(_shared_gpu_env(), MOE_DIST_EXCHANGE='p2p'), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith('{') and '"metric"' in l][0])
+    fc = res['first_contact']
+    assert res['n_gpus'] == 3 and fc['ranks_seen'] == 3 and fc['exchange_mode'] == 'p2p' and fc['bit_identical'] is True, fc
 
 
 def test_bench_gpus2_started_plainly(dev):
@@ -500,4 +514,6 @@ def test_bench_gpus2_started_plainly(dev):
     assert res['n_gpus'] == 2 and res['config']['frames_per_step'] == 2 and res['scaling'] == 'weak'
     assert res['config']['parity_ok'] is True and res['config']['parity']['natural']['worst_max_abs'] <= TOL
     assert res['value'] > 0 and res['steps'] == 2
+    fc = res['first_contact']
+    assert fc['ranks_seen'] == 2 and fc['bit_identical'] is True and fc['exchange_mode'] == 'all_to_all' and fc['exchange_fallback'] is None, fc
     _report('bench_gpus2_shared_gpu', {'value': res['value'], 'ms_per_step': res['ms_per_step'], 'wall_s': round(time.time() - t0, 1)})

@@ -1334,6 +1334,35 @@ def test_consecutive_forwards_on_slices_of_one_image_overlap_and_keep_their_bits
         assert torch.equal(got, want_bt)
 
 
+def test_forward_takes_part_in_a_hip_graph_capture(dev):
+    """A forward is plain stream work: captured into a hipGraph (torch.cuda.CUDAGraph) and replayed on new input data it gives the eager bits -- with the U branch's fork / join
+    as event edges inside the capture (branch_streams) and without; the overlap path of moe_net_forward_ex stands aside while its stream captures.  (tools/graph_probe.py:
+    replay is not faster than eager launches, 0.816 vs 0.815 ms per 3 x 256 x 256 forward of a4 -- the per-tile loop is bound by the GPU, not by launches.)"""
+    for key in ('a4', 'a2'):
+        m = module_for(key, 'auto', torch.float16)
+        x = torch.from_numpy(gd.natural_image(3, (3, 128, 160))).to(dev).half()[:, None].contiguous()
+        x2 = torch.from_numpy(gd.noise_image(4, (3, 128, 160))).to(dev).half()[:, None].contiguous()
+        for fork in (1, 0):
+            try:
+                m.set_option('branch_streams', fork)
+                want2 = m(x2)[-1].clone()
+                xs = x.clone()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    m(xs)                                      # (workspace grown outside the capture)
+                torch.cuda.current_stream().wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    y = m(xs)[-1]
+                xs.copy_(x2)
+                g.replay()
+                torch.cuda.synchronize()
+                assert torch.equal(y, want2), (key, fork, float((y.float() - want2.float()).abs().max()))
+            finally:
+                m.set_option('branch_streams', 1)
+
+
 def test_wire_pack_unpack_kernels_vs_numpy_codec(dev):
     """moe_wire_pack / moe_wire_unpack (the 'f16s' wire format of dist.py: fp16 image + fp32 seam rows + fp32 seam columns per tile, strips as plain fp32)
     against tests/wire_codec.py, bit for bit, on the real seams of a plan plus synthetic records (odd sizes, empty ranges, one-range seams, a strip), and the
