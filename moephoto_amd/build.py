@@ -120,6 +120,13 @@ def build_probes():
     if os.path.exists(src) and (not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src)):
         os.makedirs(os.path.dirname(out), exist_ok=True)
         subprocess.check_call([hipcc(), '--offload-arch=' + ARCH, '-O3', src, '-o', out])
+    # round 6: the Winograd probes of the U branch's last up-conv (run by tools/r06_*.sh, numbers in profiles/r06/)
+    for name in ('wino_probe', 'wino1d_probe'):
+        psrc = os.path.join(root, 'tools', 'micro', name + '.hip')
+        pout = os.path.join(root, 'tools', 'micro', 'bin', name)
+        if os.path.exists(psrc) and (not os.path.exists(pout) or os.path.getmtime(pout) < os.path.getmtime(psrc)):
+            os.makedirs(os.path.dirname(pout), exist_ok=True)
+            subprocess.check_call([hipcc(), '--offload-arch=' + ARCH, '-O3', '-w', '-fno-slp-vectorize', '-mllvm', '-amdgpu-mfma-vgpr-form=1', psrc, '-o', pout])
     return out
 
 

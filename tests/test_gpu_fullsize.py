@@ -495,6 +495,12 @@ def test_bench_gpus3_on_grouped_isend_irecv(dev):
     in shared-GPU mode, MOE_DIST_EXCHANGE=p2p: the line says which form ran, and the first-contact comparison holds every rank's frames bit for bit against single-rank doCrop."""
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '3', '--steps', '2', '--warmup', '1', '--sustain', '0', '--no-cpu-baseline', '--no-noise-input']
     p = subprocess.run(cmd, cwd=ROOT, env=dict(_shared_gpu_env(), MOE_DIST_EXCHANGE='p2p'), capture_output=True, text=True, timeout=900)
+    if p.returncode != 0:
+        try:
+            os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+            open(os.path.join(ROOT, 'gpurun_out', 'bench_gpus3_p2p_failure.txt'), 'w').write(p.stdout + '\n---- stderr ----\n' + p.stderr)
+        except Exception:
+            pass
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     res = json.loads([l for l in p.stdout.splitlines() if l.startswith('{') and '"metric"' in l][0])
     fc = res['first_contact']
