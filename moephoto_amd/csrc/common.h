@@ -143,6 +143,35 @@ struct TailAddArgs {
 };
 void launch_tailadd(const TailAddArgs& a, hipStream_t s);
 
+// The upsampler stage of a x3 net (3x3, 64 -> 576, + bias, PixelShuffle(3), PReLU) with the 64 -> 1 tail conv: a workgroup = the three phases of one phase row
+// (conv3x3_ps9.hip), three workgroups per range of rows
+struct Ps9Args {
+    const half_t* in;        // [B][H][W][64]
+    const half_t* wpk;       // pack_conv fragments [phase 9][72][lane 64][8]
+    const float* bias;       // [576] fp32 in packed output-channel order (ConvLayer::bias)
+    const half_t* tail_w;    // eight A fragments of the tail conv (engine.cpp tail(): "<key>.frag")
+    float* plane;            // out: [dy 3][B][3H][3W] fp32, S[dy][HR row][HR column] = the tail conv's sums over dx for tap row dy, terms crossing a 32-pixel column left out
+    float* apron;            // out: [side 2][dy 3][B][px][3H] fp32, those terms (side 0: for the column to the right, 1: to the left)
+    float slope;             // PReLU slope (< 1)
+    int B, H, W;             // the conv's input size
+    int split;               // the tail conv's activation operand as hi + lo 2^-11 (MOE_PREC_MIXED, R branch)
+};
+bool launch_conv3x3_ps9(const Ps9Args& a, int max_groups, hipStream_t s);   // false: not applicable (caller keeps conv3x3_sp + nine tap planes + tapsum<3>)
+bool ps9_applicable(int B, int H, int W);
+inline bool ps9_tail_applicable(int B, int H, int W, float slope) { return slope < 1.f && ps9_applicable(B, H, W); }      // the ONE predicate (see ps4_tail_applicable)
+size_t ps9_plane_bytes(int B, int H, int W);
+size_t ps9_apron_bytes(int B, int H, int W);
+hipError_t conv3x3_ps9_init();
+// y[Y][X] = sum over both branches of S0[Y - 1][X] + S1[Y][X] + S2[Y + 1][X] + their column aprons (conv3x3_ps9.hip), cast to the caller's type
+struct TailAdd3Args {
+    const float* p0; const float* p1;      // [3][B][H][W] fp32 (p1 may be nullptr)
+    const float* a0; const float* a1;      // [2][3][B][px][H]
+    void* y; int y_dtype; const long long* y_off;
+    int B, H, W, px;                       // HR size; px: 32-pixel columns of the conv input (96 HR columns each)
+    int vec_ok;                            // every output row start is 16-byte aligned
+};
+void launch_tailadd3(const TailAdd3Args& a, hipStream_t s);
+
 // One fused ARSB  y = x + conv_2(PReLU(conv_1(x)))  (arsb32c.hip; conv_2's weights carry the ScaleLayer factor)
 struct ArsbArgs {
     const half_t* x_hi; const half_t* x_lo;   // stream in  [B][H][W][64] (x_lo: low part in units of 2^-11, or nullptr)

@@ -387,6 +387,7 @@ hipError_t conv_mfma_init()
     if ((e = conv1x1_init()) != hipSuccess) return e;
     if ((e = conv3x3_rw_init()) != hipSuccess) return e;
     if ((e = conv3x3_ps4_init()) != hipSuccess) return e;
+    if ((e = conv3x3_ps9_init()) != hipSuccess) return e;
     int dev = 0;
     e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;

@@ -1115,7 +1115,7 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         float* tp[2] = {nullptr, nullptr};
         const bool sr = n.arch != MOE_ARCH_NETDN;
         const bool fuse = sr && can_fuse_tail(n, f, B, h, w);      // last upsampler conv + 64->1 tail conv in one kernel
-        bool ps4 = false;
+        bool ps4 = false, ps9 = false;
         int H = h, W = w;
         if (sr) {   // form of the fused tail's output: phase-class sums when the last stage is a x2 shuffle the register-weight kernel takes
             int hl = h, wl = w;
@@ -1131,6 +1131,12 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
             f.tail_form = ok ? 1 : 0;
             // the same layer with all four phases in one workgroup (conv3x3_ps4.hip): one fp32 plane + column aprons per branch, added by tailadd
             ps4 = ok && n.opt.up_impl == 1 && ps4_ok && (2 * wl) % 8 == 0;
+            // x3 nets: the phase-row form of the same kernel (conv3x3_ps9.hip): three fp32 planes S[dy] + column aprons per branch, added by tailadd3
+            ps9 = fuse && n.opt.up_impl == 1 && n.r == 3 && n.max_groups >= 3;
+            for (const char* br : {"u", "convt_R1"}) {
+                const auto it = n.conv_index.find(std::string(br) + ".up" + std::to_string(n.stages - 1));
+                ps9 = ps9 && it != n.conv_index.end() && ps9_tail_applicable(B, hl, wl, n.convs[it->second].slope);
+            }
         }
         float* ps_plane[2] = {nullptr, nullptr};
         float* ps_apron[2] = {nullptr, nullptr};
@@ -1154,6 +1160,25 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
                         for (int rep = f.repeats(key); rep > 0; --rep) done = launch_conv3x3_ps4(q, n.max_groups, f.s);
                         f.prof_end(rec);
                         if (!done) return fail(MOE_EINVAL, "fused tail kernel (ps4) rejected layer %s", key.c_str());
+                    }
+                    H *= n.r; W *= n.r;
+                    continue;
+                }
+                if (ps9 && st == n.stages - 1) {
+                    ps_plane[br] = (float*)f.ar.take(ps9_plane_bytes(B, H, W) + 4096);
+                    ps_apron[br] = (float*)f.ar.take(ps9_apron_bytes(B, H, W) + 4096);
+                    if (!f.dry()) {
+                        const ConvLayer& L = n.convs[n.conv_index.at(key)];
+                        Ps9Args q{};
+                        q.in = cur.hi; q.wpk = f.blob<half_t>(L.w_hi); q.bias = L.has_bias ? f.blob<float>(L.bias) : f.small<float>("zero_bias");
+                        q.tail_w = f.small<half_t>(br == 0 ? "tail_r.frag" : "tail_u.frag");
+                        q.plane = ps_plane[br]; q.apron = ps_apron[br]; q.slope = L.slope; q.B = B; q.H = H; q.W = W;
+                        q.split = (f.mixed && f.tail_split_for(key)) ? 1 : 0;
+                        const int rec = f.prof_begin(key, 2.0 * (double)B * H * W * L.cout * L.cin * L.taps);
+                        bool done = false;
+                        for (int rep = f.repeats(key); rep > 0; --rep) done = launch_conv3x3_ps9(q, n.max_groups, f.s);
+                        f.prof_end(rec);
+                        if (!done) return fail(MOE_EINVAL, "fused tail kernel (ps9) rejected layer %s", key.c_str());
                     }
                     H *= n.r; W *= n.r;
                     continue;
@@ -1318,6 +1343,19 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
                 const int rec = f.prof_begin("tailadd", 0.0);
                 gate();
                 launch_tailadd(t, s);
+                f.prof_end(rec);
+            }
+            return MOE_OK;
+        }
+        if (ps9) {
+            if (!f.dry()) {
+                TailAdd3Args t{};
+                t.p0 = ps_plane[0]; t.p1 = ps_plane[1]; t.a0 = ps_apron[0]; t.a1 = ps_apron[1];
+                t.y = y; t.y_dtype = y_dtype; t.y_off = y_off_dev; t.B = B; t.H = H; t.W = W; t.px = (W / 3 + kTileW - 1) / kTileW;
+                t.vec_ok = f.y_vec;
+                const int rec = f.prof_begin("tailadd", 0.0);
+                gate();
+                launch_tailadd3(t, s);
                 f.prof_end(rec);
             }
             return MOE_OK;

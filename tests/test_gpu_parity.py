@@ -1057,6 +1057,51 @@ def test_upconv_all_phases_in_one_workgroup_vs_per_phase_form(key, dev):
         m.set_option('up_impl', 'ps4').set_option('max_groups', 0)
 
 
+def test_x3_upconv_phase_rows_vs_per_phase_form(dev):
+    """Net3x's upsampler stage on conv3x3_ps9.hip (option up_impl = ps4, the default: a workgroup = the three phases of one phase row, rows streamed down a
+    32-pixel column, the 64 -> 1 tail's horizontal sums closed in the workgroup, three fp32 planes S[dy] + column aprons per branch, tailadd3) against round 2's
+    form (up_impl = rw: conv3x3_sp per phase, nine tap planes, tapsum<3>).  The two main convs accumulate in different orders (an fp16 rounding of an activation
+    flips now and then: the forms agree to ~1e-4, a misplaced apron or phase would show as 1e-2); both hold the tolerance against the oracle; a launch repeated
+    gives the same bits; the result does not depend on how the ranges are cut (7 workgroups = 2 ranges instead of 80) -- on shapes ragged against the 32-pixel
+    columns (the masked variant), with several planes, strips and columns, with and without the activation split of the R branch."""
+    key = 'a3'
+    arch = gd.MODELS[key][0]
+    sd = gd.state_dict_for(key, load_state_dict_file)
+    m = module_for(key)
+    shapes = ((3, 8, 8), (3, 24, 40), (2, 40, 264), (3, 16, 72), (1, 88, 64), (3, 64, 96), (4, 128, 128), (3, 256, 256))
+    try:
+        for shape in shapes:
+            for kind in ('natural', 'noise'):
+                x = (gd.natural_image(37, shape) if kind == 'natural' else gd.noise_image(37, shape))[:, None]
+                xd = torch.from_numpy(x).to(dev)
+                want = onets.forward(arch, sd, x).numpy() if shape[1] * shape[2] <= 128 * 128 else None
+                for split in ('r', '0'):
+                    m.set_option('tail_split', split)
+                    y_sp = m.set_option('up_impl', 'rw')(xd)[-1].cpu().numpy()
+                    y_ps = m.set_option('up_impl', 'ps4')(xd)[-1].cpu().numpy()
+                    y_again = m(xd)[-1].cpu().numpy()
+                    y_cut = m.set_option('max_groups', 7)(xd)[-1].cpu().numpy()
+                    y_one = m.set_option('max_groups', 3)(xd)[-1].cpu().numpy()
+                    m.set_option('max_groups', 0)
+                    assert np.isfinite(y_ps).all(), (shape, kind, split)
+                    scale = max(1.0, float(np.abs(y_sp).max()))
+                    assert np.abs(y_ps - y_sp).max() <= (2.5e-4 if kind == 'natural' else 6e-4) * scale, (shape, kind, split, float(np.abs(y_ps - y_sp).max()))
+                    assert np.array_equal(y_ps, y_again), (shape, kind, split)
+                    assert np.array_equal(y_ps, y_cut), (shape, kind, split, float(np.abs(y_ps - y_cut).max()))
+                    assert np.array_equal(y_ps, y_one), (shape, kind, split, float(np.abs(y_ps - y_one).max()))
+                    if want is not None and split == 'r':
+                        assert np.abs(y_ps - want).max() <= TOL, (shape, kind, float(np.abs(y_ps - want).max()))
+        # an fp16 result tensor (the drop-in path's dtype): tailadd3 rounds once
+        x = gd.noise_image(7, (3, 24, 40))[:, None]
+        m16 = module_for(key, dtype=torch.float16)
+        y16 = m16(torch.from_numpy(x).to(dev).half())[-1].float().cpu().numpy()
+        m32 = module_for(key)
+        y32 = m32(torch.from_numpy(x.astype(np.float16).astype(np.float32)).to(dev))[-1].cpu().numpy()
+        assert np.abs(y16 - y32).max() <= HALF_OUT * max(1.0, float(np.abs(y32).max()) / 2), float(np.abs(y16 - y32).max())
+    finally:
+        m.set_option('up_impl', 'ps4').set_option('max_groups', 0).set_option('tail_split', 'r')
+
+
 def test_integration_md_stub_drives_every_family(dev):
     """INTEGRATION.md section 1 is the binding a MoePhoto maintainer would add (a ctypes stub over include/moephoto_amd.h).  This test EXECUTES that text --
     the first python block of the file, with the library path filled in -- and drives one SR key, one NetDN key, one SEDN key and one lite key through the

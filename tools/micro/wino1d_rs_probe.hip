@@ -30,6 +30,9 @@ typedef const __attribute__((address_space(3))) half8_t* lds_h8_t;
 #ifndef WP_FILL
 #define WP_FILL 5          // VALU / SALU instructions pinned behind each MFMA
 #endif
+#ifndef WP_SLOT
+#define WP_SLOT 1          // 1: one unit of <= 16 VALU instructions behind every group of four MFMAs | 0: the first form (32-instruction units)
+#endif
 #ifndef WP_XCD
 #define WP_XCD 1
 #endif
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(256) void wino_kernel(Args a)
                 const half2_t v = {(half_t)Yv[2 * r], (half_t)Yv[2 * r + 1]};
                 const half2_t m = __builtin_elementwise_max(v, v * slope2);
                 pk[r] = __builtin_bit_cast(unsigned, m);
-                if (MODE == 0) chk = __builtin_amdgcn_fdot2(m, tw2[r], chk, false);
+                if (MODE == 0) chk = __builtin_amdgcn_fdot2(m, tw2[0], chk, false);      // (one weight pair for every channel pair: the stand-in needs the instruction, not 8 registers)
             }
             if (MODE == 1 && hf == 1) {
                 const int ox = x0 + 2 * n + j;
@@ -235,7 +238,26 @@ __global__ __launch_bounds__(256) void wino_kernel(Args a)
                 constexpr int st = d == 0 ? sC : d == 1 ? sM : sN, dy = 2 - d;
 #pragma unroll
                 for (int pp = 0; pp < 4; ++pp) acc[st][pp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[dy * 4 + pp][ks], fr[pp], acc[st][pp], 0, 0, 0);
-                // ---- what rides behind these four MFMAs ---------------------------------------------------------------------------------------------------------------------
+                // ---- what rides behind these four MFMAs: ONE unit of <= 16 VALU instructions per group (an MFMA hides ~5 other instructions when they sit evenly in its gaps) ----
+#if WP_SLOT
+                // the row completed by the PREVIOUS step (r - 2): the second half of its output transform, then its epilogue; this step's completing row (r - 1) opens its
+                // transform behind group 9 (k-slice 3, dy 2); the new row's accumulators are first written in group 2: Y1 is read out before that
+                if (g == 0) Y1 = acc[sN][1] - acc[sN][2];                               // (set sN still holds row r - 2 here: it was the completing set of the previous step)
+                if (g == 1) Y1 = Y1 - acc[sN][3];
+                if (g == 2) op_e(r - 2, ic<0>{}, ic<0>{});
+                if (g == 3) op_e(r - 2, ic<0>{}, ic<1>{});
+                if (g == 4) op_e(r - 2, ic<1>{}, ic<0>{});
+                if (g == 5) op_e(r - 2, ic<1>{}, ic<1>{});
+                if (g == 6) x_load(bpar ^ 1, u);
+                if (g == 7) x_put((v + 3) % 6);
+                if (u == 0 && g >= 8 && g <= 9) {
+                    const int B2 = i / 3 + 2;
+                    if (g == 8) { dma_piece(B2, ic<0>{}); dma_piece(B2, ic<1>{}); dma_piece(B2, ic<2>{}); dma_piece(B2, ic<3>{}); }
+                    if (g == 9) { dma_piece(B2, ic<4>{}); dma_piece(B2, ic<5>{}); dma_piece(B2, ic<6>{}); }
+                }
+                if (g == 10) Y0 = acc[sC][0] + acc[sC][1];
+                if (g == 11) Y0 = Y0 + acc[sC][2];
+#else
                 if (g == 0) op_e(r - 2, ic<0>{}, ic<0>{});                             // (the row whose Y0 / Y1 closed the previous step)
                 if (g == 1) op_e(r - 2, ic<0>{}, ic<1>{});
                 if (g == 2) op_e(r - 2, ic<1>{}, ic<0>{});
@@ -254,6 +276,7 @@ __global__ __launch_bounds__(256) void wino_kernel(Args a)
                 }
                 if (g == 10) Y0 = (acc[sC][0] + acc[sC][1]) + acc[sC][2];              // row r - 1 is complete since group 9 (k-slice 3, dy 2)
                 if (g == 11) Y1 = (acc[sC][1] - acc[sC][2]) - acc[sC][3];
+#endif
 #if WP_PIN
 #pragma unroll
                 for (int i_ = 0; i_ < 4; ++i_) {
@@ -276,6 +299,9 @@ __global__ __launch_bounds__(256) void wino_kernel(Args a)
             step(i, ic<0>{}); step(i + 1, ic<1>{}); step(i + 2, ic<2>{}); step(i + 3, ic<3>{}); step(i + 4, ic<4>{}); step(i + 5, ic<5>{});
         }
         // the row whose Y closed the last step (row nsteps - 3 >= H - 1 ... its epilogue; rows >= H are discarded by the store's predicate)
+#if WP_SLOT
+        { constexpr int sL = (5 % 3 + 2) % 3; Y1 = (acc[sL][1] - acc[sL][2]) - acc[sL][3]; }      // (the completing set of the last step, v = 5)
+#endif
         op_e(nsteps - 3, ic<0>{}, ic<0>{}); op_e(nsteps - 3, ic<0>{}, ic<1>{}); op_e(nsteps - 3, ic<1>{}, ic<0>{}); op_e(nsteps - 3, ic<1>{}, ic<1>{});
     }
     if (MODE == 0) a.chk[blockIdx.x * 256 + tid] = chk;
