@@ -155,6 +155,7 @@ struct Ps9Args {
     float slope;             // PReLU slope (< 1)
     int B, H, W;             // the conv's input size
     int split;               // the tail conv's activation operand as hi + lo 2^-11 (MOE_PREC_MIXED, R branch)
+    int xcd_map;             // set by the launcher: the block -> (range, phase row) map
 };
 bool launch_conv3x3_ps9(const Ps9Args& a, int max_groups, hipStream_t s);   // false: not applicable (caller keeps conv3x3_sp + nine tap planes + tapsum<3>)
 bool ps9_applicable(int B, int H, int W);

@@ -39,6 +39,9 @@
 #ifndef PS4_FILL
 #define PS4_FILL 5        // VALU / SALU slots pinned behind each MFMA of a chunk
 #endif
+#ifndef PS4_ZSKIP
+#define PS4_ZSKIP 1       // 1: the input blocks above / below the image (all zeros) run no MFMAs (round 6) | 0: every block alike (A/B)
+#endif
 #ifndef PS4_ABL
 #define PS4_ABL 0         // timing ablations (tools/mk_variant.sh; results are wrong): 1 no row epilogue (PReLU, tail GEMM, image writes), 2 no finishing / DMA ops,
 #endif                    // 4 no bias reload, 8 no fragment reads, 16 no barrier, 32 no tail MFMAs only, 64 no DMA of the next block, 128 (with 64) both ring halves filled with real data at the head of a strip
@@ -263,6 +266,11 @@ __global__ __launch_bounds__(256) void conv3x3_ps4_kernel(Ps4Args a)
         item += s1 - s0;
         const int x0 = pxi * kTileW;
         const int nblk = s1 - s0 + 3;                         // input blocks s0 - 1 .. s1, then (fused tail) one more iteration for the last finishing tasks
+        // the block above the image (s0 = 0) holds zeros only: it is not run at all (the accumulators start as the bias either way, and the tap rows -2, -1 are written as
+        // zeros by the epilogues of the next block); the block below the image (s1 = nyb) runs its epilogues -- the last two rows of the image, the zero tap rows H, H + 1 --
+        // without MFMAs and fragment reads.  Same bits: a product with a zero activation adds nothing.
+        const int kfirst = (PS4_ZSKIP && s0 == 0) ? 1 : 0;
+        const int kz = (PS4_ZSKIP && s1 == nyb) ? nblk - 2 : nblk - 1;      // blocks [kfirst, kz) run MFMAs
         const bool okx = x0 + j < W;
         const int ylo = RB * s0, yhi = RB * s1;
 
@@ -271,7 +279,7 @@ __global__ __launch_bounds__(256) void conv3x3_ps4_kernel(Ps4Args a)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         {
-            const int ya = RB * (s0 - 1), xa = x0 - 1;
+            const int ya = RB * (s0 - 1 + kfirst), xa = x0 - 1;
             const unsigned org = (unsigned)((b * H + ya + RB) * W + xa + 1) * 128u;
 #pragma unroll
             for (int m = 0; m < 5; ++m) {
@@ -295,12 +303,13 @@ __global__ __launch_bounds__(256) void conv3x3_ps4_kernel(Ps4Args a)
             fr[1] = *(lds_h8_t)(fa[0] ^ 32u);
         }
 
-        auto block = [&](int k, auto BUF_, auto LAST_) __attribute__((always_inline)) {
+        auto block = [&](int k, auto BUF_, auto KIND_) __attribute__((always_inline)) {
             constexpr int BUF = decltype(BUF_)::value;
-            constexpr bool LAST = decltype(LAST_)::value;     // the iteration behind the last input block: only its finishing task is wanted
+            constexpr bool LAST = decltype(KIND_)::value == 2;     // the iteration behind the last input block: only its finishing task is wanted
+            constexpr bool ZERO = decltype(KIND_)::value == 1;     // an input block of zeros (below the image): epilogues, finishing and barrier, no MFMAs
             const int Rk = RB * (s0 - 1 + k);                 // first input row of this block
             // the next block's DMA
-            const bool live = k + 2 < nblk;                   // (the last iteration has no input)
+            const bool live = k + 1 < kz;                     // (the next block is one that reads its input)
             const int yan = Rk + RB, xan = x0 - 1;
             const unsigned orgn = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((b * H + yan + RB) * W + xan + 1) * 128u));
             // finishing task of this wave: conv row yf, published by the previous block's barrier
@@ -451,13 +460,15 @@ __global__ __launch_bounds__(256) void conv3x3_ps4_kernel(Ps4Args a)
                     // branch cost 15 % of the kernel for 10 % of its MFMAs)
                     auto half = [&](auto HC_) __attribute__((always_inline)) {
                         constexpr int hc = decltype(HC_)::value;
+                        if constexpr (!ZERO) {
 #pragma unroll
-                        for (int u = 3 * hc; u < 3 * hc + 3; ++u) {
-                            const int dy = u >> 1, cg = u & 1;
-                            const int sl = (e + 1 - dy + 4) & 3;
-                            acc[sl][cg] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cg][(dy * 3 + dx) * 4 + ks], fr[f % 3], acc[sl][cg], 0, 0, 0);
+                            for (int u = 3 * hc; u < 3 * hc + 3; ++u) {
+                                const int dy = u >> 1, cg = u & 1;
+                                const int sl = (e + 1 - dy + 4) & 3;
+                                acc[sl][cg] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cg][(dy * 3 + dx) * 4 + ks], fr[f % 3], acc[sl][cg], 0, 0, 0);
+                            }
                         }
-                        if constexpr (hc == 0) {      // the fragment of chunk f + 2
+                        if constexpr (hc == 0 && !ZERO) {      // the fragment of chunk f + 2
                             constexpr int f2 = (f + 2) % 12;
                             constexpr int rowsel = f + 2 < 12 ? BUF * RB + e : (e < 3 ? BUF * RB + e + 1 : (BUF ^ 1) * RB);
                             if (!(PS4_ABL & 8)) fr[(f + 2) % 3] = *(lds_h8_t)((fa[f2 >> 2] ^ (unsigned)((f2 & 3) * 32)) + (unsigned)(rowsel * ROWB));
@@ -506,7 +517,7 @@ __global__ __launch_bounds__(256) void conv3x3_ps4_kernel(Ps4Args a)
                     half(std::integral_constant<int, 1>{});
 #ifndef PS4_NOPIN
 #pragma unroll
-                    for (int hc = 0; hc < 2; ++hc) {
+                    for (int hc = 0; hc < (ZERO ? 0 : 2); ++hc) {
                         const int h = 2 * f + hc;
                         const int MH = TAIL ? 20 : 10;
                         const int m_lo = h < MH ? h * LM.n / MH : LM.n, m_hi = h < MH ? (h + 1) * LM.n / MH : LM.n;
@@ -537,13 +548,17 @@ __global__ __launch_bounds__(256) void conv3x3_ps4_kernel(Ps4Args a)
             step(std::integral_constant<int, 3>{});
         };
 
-        int k = 0;
-        for (; k + 2 < nblk; k += 2) {
-            block(k, std::integral_constant<int, 0>{}, std::false_type{});
-            block(k + 1, std::integral_constant<int, 1>{}, std::false_type{});
+        typedef std::integral_constant<int, 0> Run;
+        typedef std::integral_constant<int, 1> Zero;
+        typedef std::integral_constant<int, 2> Last;
+        int k = kfirst;
+        for (; k + 1 < kz; k += 2) {
+            block(k, std::integral_constant<int, 0>{}, Run{});
+            block(k + 1, std::integral_constant<int, 1>{}, Run{});
         }
-        if (k + 1 < nblk) { block(k, std::integral_constant<int, 0>{}, std::false_type{}); ++k; }
-        if (TAIL) block(k, std::integral_constant<int, 0>{}, std::true_type{});      // (its ring half is not used)
+        if (k < kz) { block(k, std::integral_constant<int, 0>{}, Run{}); ++k; }
+        if (k < nblk - 1) { block(k, std::integral_constant<int, 0>{}, Zero{}); ++k; }      // (reads no input: its ring half does not matter)
+        if (TAIL) block(k, std::integral_constant<int, 0>{}, Last{});      // (its ring half is not used)
     }
 #endif
 }

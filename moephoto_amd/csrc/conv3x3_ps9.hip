@@ -35,8 +35,11 @@
 #define PS9_FILL 5        // VALU / SALU slots pinned behind each MFMA of a chunk
 #endif
 #ifndef PS9_XCD
-#define PS9_XCD 1         // 1: the three workgroups (pi = 0, 1, 2) of a range on ONE XCD (blocks go round-robin to the eight XCDs: the second and third read of the
-#endif                    // input rows hit that XCD's L2) | 0: pi = blockIdx % 3
+#define PS9_XCD 1         // 1: the XCD-aware block -> (range, phase row) map for launches that fill the chip | 0: pi = blockIdx % 3 always (A/B)
+#endif
+#ifndef PS9_ZSKIP
+#define PS9_ZSKIP 1       // 1: the input blocks above / below the image (all zeros) run no MFMAs | 0: every block alike (A/B)
+#endif
 
 namespace {
 
@@ -123,10 +126,19 @@ __global__ __launch_bounds__(NT) void conv3x3_ps9_kernel(Ps9Args a)
 
     // ---- this workgroup's phase row pi and its range of the column-major sequence of four-row blocks --------------------------------------------------
     const int px = (W + kTileW - 1) / kTileW, nyb = H / RB;
-    int pi, g;
-    const int G = (int)gridDim.x / 3;
-    if (PS9_XCD && G % 8 == 0) { pi = ((int)blockIdx.x >> 3) % 3; g = ((int)blockIdx.x / 24) * 8 + ((int)blockIdx.x & 7); }
-    else { pi = (int)blockIdx.x % 3; g = (int)blockIdx.x / 3; }
+    // block -> (range g of G, phase row pi).  xcd_map: blocks go round-robin to the eight XCDs; the three workgroups of a range sit on ONE XCD wherever that divides (the
+    // second and third fetch of its input rows hit that XCD's L2): an XCD's S = grid / 8 workgroups form S / 3 ranges, what is left over forms ranges across XCDs
+    int pi, g, G;
+    if (a.xcd_map) {
+        const int S = (int)gridDim.x >> 3, q = S / 3, r = S - 3 * q, x = (int)blockIdx.x & 7, i = (int)blockIdx.x >> 3;
+        G = 8 * q + (8 * r) / 3;
+        if (i < 3 * q) { pi = i % 3; g = x * q + i / 3; }
+        else {
+            const int l = (i - 3 * q) * 8 + x;
+            if (l >= 3 * ((8 * r) / 3)) return;
+            pi = l % 3; g = 8 * q + l / 3;
+        }
+    } else { G = (int)gridDim.x / 3; pi = (int)blockIdx.x % 3; g = (int)blockIdx.x / 3; }
     const long long nitems = (long long)a.B * px * nyb;
     int item = (int)(nitems * g / G);
     const int item_end = (int)(nitems * (g + 1) / G);
@@ -239,6 +251,11 @@ __global__ __launch_bounds__(NT) void conv3x3_ps9_kernel(Ps9Args a)
         item += s1 - s0;
         const int x0 = pxi * kTileW;
         const int nblk = s1 - s0 + 3;                         // input blocks s0 - 1 .. s1, then one more iteration for the last finishing rounds
+        // the block above the image (s0 = 0) holds zeros only: it is not run at all (the accumulators start as the bias either way); the block below the image
+        // (s1 = nyb) runs its epilogues -- the last two rows of the image are finished there -- without MFMAs and fragment reads.  Same bits: a product with a zero
+        // activation adds nothing.
+        const int kfirst = (PS9_ZSKIP && s0 == 0) ? 1 : 0;
+        const int kz = (PS9_ZSKIP && s1 == nyb) ? nblk - 2 : nblk - 1;      // blocks [kfirst, kz) run MFMAs
         const bool okx = x0 + j < W;
         const int ylo = RB * s0, yhi = RB * s1;
 
@@ -247,7 +264,7 @@ __global__ __launch_bounds__(NT) void conv3x3_ps9_kernel(Ps9Args a)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         {
-            const int ya = RB * (s0 - 1), xa = x0 - 1;
+            const int ya = RB * (s0 - 1 + kfirst), xa = x0 - 1;
             const unsigned org = (unsigned)((b * H + ya + RB) * W + xa + 1) * 128u;
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
@@ -267,12 +284,13 @@ __global__ __launch_bounds__(NT) void conv3x3_ps9_kernel(Ps9Args a)
             fr[1] = *(lds_h8_t)(fa[0] ^ 32u);
         }
 
-        auto block = [&](int k, auto BUF_, auto LAST_) __attribute__((always_inline)) {
+        auto block = [&](int k, auto BUF_, auto KIND_) __attribute__((always_inline)) {
             constexpr int BUF = decltype(BUF_)::value;
-            constexpr bool LAST = decltype(LAST_)::value;     // the iteration behind the last input block: only its finishing rounds are wanted
+            constexpr bool LAST = decltype(KIND_)::value == 2;     // the iteration behind the last input block: only its finishing rounds are wanted
+            constexpr bool ZERO = decltype(KIND_)::value == 1;     // an input block of zeros (below the image): epilogues, finishing and barrier, no MFMAs
             const int Rk = RB * (s0 - 1 + k);                 // first input row of this block
             // the next block's DMA
-            const bool live = k + 2 < nblk;                   // (the last iteration has no input)
+            const bool live = k + 1 < kz;                     // (the next block is one that reads its input)
             const int yan = Rk + RB, xan = x0 - 1;
             const unsigned orgn = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((b * H + yan + RB) * W + xan + 1) * 128u));
             // finishing: the rows Rk - 6 .. Rk - 3 (their epilogues rode in the previous block, published by its barrier)
@@ -413,13 +431,15 @@ __global__ __launch_bounds__(NT) void conv3x3_ps9_kernel(Ps9Args a)
                     // A chunk is two halves of three MFMAs, each followed by its slice of the op lists: at most one tail MFMA per half (conv3x3_ps4.hip)
                     auto half = [&](auto HC_) __attribute__((always_inline)) {
                         constexpr int hc = decltype(HC_)::value;
+                        if constexpr (!ZERO) {
 #pragma unroll
-                        for (int u = 3 * hc; u < 3 * hc + 3; ++u) {
-                            const int dy = u >> 1, cg = u & 1;
-                            const int sl = (e + 1 - dy + 4) & 3;
-                            acc[sl][cg] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cg][(dy * 3 + dx) * 4 + ks], fr[f % 3], acc[sl][cg], 0, 0, 0);
+                            for (int u = 3 * hc; u < 3 * hc + 3; ++u) {
+                                const int dy = u >> 1, cg = u & 1;
+                                const int sl = (e + 1 - dy + 4) & 3;
+                                acc[sl][cg] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cg][(dy * 3 + dx) * 4 + ks], fr[f % 3], acc[sl][cg], 0, 0, 0);
+                            }
                         }
-                        if constexpr (hc == 0) {      // the fragment of chunk f + 2
+                        if constexpr (hc == 0 && !ZERO) {      // the fragment of chunk f + 2
                             constexpr int f2 = (f + 2) % 12;
                             constexpr int rowsel = f + 2 < 12 ? BUF * RB + e : (e < 3 ? BUF * RB + e + 1 : (BUF ^ 1) * RB);
                             fr[(f + 2) % 3] = *(lds_h8_t)((fa[f2 >> 2] ^ (unsigned)((f2 & 3) * 32)) + (unsigned)(rowsel * ROWB));
@@ -465,7 +485,7 @@ __global__ __launch_bounds__(NT) void conv3x3_ps9_kernel(Ps9Args a)
                     half(std::integral_constant<int, 1>{});
 #ifndef PS9_NOPIN
 #pragma unroll
-                    for (int hc = 0; hc < 2; ++hc) {
+                    for (int hc = 0; hc < (ZERO ? 0 : 2); ++hc) {
                         const int h = 2 * f + hc;
                         const int MH = 20;
                         const int m_lo = h < MH ? h * LM.n / MH : LM.n, m_hi = h < MH ? (h + 1) * LM.n / MH : LM.n;
@@ -493,13 +513,17 @@ __global__ __launch_bounds__(NT) void conv3x3_ps9_kernel(Ps9Args a)
             step(std::integral_constant<int, 3>{});
         };
 
-        int k = 0;
-        for (; k + 2 < nblk; k += 2) {
-            block(k, std::integral_constant<int, 0>{}, std::false_type{});
-            block(k + 1, std::integral_constant<int, 1>{}, std::false_type{});
+        typedef std::integral_constant<int, 0> Run;
+        typedef std::integral_constant<int, 1> Zero;
+        typedef std::integral_constant<int, 2> Last;
+        int k = kfirst;
+        for (; k + 1 < kz; k += 2) {
+            block(k, std::integral_constant<int, 0>{}, Run{});
+            block(k + 1, std::integral_constant<int, 1>{}, Run{});
         }
-        if (k + 1 < nblk) { block(k, std::integral_constant<int, 0>{}, std::false_type{}); ++k; }
-        block(k, std::integral_constant<int, 0>{}, std::true_type{});      // (its ring half is not used)
+        if (k < kz) { block(k, std::integral_constant<int, 0>{}, Run{}); ++k; }
+        if (k < nblk - 1) { block(k, std::integral_constant<int, 0>{}, Zero{}); ++k; }      // (reads no input: its ring half does not matter)
+        block(k, std::integral_constant<int, 0>{}, Last{});
     }
 #endif
 }
@@ -604,15 +628,20 @@ bool launch_conv3x3_ps9(const Ps9Args& a, int max_groups, hipStream_t s)
     if (!ps9_tail_applicable(a.B, a.H, a.W, a.slope) || max_groups < 3) return false;
     const int px = (a.W + kTileW - 1) / kTileW;
     const long long items = (long long)a.B * px * (a.H / RB);
-    int G = (int)std::min<long long>(items, max_groups / 3);      // ranges; three workgroups (phase rows) each
-    if (PS9_XCD && G >= 8) G = G / 8 * 8;                                    // (whole XCD rounds: the kernel's block -> (range, phase row) map keeps a range's three workgroups on one XCD)
+    Ps9Args q = a;
+    int grid;
+    {
+        const int S = max_groups / 8, nq = S / 3, r = S - 3 * nq, G = 8 * nq + (8 * r) / 3;      // the XCD-aware map (see the kernel): G ranges on a grid of 8 S workgroups
+        if (PS9_XCD && nq >= 1 && items >= G) { q.xcd_map = 1; grid = 8 * S; }
+        else { q.xcd_map = 0; grid = 3 * (int)std::min<long long>(items, max_groups / 3); }      // ranges; three workgroups (phase rows) each
+    }
     const bool ragged = a.W % kTileW != 0;
     if (a.split) {
-        if (ragged) conv3x3_ps9_kernel<true, true><<<dim3(3 * G), dim3(NT), LDS_BYTES, s>>>(a);
-        else conv3x3_ps9_kernel<true, false><<<dim3(3 * G), dim3(NT), LDS_BYTES, s>>>(a);
+        if (ragged) conv3x3_ps9_kernel<true, true><<<dim3(grid), dim3(NT), LDS_BYTES, s>>>(q);
+        else conv3x3_ps9_kernel<true, false><<<dim3(grid), dim3(NT), LDS_BYTES, s>>>(q);
     } else {
-        if (ragged) conv3x3_ps9_kernel<false, true><<<dim3(3 * G), dim3(NT), LDS_BYTES, s>>>(a);
-        else conv3x3_ps9_kernel<false, false><<<dim3(3 * G), dim3(NT), LDS_BYTES, s>>>(a);
+        if (ragged) conv3x3_ps9_kernel<false, true><<<dim3(grid), dim3(NT), LDS_BYTES, s>>>(q);
+        else conv3x3_ps9_kernel<false, false><<<dim3(grid), dim3(NT), LDS_BYTES, s>>>(q);
     }
     return true;
 }

@@ -311,6 +311,7 @@ NOT_IN_THE_TABLE = {
     'tail_kernel<1>': 'unfused 1x1 tail (lite with fuse_tail = 0)',
     'tail_kernel<9>': 'first-generation 3x3 tail: MOE_TAIL_V1',
     'tailadd_kernel<false>': 'branch sum into output planes that are not 16-byte aligned',
+    'tailadd3_kernel<false>': 'the same for x3 nets (conv3x3_ps9)',
     'tapsum2_kernel': 'nine-plane fused tail of x2 nets: tail_form = planes',
     'tapsum4_kernel<false>': 'phase-class sums into unaligned output planes',
     'tapsum_kernel<2>': 'nine-plane fused tail, scalar form',
@@ -330,6 +331,7 @@ def test_every_compiled_kernel_instantiation_has_a_user():
     for case, ks in table['cases'].items():      # every default-arithmetic case of the table resolves its layers to library kernels, and the families to their own trunk kernel
         assert ks, case
     assert 'arsb32c_kernel<true, 4>' in table['cases']['a4/auto/frame'] and 'conv3x3_ps4_kernel<2, false>' in table['cases']['a4/auto/frame']
+    assert 'conv3x3_ps9_kernel<true, false>' in table['cases']['a3/auto/frame'] and 'tapsum_kernel<3>' not in table['cases']['a3/auto/frame']      # (round 6: x3 nets off the per-phase form)
     assert 'arsb32c_kernel<true, 3>' in table['cases']['dn_lite5/auto/frame'] and 'conv64_s_kernel<6>' in table['cases']['l25/auto/frame']
     assert 'conv1x1_kernel<true, 4, true>' in table['cases']['lite4/auto/frame'] and not any('conv_mfma' in k for k in table['cases']['lite8/auto/frame'])      # (round 5: lite8 off the generic kernel)
     orphans = sorted(k for k in compiled - launched if k not in NOT_IN_THE_TABLE and not k.startswith(NOT_THE_NET))
