@@ -98,6 +98,7 @@ struct Conv1x1Args {
     const float* tail_w; float* tail_out;         // fused tail: [64] fp32 weights in the chunk's channel order, fp32 plane out
     float slope;                                  // PReLU slope (<= 1; 1: none)
     int B, H, W, r, nchunks, out_cs;
+    int nks;                                      // k-slices of 16 input channels that are not all zeros: 3 for the 48-channel nets (option k48), else 4
 };
 bool launch_conv1x1(const Conv1x1Args& a, int max_groups, hipStream_t s);   // false: shape not compiled (caller uses conv_mfma_kernel)
 hipError_t conv1x1_init();

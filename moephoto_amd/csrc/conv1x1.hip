@@ -101,6 +101,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a)
 #pragma unroll
             for (int e = 0; e < 8; ++e) tw[nb][g][e] = TAIL ? a.tail_w[32 * nb + 16 * g + 8 * hh + e] : 0.f;
     const RowConsts kc = {1.0f, 0.00048828125f, -2048.f};
+    const bool k4 = a.nks > 3;           // (uniform: one scalar branch per chunk)
 
     // ---- this wave's tiles: t = gw, gw + S, ... over (row = b H + y, xt) ------------------------------------------------------------
     const int px = (a.W + 31) >> 5;
@@ -140,9 +141,10 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a)
         // outstanding then merely make the wait longer than necessary.
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 1) * C::NP) : "memory");
         const unsigned tb = ring0 + (unsigned)(slot * C::TILE);
-        half8_t bh[4], blo[4];
+        half8_t bh[4] = {}, blo[4] = {};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
+            if (ks == 3 && !k4) continue;      // (48-channel nets: channels 48..63 are zeros in activations and weights -- the fourth k-slice adds nothing: same bits)
             bh[ks] = *(lds_h8_t)(tb + bofs[ks]);
             if (X3) blo[ks] = *(lds_h8_t)(tb + 4096u + bofs[ks]);
         }
@@ -158,7 +160,8 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) { ah[nb][e] = 0.f; al[nb][e] = 0.f; }
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks == 3 && !k4) continue;
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) {
                     const half8_t whi = *(lds_h8_t)(wl + (unsigned)(((c * SEG + 0) * 8 + 2 * ks + nb) * 1024));
@@ -169,6 +172,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a)
                         al[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, blo[ks], al[nb], 0, 0, 0);
                     }
                 }
+            }
             // epilogue of chunk c: + low-order products, + bias, PReLU in fp32 (slope <= 1), then the tail dot or fp16 (hi [, lo]) stores
             float dot = 0.f;
             unsigned so = 0, vst = 0;

@@ -857,6 +857,7 @@ struct Fwd {
             q.w_hi = blob<half_t>(L.w_hi); q.w_lo = x3 ? blob<half_t>(L.w_lo) : nullptr; q.bias = a.bias;
             q.tail_w = tail1_w; q.tail_out = tail1_out; q.slope = L.slope;
             q.B = B; q.H = H; q.W = W; q.r = L.r; q.nchunks = L.nchunks; q.out_cs = out_cs;
+            q.nks = (L.cin <= 48 && n.opt.k48) ? 3 : 4;
             const int rec = prof_begin(key, (x3 ? 3 : 1) * 2.0 * (double)B * H * W * L.cout * L.cin);
             const bool ok = launch_conv1x1(q, n.max_groups, s);
             prof_end(rec);
