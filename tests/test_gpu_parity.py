@@ -1102,6 +1102,29 @@ def test_x3_upconv_phase_rows_vs_per_phase_form(dev):
         m.set_option('up_impl', 'ps4').set_option('max_groups', 0).set_option('tail_split', 'r')
 
 
+@pytest.mark.parametrize('key', ['a3', 'a4'])
+def test_branch_sum_into_unaligned_output_planes(key, dev):
+    """moe_net_forward writes the caller's tensor directly; when its planes do not start 16-byte aligned (a view one element into a buffer) the branch sums
+    (tailadd / tailadd3, conv3x3_ps4.hip / conv3x3_ps9.hip) take their scalar-store form: the same values, bit for bit, as into an aligned tensor -- fp32 and fp16."""
+    from moephoto_amd import _lib
+    m = module_for(key)
+    sc = m.scale
+    x = gd.noise_image(61, (3, 24, 40))[:, None]
+    for dt, code in ((torch.float32, _lib.F32), (torch.float16, _lib.F16)):
+        xd = torch.from_numpy(x).to(dev).to(dt)
+        md = module_for(key, dtype=dt) if dt == torch.float16 else m
+        want = md(xd)[-1]
+        n = want.numel()
+        buf = torch.full((n + 16,), float('nan'), dtype=dt, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        sB, _, sH, sW = xd.stride()
+        _lib.check(_lib.lib().moe_net_forward(md._h, xd.data_ptr(), code, 3, 24, 40, sB, sH, sW, None, buf.data_ptr() + buf.element_size(), code, None, stream))
+        torch.cuda.synchronize()
+        got = buf[1:1 + n].view(want.shape)
+        assert torch.equal(got, want), (key, str(dt), float((got.float() - want.float()).abs().max()))
+        assert torch.isnan(buf[0]) and torch.isnan(buf[1 + n:]).all()          # nothing written outside the planes
+
+
 def test_integration_md_stub_drives_every_family(dev):
     """INTEGRATION.md section 1 is the binding a MoePhoto maintainer would add (a ctypes stub over include/moephoto_amd.h).  This test EXECUTES that text --
     the first python block of the file, with the library path filled in -- and drives one SR key, one NetDN key, one SEDN key and one lite key through the
