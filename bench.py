@@ -110,7 +110,8 @@ def main():
     ap.add_argument('--no-dropin-loop', action='store_true', help='skip the per-tile drop-in loop leg')
     ap.add_argument('--config', type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json's configs[N-1]: 2 = the headline (default), 3 = 4K l25 -> a2 chain, "
                     '4 = batch of 64 1080p frames, 5 = one 8K frame -> 32K with 512-px tiles (bench_extra.py)')
-    ap.add_argument('--wire', default='f32', choices=['f32', 'f16s'], help='configs 3-5 under --gpus N: tile results between ranks as fp32, or as fp16 + fp32 seams (dist.py)')
+    ap.add_argument('--wire', default='f16s', choices=['f32', 'f16s'], help='--gpus N: tile results between ranks as fp16 + fp32 seams (default: the canvases are fp16 and come out bit-identical, '
+                    '0.54-0.57 of the bytes on the links; dist.py), or as fp32')
     ap.add_argument('--strong', action='store_true', help='--gpus N: ONE frame per step, its 40 tiles dealt over the N ranks and the canvas folded in row bands (strong scaling: '
                     'the north star\'s "tiles of a frame across the GPUs") instead of N frames per step (weak scaling, the default)')
     ap.add_argument('--no-extras', action='store_true', help='config 2: skip the roofline objects of the HBM-bound members and the I/O edges')
@@ -194,8 +195,8 @@ def main():
             return ip.doCrop(opt, fr[0])
         from moephoto_amd.dist import run_frame_bands, run_frames
         if strong:      # one frame: tiles round-robin over the ranks, every rank folds its row band; the canvas stays sharded
-            return run_frame_bands(opt, fr[:1], out_dtype=torch.float16, max_tiles_per_batch=args.tiles_per_batch)
-        return run_frames(opt, fr, out_dtype=torch.float16, max_tiles_per_batch=args.tiles_per_batch)
+            return run_frame_bands(opt, fr[:1], out_dtype=torch.float16, max_tiles_per_batch=args.tiles_per_batch, wire=args.wire)
+        return run_frames(opt, fr, out_dtype=torch.float16, max_tiles_per_batch=args.tiles_per_batch, wire=args.wire)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -266,6 +267,7 @@ def main():
                    'parallelism': ('tile-parallel x{}: ONE frame, tiles round-robin over the ranks, all-to-all of tile results + blend strips, every rank folds its row band (canvas stays sharded)'.format(world) if strong else
                                    'tile-parallel x{} (round-robin tiles, all-to-all of tile results, stitch on rank f%N)'.format(world)) if world > 1 else 'single GPU',
                    'precision': precision, 'exact_blocks': model.exact_blocks(),
+                   **({'wire': args.wire} if world > 1 else {}),
                    'input': 'natural-image-like synthetic frame (tests/golden_defs.natural_image)'},
         'device': {'compute_units': dinfo['compute_units'], 'max_clock_ghz': round(dinfo['clock_khz'] / 1e6, 3),
                    'peak_fp16_mfma_tflops': round(peak_tflops, 1), 'peak_formula': 'CUs x 4 SIMD x 1024 FLOP/clk x max clock (hipDeviceProp)'},
