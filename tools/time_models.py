@@ -24,7 +24,7 @@ runDN.mode_switch['25'] = (path,) + tuple(runDN.mode_switch['25'][1:])
 x = torch.from_numpy(gd.natural_image(1000, (3, 1080, 1920))).cuda().half()
 cases = [('SR a2', lambda: runSR.getOpt({'model': 'a', 'scale': 2})), ('SR a3', lambda: runSR.getOpt({'model': 'a', 'scale': 3})),
          ('SR a4', lambda: runSR.getOpt({'model': 'a', 'scale': 4})), ('SR lite2', lambda: runSR.getOpt({'model': 'lite', 'scale': 2})),
-         ('SR lite4', lambda: runSR.getOpt({'model': 'lite', 'scale': 4})), ('DN lite5', lambda: runDN.getOpt({'model': 'lite5'})),
+         ('SR lite4', lambda: runSR.getOpt({'model': 'lite', 'scale': 4})), ('SR lite8', lambda: runSR.getOpt({'model': 'lite', 'scale': 8})), ('DN lite5', lambda: runDN.getOpt({'model': 'lite5'})),
          ('DN l25', lambda: runDN.getOpt({'model': '25'}))]
 only = os.environ.get('TM_ONLY')          # e.g. TM_ONLY='SR a3' TM_PREC=fp16 under rocprofv3
 for name, mk in cases:
