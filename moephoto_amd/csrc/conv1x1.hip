@@ -14,7 +14,8 @@
 //   * weight rows are permuted when they are copied to LDS so that registers 8g..8g+7 of a lane are eight consecutive channels:
 //     16-byte stores without any lane pairing; bias and the tail weights sit in LDS / registers in the same order.
 //
-// LDS: weights NCH x 8 KiB (x2 with split operands) + bias + 4 waves x RING x (4 | 8) KiB.
+// LDS: weights NCH x 8 KiB (x2 with split operands) + bias + 4 waves x RING x (4 | 8) KiB.  Round 6: the split-operand four-chunk stages of the 48-channel nets (lite's
+// default arithmetic; template NKS = 3: the all-zero fourth k-slice is not computed) hold their 48 weight fragments in registers (192 AGPRs): no weight bytes in LDS, RING = 4.
 #include "common.h"
 #include "rowtile.h"
 
@@ -25,12 +26,16 @@ typedef unsigned u2_t __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(3))) half8_t* lds_h8_t;
 typedef const __attribute__((address_space(3))) float4_t* lds_f4_t;
 
-template <bool X3, int NCH, bool TAIL>
+template <bool X3, int NCH, bool TAIL, int NKS = 4>
 struct Cfg {
     static constexpr int NP = X3 ? 8 : 4;                                    // DMA pieces per tile
     static constexpr int NS = TAIL ? 2 : NCH * 4 * (X3 ? 2 : 1);            // stores per tile
     static constexpr int TILE = X3 ? 8192 : 4096;
-    static constexpr int WB = NCH * 8 * 1024 * (X3 ? 2 : 1);
+    // Round 6: the split-operand upsampler stages of the 48-channel nets (X3, four chunks, three k-slices: lite's default arithmetic) keep their 48 weight fragments in
+    // REGISTERS (192 AGPRs) instead of 64 KiB of LDS: the ring grows from two tiles to four per wave (one tile ahead was 32 KiB in flight per CU against the ~46 KiB that
+    // 6 TB/s x 2 us over 256 CUs ask for: these launches ran at 0.6 of the HBM roofline), and 48 KiB of LDS reads per tile disappear
+    static constexpr bool WREG = X3 && NCH == 4 && NKS == 3;
+    static constexpr int WB = WREG ? 0 : NCH * 8 * 1024 * (X3 ? 2 : 1);
     static constexpr int BIASB = NCH * 256;
     static constexpr int byLds = (163840 - WB - BIASB) / (4 * TILE);
     static constexpr int byCnt = 1 + 63 / NP;
@@ -39,11 +44,12 @@ struct Cfg {
     static_assert(RING >= 2, "ring");
 };
 
-template <bool X3, int NCH, bool TAIL>
+template <bool X3, int NCH, bool TAIL, int NKS = 4>
 __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)      // (the host pass only needs the launch stub)
-    using C = Cfg<X3, NCH, TAIL>;
+    using C = Cfg<X3, NCH, TAIL, NKS>;
+    constexpr bool WREG = C::WREG;
     constexpr int R = NCH == 4 ? 2 : 1, RING = C::RING, SEG = X3 ? 2 : 1;
     constexpr unsigned kOOR = 0xFFFF0000u;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -52,13 +58,28 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a)
     const int w4 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, hh = lane >> 5;
 
+    half8_t wr[WREG ? NCH : 1][WREG ? SEG : 1][WREG ? 2 * NKS : 1];      // (WREG: fragment (chunk, part, 2 ks + nb), in AGPRs)
     // ---- weights -> LDS: fragment (chunk c, part s, k-slice ks, n-block nb) at ((c * SEG + s) * 8 + 2 ks + nb) KiB.  MFMA row i = 8q + 4h + e
     // of a 32x32 result lands in register 4q + e of the lanes hh = h; giving row i the channel 16 (q >> 1) + 8 h + 4 (q & 1) + e makes registers
     // 8g .. 8g+7 of lane (j, hh) the consecutive channels 32 nb + 16 g + 8 hh ..
     {
         const int wi = lane & 31, wq = wi >> 3;
         const int src = (lane & 32) | (16 * (wq >> 1) + 8 * ((wi >> 2) & 1) + 4 * (wq & 1) + (wi & 3));
-        for (int f = w4; f < NCH * SEG * 8; f += 4) {
+        if constexpr (WREG) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int sg = 0; sg < SEG; ++sg)
+#pragma unroll
+                    for (int k = 0; k < 2 * NKS; ++k) wr[c][sg][k] = *(const half8_t*)((sg == 0 ? a.w_hi : a.w_lo) + ((c * 8 + k) * 64 + src) * 8);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int sg = 0; sg < SEG; ++sg)
+#pragma unroll
+                    for (int k = 0; k < 2 * NKS; ++k) asm volatile("" : "+a"(wr[c][sg][k]));
+        }
+        for (int f = w4; f < (WREG ? 0 : NCH * SEG * 8); f += 4) {
             const int c = f / (SEG * 8), s = (f / 8) % SEG, k = f & 7;
             const half_t* wsrc = (s == 0 ? a.w_hi : a.w_lo) + ((c * 8 + k) * 64 + src) * 8;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wsrc, (__attribute__((address_space(3))) void*)(smem + f * 1024), 16, 0, 0);
@@ -144,7 +165,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a)
         half8_t bh[4] = {}, blo[4] = {};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            if (ks == 3 && !k4) continue;      // (48-channel nets: channels 48..63 are zeros in activations and weights -- the fourth k-slice adds nothing: same bits)
+            if (ks >= NKS || (ks == 3 && !k4)) continue;      // (48-channel nets: channels 48..63 are zeros in activations and weights -- the fourth k-slice adds nothing: same bits)
             bh[ks] = *(lds_h8_t)(tb + bofs[ks]);
             if (X3) blo[ks] = *(lds_h8_t)(tb + 4096u + bofs[ks]);
         }
@@ -161,13 +182,17 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a)
                 for (int e = 0; e < 16; ++e) { ah[nb][e] = 0.f; al[nb][e] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                if (ks == 3 && !k4) continue;
+                if (ks >= NKS || (ks == 3 && !k4)) continue;
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) {
-                    const half8_t whi = *(lds_h8_t)(wl + (unsigned)(((c * SEG + 0) * 8 + 2 * ks + nb) * 1024));
+                    half8_t whi;
+                    if constexpr (WREG) whi = wr[c][0][2 * ks + nb];
+                    else whi = *(lds_h8_t)(wl + (unsigned)(((c * SEG + 0) * 8 + 2 * ks + nb) * 1024));
                     ah[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, bh[ks], ah[nb], 0, 0, 0);
                     if (X3) {
-                        const half8_t wlo = *(lds_h8_t)(wl + (unsigned)(((c * SEG + 1) * 8 + 2 * ks + nb) * 1024));
+                        half8_t wlo;
+                        if constexpr (WREG) wlo = wr[c][SEG - 1][2 * ks + nb];
+                        else wlo = *(lds_h8_t)(wl + (unsigned)(((c * SEG + 1) * 8 + 2 * ks + nb) * 1024));
                         al[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, bh[ks], al[nb], 0, 0, 0);
                         al[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, blo[ks], al[nb], 0, 0, 0);
                     }
@@ -240,16 +265,16 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a)
 #endif
 }
 
-template <bool X3, int NCH, bool TAIL>
+template <bool X3, int NCH, bool TAIL, int NKS = 4>
 hipError_t set_limit()
 {
-    return hipFuncSetAttribute((const void*)conv1x1_kernel<X3, NCH, TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<X3, NCH, TAIL>::LDS);
+    return hipFuncSetAttribute((const void*)conv1x1_kernel<X3, NCH, TAIL, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<X3, NCH, TAIL, NKS>::LDS);
 }
 
-template <bool X3, int NCH, bool TAIL>
+template <bool X3, int NCH, bool TAIL, int NKS = 4>
 void launch_t(const Conv1x1Args& a, int groups, hipStream_t s)
 {
-    conv1x1_kernel<X3, NCH, TAIL><<<dim3(groups), dim3(256), Cfg<X3, NCH, TAIL>::LDS, s>>>(a);
+    conv1x1_kernel<X3, NCH, TAIL, NKS><<<dim3(groups), dim3(256), Cfg<X3, NCH, TAIL, NKS>::LDS, s>>>(a);
 }
 
 }  // namespace
@@ -263,6 +288,8 @@ hipError_t conv1x1_init()
     if ((e = set_limit<true, 4, false>()) != hipSuccess) return e;
     if ((e = set_limit<false, 4, true>()) != hipSuccess) return e;
     if ((e = set_limit<true, 4, true>()) != hipSuccess) return e;
+    if ((e = set_limit<true, 4, false, 3>()) != hipSuccess) return e;
+    if ((e = set_limit<true, 4, true, 3>()) != hipSuccess) return e;
     return hipSuccess;
 }
 
@@ -281,7 +308,7 @@ bool launch_conv1x1(const Conv1x1Args& a, int max_groups, hipStream_t s)
     const int groups = (int)std::min<long long>(max_groups, (ntiles + 3) / 4);
     if (groups < 1) return false;
     if (a.nchunks == 1) { if (x3) launch_t<true, 1, false>(a, groups, s); else launch_t<false, 1, false>(a, groups, s); }
-    else if (!tail) { if (x3) launch_t<true, 4, false>(a, groups, s); else launch_t<false, 4, false>(a, groups, s); }
-    else { if (x3) launch_t<true, 4, true>(a, groups, s); else launch_t<false, 4, true>(a, groups, s); }
+    else if (!tail) { if (x3 && a.nks == 3) launch_t<true, 4, false, 3>(a, groups, s); else if (x3) launch_t<true, 4, false>(a, groups, s); else launch_t<false, 4, false>(a, groups, s); }
+    else { if (x3 && a.nks == 3) launch_t<true, 4, true, 3>(a, groups, s); else if (x3) launch_t<true, 4, true>(a, groups, s); else launch_t<false, 4, true>(a, groups, s); }
     return true;
 }
