@@ -176,10 +176,16 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a)
         for (int c = 0; c < NCH; ++c) {
             const int si = c >> 1, sj = c & 1;
             float16_t ah[2], al[2];
+            // the bias is the accumulators' initial value (round 6: one add per output less in an epilogue that holds the folded-tail form at 13.7 VALU instructions per MFMA)
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) { ah[nb][e] = 0.f; al[nb][e] = 0.f; }
+                for (int g = 0; g < 2; ++g) {
+                    const float4_t b0 = *(lds_f4_t)(bl + (unsigned)((64 * c + 32 * nb + 16 * g) * 4));
+                    const float4_t b1 = *(lds_f4_t)(bl + (unsigned)((64 * c + 32 * nb + 16 * g + 4) * 4));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { ah[nb][8 * g + e] = b0[e]; ah[nb][8 * g + 4 + e] = b1[e]; al[nb][8 * g + e] = 0.f; al[nb][8 * g + 4 + e] = 0.f; }
+                }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 if (ks >= NKS || (ks == 3 && !k4)) continue;
@@ -198,7 +204,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a)
                     }
                 }
             }
-            // epilogue of chunk c: + low-order products, + bias, PReLU in fp32 (slope <= 1), then the tail dot or fp16 (hi [, lo]) stores
+            // epilogue of chunk c: + low-order products, PReLU in fp32 (slope <= 1), then the tail dot or fp16 (hi [, lo]) stores
             float dot = 0.f;
             unsigned so = 0, vst = 0;
             if (!TAIL) {
@@ -215,14 +221,11 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a)
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
-                    const float4_t b0 = *(lds_f4_t)(bl + (unsigned)((64 * c + 32 * nb + 16 * g) * 4));
-                    const float4_t b1 = *(lds_f4_t)(bl + (unsigned)((64 * c + 32 * nb + 16 * g + 4) * 4));
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         float t = ah[nb][8 * g + e];
                         if (X3) t = __builtin_fmaf(al[nb][8 * g + e], 0.00048828125f, t);
-                        t += e < 4 ? b0[e] : b1[e - 4];
                         const float ts = t * a.slope;
                         asm("v_max_f32 %0, %1, %2" : "=v"(v[e]) : "v"(t), "v"(ts));
                     }
