@@ -10,7 +10,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['conv_mfma.hip', 'conv3x3_sp.hip', 'conv3x3_rw.hip', 'conv3x3_ps4.hip', 'conv3x3_ps9.hip', 'arsb32c.hip', 'conv64_x3.hip', 'conv64_q8.hip', 'conv64_sq.hip', 'arsb_sq.hip', 'conv64_s.hip', 'conv1x1.hip', 'misc_kernels.hip', 'blend.hip', 'engine.cpp', 'planner.cpp']
+SOURCES = ['conv_mfma.hip', 'conv3x3_sp.hip', 'conv3x3_rw.hip', 'conv3x3_ps4.hip', 'conv3x3_ps9.hip', 'arsb32c.hip', 'conv64_x3.hip', 'conv64_q8.hip', 'conv64_sq.hip', 'arsb_sq.hip', 'conv64_s.hip', 'conv1x1.hip', 'conv1x1_f2.hip', 'misc_kernels.hip', 'blend.hip', 'engine.cpp', 'planner.cpp']
 HEADERS = ['common.h', 'engine.h', os.path.join('..', '..', 'include', 'moephoto_amd.h')]
 LIB = os.path.join(HERE, 'libmoephoto_amd.so')
 ARCH = 'gfx950'
@@ -18,7 +18,7 @@ ARCH = 'gfx950'
 # (MI355X_MICROARCH.md, per-instruction constants): scalar fp32 in the epilogues that ride in an MFMA stream
 # -amdgpu-mfma-vgpr-form: MFMA results in arch VGPRs (the weights occupy the AGPRs), so the epilogues read them without v_accvgpr_read
 EXTRA_FLAGS = {'blend.hip': ['-ffp-contract=off'],      # three separately rounded operations per blend, as torch evaluates the reference's expression
-               'arsb32c.hip': ['-fno-slp-vectorize', '-fno-honor-nans', '-mllvm', '-amdgpu-mfma-vgpr-form=1'], 'conv64_x3.hip': ['-fno-slp-vectorize'], 'conv64_q8.hip': ['-fno-slp-vectorize', '-fno-honor-nans', '-mllvm', '-amdgpu-mfma-vgpr-form=1'], 'conv64_sq.hip': ['-fno-slp-vectorize', '-fno-honor-nans', '-mllvm', '-amdgpu-mfma-vgpr-form=1'], 'arsb_sq.hip': ['-fno-slp-vectorize', '-fno-honor-nans', '-mllvm', '-amdgpu-mfma-vgpr-form=1'], 'conv64_s.hip': ['-fno-slp-vectorize', '-fno-honor-nans', '-mllvm', '-amdgpu-mfma-vgpr-form=1'], 'conv1x1.hip': ['-fno-slp-vectorize', '-mllvm', '-amdgpu-mfma-vgpr-form=1'], 'conv3x3_sp.hip': ['-fno-honor-nans'], 'conv3x3_rw.hip': ['-fno-honor-nans', '-fno-slp-vectorize'],
+               'arsb32c.hip': ['-fno-slp-vectorize', '-fno-honor-nans', '-mllvm', '-amdgpu-mfma-vgpr-form=1'], 'conv64_x3.hip': ['-fno-slp-vectorize'], 'conv64_q8.hip': ['-fno-slp-vectorize', '-fno-honor-nans', '-mllvm', '-amdgpu-mfma-vgpr-form=1'], 'conv64_sq.hip': ['-fno-slp-vectorize', '-fno-honor-nans', '-mllvm', '-amdgpu-mfma-vgpr-form=1'], 'arsb_sq.hip': ['-fno-slp-vectorize', '-fno-honor-nans', '-mllvm', '-amdgpu-mfma-vgpr-form=1'], 'conv64_s.hip': ['-fno-slp-vectorize', '-fno-honor-nans', '-mllvm', '-amdgpu-mfma-vgpr-form=1'], 'conv1x1.hip': ['-fno-slp-vectorize', '-mllvm', '-amdgpu-mfma-vgpr-form=1'], 'conv1x1_f2.hip': ['-fno-slp-vectorize', '-mllvm', '-amdgpu-mfma-vgpr-form=1'], 'conv3x3_sp.hip': ['-fno-honor-nans'], 'conv3x3_rw.hip': ['-fno-honor-nans', '-fno-slp-vectorize'],
                'conv3x3_ps4.hip': ['-fno-honor-nans', '-fno-slp-vectorize', '-mllvm', '-amdgpu-mfma-vgpr-form=1'],
                'conv3x3_ps9.hip': ['-fno-honor-nans', '-fno-slp-vectorize', '-mllvm', '-amdgpu-mfma-vgpr-form=1']}
 

@@ -103,6 +103,20 @@ struct Conv1x1Args {
 bool launch_conv1x1(const Conv1x1Args& a, int max_groups, hipStream_t s);   // false: shape not compiled (caller uses conv_mfma_kernel)
 hipError_t conv1x1_init();
 
+// Two upsampler stages of MoeNet_lite2 (1x1 48 -> 192, PixelShuffle(2), PReLU, twice) + the folded 48 -> 1 tail in one launch, split operands (conv1x1_f2.hip):
+// the tensor between the stages never exists; same bits as the two launches of conv1x1.hip
+struct Conv1x1F2Args {
+    const half_t* in_hi; const half_t* in_lo;     // [B][H][W][64]
+    const half_t* wa_hi; const half_t* wa_lo;     // stage A: packed A fragments [chunk 4][8] (pack_conv order)
+    const half_t* wb_hi; const half_t* wb_lo;     // stage B
+    const float* bias_a; const float* bias_b;     // [256] each, packed output-channel order
+    const float* tail_w; float* tail_out;         // [64] fp32 tail weights; fp32 plane [B][4H][4W]
+    float slope_a, slope_b;                       // PReLU slopes (<= 1)
+    int B, H, W;
+};
+bool launch_conv1x1_f2(const Conv1x1F2Args& a, int max_groups, hipStream_t s);   // false: not applicable
+hipError_t conv1x1_f2_init();
+
 void launch_conv_mfma(const ConvArgs& a, int taps, int nseg, hipStream_t s);
 int conv_mfma_max_groups();  // persistent workgroups the device holds (1 per CU)
 hipError_t conv_mfma_init(); // raise dynamic-LDS limits once per process

@@ -212,8 +212,13 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a)
                     so = (unsigned)(tc.row * a.W + tc.xt * 32) * out_px;
                     vst = okx ? (unsigned)j * out_px + (unsigned)hh * 16u : kOOR;
                 } else {
+#ifdef C1_ABL_COALESCE      // timing ablation (results WRONG): the same bytes into the same 8-KiB row segment, every store instruction 1 KiB contiguous
+                    so = ((unsigned)(2 * tc.row + si) * Wo + (unsigned)(64 * tc.xt)) * out_px + (unsigned)(sj * 4096);
+                    vst = (unsigned)lane * 16u;
+#else
                     so = ((unsigned)(2 * tc.row + si) * Wo + (unsigned)(64 * tc.xt + sj)) * out_px;
                     vst = okx ? (unsigned)(2 * j) * out_px + (unsigned)hh * 16u : kOOR;
+#endif
                 }
                 if (tc.t >= ntiles) so = kOOR;
             }
@@ -243,10 +248,15 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a)
                             }
                         }
                         const u4_t dh = {h[0], h[1], h[2], h[3]};
-                        __builtin_amdgcn_raw_buffer_store_b128(dh, rout, vst + (unsigned)(nb * 64 + g * 32), so, 0);
+#ifdef C1_ABL_COALESCE
+                        constexpr unsigned kPiece = 1024u;
+#else
+                        constexpr unsigned kPiece = 32u;
+#endif
+                        __builtin_amdgcn_raw_buffer_store_b128(dh, rout, vst + (unsigned)(nb * 2 + g) * kPiece, so, 0);
                         if (X3) {
                             const u4_t dl = {l[0], l[1], l[2], l[3]};
-                            __builtin_amdgcn_raw_buffer_store_b128(dl, routl, vst + (unsigned)(nb * 64 + g * 32), so, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(dl, routl, vst + (unsigned)(nb * 2 + g) * kPiece, so, 0);
                         }
                     }
                 }

@@ -385,6 +385,7 @@ hipError_t conv_mfma_init()
     if ((e = conv64_s_init()) != hipSuccess) return e;
     if ((e = conv64_x3_init()) != hipSuccess) return e;
     if ((e = conv1x1_init()) != hipSuccess) return e;
+    if ((e = conv1x1_f2_init()) != hipSuccess) return e;
     if ((e = conv3x3_rw_init()) != hipSuccess) return e;
     if ((e = conv3x3_ps4_init()) != hipSuccess) return e;
     if ((e = conv3x3_ps9_init()) != hipSuccess) return e;

@@ -88,6 +88,7 @@ struct NetOptions {
     int sp_impl = 1;          // sp_impl     auto (1: conv3x3_rw where it wins) | rw (2: conv3x3_rw for every epilogue it compiles) | sp (0: conv3x3_sp only)
     int tail_split = 1;       // tail_split  0 | r (1, default: the R branch's fused tail also splits its activation operand) | ru (2)
     int tail_form = 1;        // tail_form   sums (1, default: phase-class sums + aprons from conv3x3_rw, tapsum4) | planes (0: nine tap planes per phase, tapsum2)
+    int up_fuse2 = 1;         // up_fuse2    1 (default): lite's last two upsampler stages + the folded tail in ONE launch (conv1x1_f2.hip, split operands) | 0: stage by stage (conv1x1.hip; same bits)
     int up_impl = 1;          // up_impl     ps4 (1, default: the fused-tail up-conv with all four phases in one workgroup, conv3x3_ps4.hip + tailadd) | rw (0: conv3x3_rw
                               //             per phase, phase-class sums, tapsum4 -- round 3's form, kept for A/B and for shapes ps4 does not take)
     bool conv1x1 = true;      // conv1x1     lite's 1x1 layers on conv1x1.hip (0: generic kernel)
@@ -156,6 +157,7 @@ struct NetOptions {
         if (key == "tail_split") { const int t = tri(v, "0", "r", "ru", -1); if (t < 0) return false; tail_split = t; return true; }
         if (key == "tail_form") { const int t = tri(v, "planes", "sums", nullptr, -1); if (t < 0) return false; tail_form = t; return true; }
         if (key == "up_impl") { const int t = tri(v, "rw", "ps4", nullptr, -1); if (t < 0) return false; up_impl = t; return true; }
+        if (key == "up_fuse2") { const int t = onoff(v); if (t < 0) return false; up_fuse2 = t; return true; }
         if (key == "lo8") { const int t = onoff(v); if (t < 0) return false; lo8 = t; return true; }
         if (key == "x3_impl") { const int t = tri(v, "auto", "x3", "q8", -1); if (t < 0) return false; x3_impl = t; return true; }
         if (key == "k48") { const int t = onoff(v); if (t < 0) return false; k48 = t; return true; }
@@ -197,7 +199,7 @@ struct NetOptions {
     }
     void from_env()
     {
-        static const char* const names[][2] = {{"MOE_CONV_IMPL", "conv_impl"}, {"MOE_SP_IMPL", "sp_impl"}, {"MOE_TAIL_SPLIT", "tail_split"}, {"MOE_TAIL_FORM", "tail_form"}, {"MOE_UP_IMPL", "up_impl"},
+        static const char* const names[][2] = {{"MOE_CONV_IMPL", "conv_impl"}, {"MOE_SP_IMPL", "sp_impl"}, {"MOE_TAIL_SPLIT", "tail_split"}, {"MOE_TAIL_FORM", "tail_form"}, {"MOE_UP_IMPL", "up_impl"}, {"MOE_UP_FUSE2", "up_fuse2"},
                                                {"MOE_CONV1X1", "conv1x1"}, {"MOE_Q8_IMPL", "q8_impl"}, {"MOE_EXACT_FUSE", "exact_fuse"}, {"MOE_BRANCH_STREAMS", "branch_streams"}, {"MOE_BRANCH_GROUPS", "branch_groups"}, {"MOE_AUTO_CALIBRATE", "auto_calibrate"}, {"MOE_OVERLAP_CALLS", "overlap_calls"}, {"MOE_OVERLAP_GROUPS", "overlap_groups"}, {"MOE_OVERLAP_FORK", "overlap_fork"}, {"MOE_S64", "s64"}, {"MOE_K48", "k48"}, {"MOE_X3_IMPL", "x3_impl"}, {"MOE_LO8", "lo8"}, {"MOE_X3_FUSE", "x3_fuse"}, {"MOE_ARSB_FUSE", "arsb_fuse"}, {"MOE_FUSE_TAIL", "fuse_tail"},
                                                {"MOE_SEDN_FUSE", "sedn_fuse"}, {"MOE_POOL_FUSE", "pool_fuse"}, {"MOE_DBG", "dbg"}, {"MOE_TRACE_KEY", "trace_key"},
                                                {"MOE_TILES_PER_BATCH", "tiles_per_batch"}, {"MOE_MAX_GROUPS", "max_groups"}};
@@ -1499,6 +1501,31 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
             H = h; W = w;
             for (int st = 0; st < n.stages; ++st) {
                 const std::string ckey = std::string(br == 0 ? "ures" : "uim") + ".up" + std::to_string(st);
+                if (fuse1 && f.x3 && n.opt.up_fuse2 && n.opt.conv1x1 && n.opt.k48 && n.opt.conv_impl == 2 && n.stages >= 2 && st == n.stages - 2 && cur.lo &&
+                    128ll * B * H * W < (1ll << 32) - 65536) {
+                    // the last TWO stages and the tail in one launch (conv1x1_f2.hip): every layer of the upsampler is pointwise -- the tensor between the stages never exists
+                    const ConvLayer& LA = n.convs[n.conv_index.at(ckey)];
+                    const ConvLayer& LB = n.convs[n.conv_index.at(std::string(br == 0 ? "ures" : "uim") + ".up" + std::to_string(st + 1))];
+                    if (LA.taps == 1 && LB.taps == 1 && LA.cin <= 48 && LB.cin <= 48 && LA.r == 2 && LB.r == 2 && LA.nchunks == 4 && LB.nchunks == 4 && LA.w_lo && LB.w_lo &&
+                        LA.slope <= 1.f && LB.slope <= 1.f && LA.scale == 1.f && LB.scale == 1.f) {
+                        part[br] = (float*)f.ar.take((size_t)2 * B * H * 4 * W * 4 * 4);
+                        if (!f.dry()) {
+                            Conv1x1F2Args q{};
+                            q.in_hi = cur.hi; q.in_lo = cur.lo;
+                            q.wa_hi = f.blob<half_t>(LA.w_hi); q.wa_lo = f.blob<half_t>(LA.w_lo); q.wb_hi = f.blob<half_t>(LB.w_hi); q.wb_lo = f.blob<half_t>(LB.w_lo);
+                            q.bias_a = LA.has_bias ? f.blob<float>(LA.bias) : f.small<float>("zero_bias"); q.bias_b = LB.has_bias ? f.blob<float>(LB.bias) : f.small<float>("zero_bias");
+                            q.tail_w = f.small<float>(br == 0 ? "tail_r.f32" : "tail_u.f32"); q.tail_out = part[br];
+                            q.slope_a = LA.slope; q.slope_b = LB.slope; q.B = B; q.H = H; q.W = W;
+                            const int rec = f.prof_begin(ckey, 3.0 * 2.0 * (double)B * H * W * (LA.cout * LA.cin + 4.0 * LB.cout * LB.cin));
+                            const bool ok = launch_conv1x1_f2(q, n.max_groups, s);
+                            f.prof_end(rec);
+                            if (!ok) return fail(MOE_EINVAL, "fused upsampler stages (conv1x1_f2) rejected layer %s", ckey.c_str());
+                            f.tail1_parts = 1;
+                        }
+                        H *= 4; W *= 4;
+                        break;
+                    }
+                }
                 if (fuse1 && st == n.stages - 1) {
                     part[br] = (float*)f.ar.take((size_t)2 * B * H * 2 * W * 2 * 4);
                     f.conv(ckey, cur, Act{}, nullptr, H, W, nullptr, nullptr, nullptr, nullptr,

@@ -1125,6 +1125,32 @@ def test_branch_sum_into_unaligned_output_planes(key, dev):
         assert torch.isnan(buf[0]) and torch.isnan(buf[1 + n:]).all()          # nothing written outside the planes
 
 
+@pytest.mark.parametrize('key', ['lite4', 'lite8'])
+def test_lite_last_two_upsampler_stages_in_one_launch(key, dev):
+    """Option up_fuse2 (default on; conv1x1_f2.hip): the last two upsampler stages of MoeNet_lite2 and the folded 48 -> 1 tail in ONE launch -- every layer there is pointwise
+    (1x1 convs, pixel shuffle, PReLU), the 4x-resolution tensor between the stages never exists -- against the stage-by-stage form (conv1x1.hip): per layer the same products
+    in the same order and the same hi / lo roundings between the stages, so the outputs are EQUAL bit for bit; within 2e-5 of the oracle (split operands); on shapes ragged
+    against the 32-pixel tiles, tiny ones, several planes; a launch repeated gives the same bits."""
+    arch = gd.MODELS[key][0]
+    sd = gd.state_dict_for(key, load_state_dict_file)
+    m = module_for(key)
+    try:
+        for shape in ((3, 24, 40), (2, 16, 72), (1, 9, 35), (3, 8, 8), (5, 40, 33), (2, 64, 96)):
+            for kind in ('natural', 'noise'):
+                x = (gd.natural_image(67, shape) if kind == 'natural' else gd.noise_image(67, shape))[:, None]
+                xd = torch.from_numpy(x).to(dev)
+                y0 = m.set_option('up_fuse2', 0)(xd)[-1].cpu().numpy()
+                y1 = m.set_option('up_fuse2', 1)(xd)[-1].cpu().numpy()
+                y2 = m(xd)[-1].cpu().numpy()
+                assert np.isfinite(y1).all(), (key, shape, kind)
+                assert np.array_equal(y1, y0), (key, shape, kind, float(np.abs(y1 - y0).max()))
+                assert np.array_equal(y1, y2), (key, shape, kind)
+                want = onets.forward(arch, sd, x).numpy()
+                assert np.abs(y1 - want).max() <= 2e-5, (key, shape, kind, float(np.abs(y1 - want).max()))
+    finally:
+        m.set_option('up_fuse2', 1)
+
+
 def test_integration_md_stub_drives_every_family(dev):
     """INTEGRATION.md section 1 is the binding a MoePhoto maintainer would add (a ctypes stub over include/moephoto_amd.h).  This test EXECUTES that text --
     the first python block of the file, with the library path filled in -- and drives one SR key, one NetDN key, one SEDN key and one lite key through the

@@ -335,7 +335,7 @@ def test_every_compiled_kernel_instantiation_has_a_user():
     assert 'arsb32c_kernel<true, 4>' in table['cases']['a4/auto/frame'] and 'conv3x3_ps4_kernel<2, false>' in table['cases']['a4/auto/frame']
     assert 'conv3x3_ps9_kernel<true, false>' in table['cases']['a3/auto/frame'] and 'tapsum_kernel<3>' not in table['cases']['a3/auto/frame']      # (round 6: x3 nets off the per-phase form)
     assert 'arsb32c_kernel<true, 3>' in table['cases']['dn_lite5/auto/frame'] and 'conv64_s_kernel<6>' in table['cases']['l25/auto/frame']
-    assert 'conv1x1_kernel<true, 4, true, 3>' in table['cases']['lite4/auto/frame'] and not any('conv_mfma' in k for k in table['cases']['lite8/auto/frame'])      # (round 5: lite8 off the generic kernel)
+    assert 'conv1x1_f2_kernel' in table['cases']['lite4/auto/frame'] and 'conv1x1_kernel<true, 4, true, 3>' in table['cases']['lite2/auto/frame'] and not any('conv_mfma' in k for k in table['cases']['lite8/auto/frame'])      # (round 5: lite8 off the generic kernel)
     orphans = sorted(k for k in compiled - launched if k not in NOT_IN_THE_TABLE and not k.startswith(NOT_THE_NET))
     assert not orphans, 'compiled, launched by no case of tests/golden/kernel_resolution.json and not explained in NOT_IN_THE_TABLE: {}'.format(orphans)
     stale = sorted(k for k in NOT_IN_THE_TABLE if k not in compiled)
