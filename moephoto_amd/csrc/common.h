@@ -289,6 +289,7 @@ struct StemArgs {
     half_t* out_lo;                  // FP16X3 low part or nullptr
     int B, H, W, taps;
     int out_lo8;                     // the low part as fp8 e4m3 words of lo / 4, one byte a channel (what conv64_q8 with in8 reads: ConvX3Args)
+    unsigned char* out_lo8_extra;    // or nullptr: the same fp8 words IN ADDITION to the fp16 low part in out_lo (NetDN: its tail convs read the fp16 pair, conv_input2 the fp8 words)
 };
 void launch_stem(const StemArgs& a, hipStream_t s);
 

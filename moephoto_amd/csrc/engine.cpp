@@ -761,7 +761,7 @@ struct Fwd {
     // The two correction products on fp8 operands (conv64_q8.hip): 'mixed' only -- 'fp16x3' promises 2e-5, fp8 corrections deliver ~15 bits.
     // auto: the SR nets, whose all-tile sweep keeps its margin with it (worst 8.1e-4 either way, profiles/r03/m_conv64_q8.txt); the DN nets
     // (dn_lite5 7.2e-4 -> 8.6e-4 of the 1e-3 bar) stay on three fp16 products.
-    bool use_q8() const { return mixed && (n.opt.x3_impl == 2 || (n.opt.x3_impl == 0 && n.scale > 1)); }
+    bool use_q8() const { return mixed && (n.opt.x3_impl == 2 || (n.opt.x3_impl == 0 && (n.scale > 1 || n.arch == MOE_ARCH_NETDN))); }      // (round 6: NetDN too -- dn_lite5 7.6e-4 against 8.1e-4 on conv64_x3, and faster)
     // what conv() asks of a layer before it hands it to conv64_q8 (besides the tensors' own conditions)
     bool q8_capable(const ConvLayer& L) const
     {
@@ -1060,9 +1060,10 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         if (steep) { f.acc32_elems = (size_t)P * 64; f.acc32 = (float*)f.ar.take(f.acc32_elems * 4); }
     }
 
-    auto stem = [&](const Act& out) {
+    auto stem = [&](const Act& out, unsigned char* lo8_extra = nullptr) {
         if (f.dry()) return;
         StemArgs a{};
+        a.out_lo8_extra = lo8_extra;
         a.x = x; a.x_dtype = x_dtype; a.x_off = x_off_dev; a.sB = sB; a.sH = sH; a.sW = sW;
         a.w = f.small<float>("stem"); a.slope = n.scalars.at("stem_slope");
         a.out = out.hi; a.out_lo = out.lo; a.out_lo8 = out.lo8; a.B = B; a.H = h; a.W = w; a.taps = (int)n.scalars.at("stem_taps");
@@ -1106,12 +1107,16 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         // holds the fp8 residual it reads) -- for the fused ARSB kernels behind it.  The stem writes its low part in that form too (conv_input2 is its only
         // reader: the U branch takes the fp16 part).  Debug taps read fp16 low parts: no chain under set_debug.
         f.Hq = h; f.Wq = w;
-        bool chain8 = mixed && f.use_q8() && n.opt.lo8 && n.arch != MOE_ARCH_NETDN && !n.debug && !f.direct && nx >= 1 && A.lo && Bb.lo && Cc.lo;
+        // NetDN (round 6): its tail convs read the stem's fp16 pair at the very end, so the stem writes the fp8 words IN ADDITION, into a buffer of its own (lo8x: a whole
+        // low-part buffer -- the two-launch fallback of the last exact block writes its fp16 low part there instead of into the stem's)
+        const bool dn = n.arch == MOE_ARCH_NETDN;
+        bool chain8 = mixed && f.use_q8() && n.opt.lo8 && !n.debug && !f.direct && nx >= 1 && (f.dry() || (A.lo && Bb.lo && Cc.lo));      // (the planning pass has no pointers: lo8x below must be planned too)
         for (int i = 0; chain8 && i <= nx; ++i)
             for (int j = (i == 0 ? 2 : 1); chain8 && j <= 2; ++j)
                 chain8 = f.q8_capable(n.convs[n.conv_index.at(i == 0 ? std::string("input2") : "c" + std::to_string(j) + "_" + std::to_string(i))]);
-        A.lo8 = Bb.lo8 = chain8;
-        stem(A);
+        half_t* lo8x = (dn && chain8) ? (half_t*)f.ar.take((size_t)P * 64 * 2 + 2048) : nullptr;
+        A.lo8 = chain8 && !dn; Bb.lo8 = chain8;
+        stem(A, (unsigned char*)lo8x);
         f.tap("stem", A, h, w, 64, n.C);
         // ---- the two upsampler branches: R on the trunk output, U on the stem output (models.py:117-123) -- planned here, because a small launch set starts its U branch NOW, on a second stream ----
         Act fin[2];
@@ -1250,7 +1255,11 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
             }
             if (rc) return rc;
         }
-        if (int rc = trunk_conv("input2", A, Bb, nullptr, mixed)) return rc;
+        {
+            Act Ain = A;
+            if (lo8x) { Ain.lo = lo8x; Ain.lo8 = true; }
+            if (int rc = trunk_conv("input2", Ain, Bb, nullptr, mixed)) return rc;
+        }
         f.tap("input2", Bb, h, w, 64, n.C);
         // single-pass ARSBs run as ONE kernel (arsb32c.hip: conv_1's output never leaves the CU) that streams cur -> oth;
         // split-operand / debug blocks use the two-launch form, conv_1 into `oth`, conv_2 back onto `cur`
@@ -1324,7 +1333,7 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
             if (mixed && !ex) bin.lo = nullptr;
             if (int rc = trunk_conv(k1, bin, m, nullptr, ex)) return rc;
             const Act resid = cur;
-            if (ex && chain8 && i == nx) { cur.lo = A.lo; cur.lo8 = false; }      // (see chain8)
+            if (ex && chain8 && i == nx) { cur.lo = lo8x ? lo8x : A.lo; cur.lo8 = false; }      // (see chain8)
             if (int rc = trunk_conv(k2, m, cur, &resid, ex)) return rc;
             f.tap("arsb" + std::to_string(i), cur, h, w, 64, n.C);
         }
@@ -1501,8 +1510,8 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
             H = h; W = w;
             for (int st = 0; st < n.stages; ++st) {
                 const std::string ckey = std::string(br == 0 ? "ures" : "uim") + ".up" + std::to_string(st);
-                if (fuse1 && f.x3 && n.opt.up_fuse2 && n.opt.conv1x1 && n.opt.k48 && n.opt.conv_impl == 2 && n.stages >= 2 && st == n.stages - 2 && cur.lo &&
-                    128ll * B * H * W < (1ll << 32) - 65536) {
+                if (fuse1 && f.x3 && n.opt.up_fuse2 && n.opt.conv1x1 && n.opt.k48 && n.opt.conv_impl == 2 && n.stages >= 2 && st == n.stages - 2 &&
+                    128ll * B * H * W < (1ll << 32) - 65536) {      // (f.x3: every activation has its low part; no pointer tests -- the planning pass decides alike)
                     // the last TWO stages and the tail in one launch (conv1x1_f2.hip): every layer of the upsampler is pointwise -- the tensor between the stages never exists
                     const ConvLayer& LA = n.convs[n.conv_index.at(ckey)];
                     const ConvLayer& LB = n.convs[n.conv_index.at(std::string(br == 0 ? "ures" : "uim") + ".up" + std::to_string(st + 1))];

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
     for (int i = threadIdx.x; i < TAPS * 64; i += 256) w[i] = a.w[i];
     __syncthreads();
     // fp8 low parts: MODE.FP16_OVFL makes the conversion saturate (+-448) instead of producing NaN (conv64_q8.hip runs the same way)
-    if (a.out_lo8) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1\n\ts_nop 3" ::: "memory");
+    if (a.out_lo8 || a.out_lo8_extra) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1\n\ts_nop 3" ::: "memory");
     constexpr int PX = 8;
     const int nq = (a.W + PX - 1) / PX;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
 #pragma unroll
             for (int e = 0; e < 8; ++e) l[e] = (half_t)((prelu(acc[e], a.slope) - (float)o[e]) * 2048.f);
             if (!a.out_lo8) *(half8_t*)(a.out_lo + p * 64 + cg) = l;
-            else {
+            if (a.out_lo8 || a.out_lo8_extra) {
                 // the eight values / 4 as e4m3: the word conv64_q8's own conversion would make of them (its cvt4: one asm block, the two words' conversions
                 // alternating, a wait state behind the half-register writes)
                 typedef unsigned u4v __attribute__((ext_vector_type(4)));
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
                              "v_cvt_scalef32_pk_fp8_f16 %1, %5, %6 op_sel:[0,0,1]\n\t"
                              "s_nop 0"
                              : "=&v"(p0), "=&v"(p1) : "v"(lw[0]), "v"(lw[1]), "v"(lw[2]), "v"(lw[3]), "v"(quarter));
-                *(uint2*)((unsigned char*)a.out_lo + p * 64 + cg) = make_uint2(p0, p1);
+                *(uint2*)((a.out_lo8 ? (unsigned char*)a.out_lo : a.out_lo8_extra) + p * 64 + cg) = make_uint2(p0, p1);
             }
         }
     }

@@ -841,8 +841,9 @@ def test_fp8_low_part_chain(key, blocks, dev):
 
 
 def test_fp8_corrections_default_by_family(dev):
-    """x3_impl = auto: the SR nets run their exact layers through conv64_q8 (bit-equal to the explicit setting), the DN nets through conv64_x3."""
-    for key, same_as in (('a2', 'q8'), ('dn_lite5', 'x3')):
+    """x3_impl = auto: the SR nets AND (since round 6: the stem writes the fp8 words beside its fp16 low part) the DN nets run their exact layers through the fp8-correction
+    kernels (bit-equal to the explicit setting 'q8', not to 'x3')."""
+    for key, same_as in (('a2', 'q8'), ('dn_lite5', 'q8')):
         m = module_for(key)
         try:
             xd = torch.from_numpy(gd.noise_image(31, (2, 40, 72))[:, None]).to(dev)
