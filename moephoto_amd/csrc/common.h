@@ -289,7 +289,6 @@ struct StemArgs {
     half_t* out_lo;                  // FP16X3 low part or nullptr
     int B, H, W, taps;
     int out_lo8;                     // the low part as fp8 e4m3 words of lo / 4, one byte a channel (what conv64_q8 with in8 reads: ConvX3Args)
-    unsigned char* out_lo8_extra;    // or nullptr: the same fp8 words IN ADDITION to the fp16 low part in out_lo (NetDN: its tail convs read the fp16 pair, conv_input2 the fp8 words)
 };
 void launch_stem(const StemArgs& a, hipStream_t s);
 
@@ -298,6 +297,7 @@ struct TailArgs {
     const half_t* w0; const half_t* w1;    // [taps][64] fp16
     const half_t* in0_lo; const half_t* in1_lo;  // FP16X3 low parts (all four or none)
     const half_t* w0_lo; const half_t* w1_lo;
+    int in1_lo8;                           // in1_lo holds fp8 e4m3 words of lo / 4, one byte a channel (what the stem wrote for conv_input2: NetDN on the fp8-correction chain); 3x3 taps only
     const void* skip; int skip_dtype;      // optional 1-channel skip (SEDN: + x), strided like the stem input
     const long long* skip_off; long long skip_sB, skip_sH, skip_sW;   // skip_off nullptr: b * skip_sB
     void* y; int y_dtype;                  // MOE_F32 / MOE_F16

@@ -1060,10 +1060,9 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         if (steep) { f.acc32_elems = (size_t)P * 64; f.acc32 = (float*)f.ar.take(f.acc32_elems * 4); }
     }
 
-    auto stem = [&](const Act& out, unsigned char* lo8_extra = nullptr) {
+    auto stem = [&](const Act& out) {
         if (f.dry()) return;
         StemArgs a{};
-        a.out_lo8_extra = lo8_extra;
         a.x = x; a.x_dtype = x_dtype; a.x_off = x_off_dev; a.sB = sB; a.sH = sH; a.sW = sW;
         a.w = f.small<float>("stem"); a.slope = n.scalars.at("stem_slope");
         a.out = out.hi; a.out_lo = out.lo; a.out_lo8 = out.lo8; a.B = B; a.H = h; a.W = w; a.taps = (int)n.scalars.at("stem_taps");
@@ -1080,7 +1079,7 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         if (u) { a.in1 = u->hi; a.w1 = f.small<half_t>("tail_u"); }
         if (r->lo && (!u || u->lo)) {     // split operands (FP16X3; MIXED on NetDN, whose tail convs read the hi + lo stream directly)
             a.in0_lo = r->lo; a.w0_lo = f.small<half_t>("tail_r.lo");
-            if (u) { a.in1_lo = u->lo; a.w1_lo = f.small<half_t>("tail_u.lo"); }
+            if (u) { a.in1_lo = u->lo; a.w1_lo = f.small<half_t>("tail_u.lo"); a.in1_lo8 = u->lo8; }
         }
         if (skip) { a.skip = x; a.skip_dtype = x_dtype; a.skip_off = x_off_dev; a.skip_sB = sB; a.skip_sH = sH; a.skip_sW = sW; }
         a.y = y; a.y_dtype = y_dtype; a.y_off = y_off_dev; a.B = B; a.H = H; a.W = W; a.taps = (int)n.scalars.at("tail_taps");
@@ -1107,16 +1106,18 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         // holds the fp8 residual it reads) -- for the fused ARSB kernels behind it.  The stem writes its low part in that form too (conv_input2 is its only
         // reader: the U branch takes the fp16 part).  Debug taps read fp16 low parts: no chain under set_debug.
         f.Hq = h; f.Wq = w;
-        // NetDN (round 6): its tail convs read the stem's fp16 pair at the very end, so the stem writes the fp8 words IN ADDITION, into a buffer of its own (lo8x: a whole
-        // low-part buffer -- the two-launch fallback of the last exact block writes its fp16 low part there instead of into the stem's)
+        // NetDN (round 6): its tail convs read the stem's hi + lo pair at the very end -- tail3 takes the stem's low part as the same fp8 words (TailArgs::in1_lo8), so the
+        // stem writes ONE low-part form here too.  What NetDN cannot share is the buffer: the two-launch fallback of the last exact block writes its fp16 low part into a
+        // buffer of its own (lo16x) instead of over the stem's words.
         const bool dn = n.arch == MOE_ARCH_NETDN;
-        bool chain8 = mixed && f.use_q8() && n.opt.lo8 && !n.debug && !f.direct && nx >= 1 && (f.dry() || (A.lo && Bb.lo && Cc.lo));      // (the planning pass has no pointers: lo8x below must be planned too)
+        bool chain8 = mixed && f.use_q8() && n.opt.lo8 && !n.debug && !f.direct && nx >= 1 && (f.dry() || (A.lo && Bb.lo && Cc.lo));      // (the planning pass has no pointers: lo16x below must be planned too)
+        if (dn && (int)n.scalars.at("tail_taps") != 9) chain8 = false;      // (the 1x1 tail kernel reads fp16 pairs only)
         for (int i = 0; chain8 && i <= nx; ++i)
             for (int j = (i == 0 ? 2 : 1); chain8 && j <= 2; ++j)
                 chain8 = f.q8_capable(n.convs[n.conv_index.at(i == 0 ? std::string("input2") : "c" + std::to_string(j) + "_" + std::to_string(i))]);
-        half_t* lo8x = (dn && chain8) ? (half_t*)f.ar.take((size_t)P * 64 * 2 + 2048) : nullptr;
-        A.lo8 = chain8 && !dn; Bb.lo8 = chain8;
-        stem(A, (unsigned char*)lo8x);
+        half_t* lo16x = (dn && chain8) ? (half_t*)f.ar.take((size_t)P * 64 * 2 + 2048) : nullptr;
+        A.lo8 = Bb.lo8 = chain8;
+        stem(A);
         f.tap("stem", A, h, w, 64, n.C);
         // ---- the two upsampler branches: R on the trunk output, U on the stem output (models.py:117-123) -- planned here, because a small launch set starts its U branch NOW, on a second stream ----
         Act fin[2];
@@ -1255,11 +1256,7 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
             }
             if (rc) return rc;
         }
-        {
-            Act Ain = A;
-            if (lo8x) { Ain.lo = lo8x; Ain.lo8 = true; }
-            if (int rc = trunk_conv("input2", Ain, Bb, nullptr, mixed)) return rc;
-        }
+        if (int rc = trunk_conv("input2", A, Bb, nullptr, mixed)) return rc;
         f.tap("input2", Bb, h, w, 64, n.C);
         // single-pass ARSBs run as ONE kernel (arsb32c.hip: conv_1's output never leaves the CU) that streams cur -> oth;
         // split-operand / debug blocks use the two-launch form, conv_1 into `oth`, conv_2 back onto `cur`
@@ -1333,7 +1330,7 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
             if (mixed && !ex) bin.lo = nullptr;
             if (int rc = trunk_conv(k1, bin, m, nullptr, ex)) return rc;
             const Act resid = cur;
-            if (ex && chain8 && i == nx) { cur.lo = lo8x ? lo8x : A.lo; cur.lo8 = false; }      // (see chain8)
+            if (ex && chain8 && i == nx) { cur.lo = lo16x ? lo16x : A.lo; cur.lo8 = false; }      // (see chain8)
             if (int rc = trunk_conv(k2, m, cur, &resid, ex)) return rc;
             f.tap("arsb" + std::to_string(i), cur, h, w, 64, n.C);
         }

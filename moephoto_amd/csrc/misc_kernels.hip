@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
     for (int i = threadIdx.x; i < TAPS * 64; i += 256) w[i] = a.w[i];
     __syncthreads();
     // fp8 low parts: MODE.FP16_OVFL makes the conversion saturate (+-448) instead of producing NaN (conv64_q8.hip runs the same way)
-    if (a.out_lo8 || a.out_lo8_extra) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1\n\ts_nop 3" ::: "memory");
+    if (a.out_lo8) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1\n\ts_nop 3" ::: "memory");
     constexpr int PX = 8;
     const int nq = (a.W + PX - 1) / PX;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
 #pragma unroll
             for (int e = 0; e < 8; ++e) l[e] = (half_t)((prelu(acc[e], a.slope) - (float)o[e]) * 2048.f);
             if (!a.out_lo8) *(half8_t*)(a.out_lo + p * 64 + cg) = l;
-            if (a.out_lo8 || a.out_lo8_extra) {
+            else {
                 // the eight values / 4 as e4m3: the word conv64_q8's own conversion would make of them (its cvt4: one asm block, the two words' conversions
                 // alternating, a wait state behind the half-register writes)
                 typedef unsigned u4v __attribute__((ext_vector_type(4)));
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
                              "v_cvt_scalef32_pk_fp8_f16 %1, %5, %6 op_sel:[0,0,1]\n\t"
                              "s_nop 0"
                              : "=&v"(p0), "=&v"(p1) : "v"(lw[0]), "v"(lw[1]), "v"(lw[2]), "v"(lw[3]), "v"(quarter));
-                *(uint2*)((a.out_lo8 ? (unsigned char*)a.out_lo : a.out_lo8_extra) + p * 64 + cg) = make_uint2(p0, p1);
+                *(uint2*)((unsigned char*)a.out_lo + p * 64 + cg) = make_uint2(p0, p1);
             }
         }
     }
@@ -238,7 +238,16 @@ __global__ __launch_bounds__(256) void tail3_kernel(TailArgs a)
             const long long off = ((long long)(b * a.H + yy) * a.W + x) * 64 + cgi * 8;
             half8_t v = {0, 0, 0, 0, 0, 0, 0, 0}, vl = {0, 0, 0, 0, 0, 0, 0, 0};
             if (ok) v = *(const half8_t*)(in + off);
-            if (ok && in_lo) vl = *(const half8_t*)(in_lo + off);
+            if (ok && in_lo) {
+                if (which && a.in1_lo8) {      // the stem's low part as fp8 words of lo / 4 (bytes in channel order): every value * 4 is exact in fp16
+                    typedef float f2v __attribute__((ext_vector_type(2)));
+                    const uint2 q = *(const uint2*)((const unsigned char*)in_lo + off);
+                    const f2v f0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)q.x, false), f1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)q.x, true);
+                    const f2v f2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)q.y, false), f3 = __builtin_amdgcn_cvt_pk_f32_fp8((int)q.y, true);
+                    vl = half8_t{(half_t)(f0[0] * 4.f), (half_t)(f0[1] * 4.f), (half_t)(f1[0] * 4.f), (half_t)(f1[1] * 4.f),
+                                 (half_t)(f2[0] * 4.f), (half_t)(f2[1] * 4.f), (half_t)(f3[0] * 4.f), (half_t)(f3[1] * 4.f)};
+                } else vl = *(const half8_t*)(in_lo + off);
+            }
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
                 const int o = r - dy;
@@ -1085,7 +1094,7 @@ void launch_tail(const TailArgs& a, hipStream_t s)
 {
     static const bool old9 = [] { const char* e = getenv("MOE_TAIL_V1"); return e && !strcmp(e, "1"); }();
     const int blocks = ((a.W + 31) / 32) * ((a.H + 7) / 8) * a.B;
-    if (a.taps == 9 && !old9) hipLaunchKernelGGL(tail3_kernel, dim3(((a.W + 29) / 30) * ((a.H + 7) / 8) * a.B), dim3(256), 0, s, a);
+    if (a.taps == 9 && (!old9 || a.in1_lo8)) hipLaunchKernelGGL(tail3_kernel, dim3(((a.W + 29) / 30) * ((a.H + 7) / 8) * a.B), dim3(256), 0, s, a);
     else if (a.taps == 9) hipLaunchKernelGGL((tail_kernel<9>), dim3(blocks), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((tail_kernel<1>), dim3(blocks), dim3(256), 0, s, a);
 }
