@@ -202,8 +202,14 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a)
 // per-dx partial sums S[dx] of its column (they belong to the outputs at columns c+1, c, c-1 for dx = 0, 1, 2).  The partials go through LDS once:
 // thread (c, o = cg) then adds S0[c-1] + S1[c] + S2[c+1] over the eight channel groups and stores one pixel.
 // (The first form loads every element three times -- once per dx -- and ran at 1.3-2 TB/s.)
+// LO (the hi + lo form: FP16X3, MIXED on NetDN): the operands are put together in fp32 -- x = hi + lo 2^-11 and w = w_hi + w_lo 2^-11 are exact there (22 significant bits) --
+// and every tap is four packed fp32 FMAs on two accumulators (even / odd channel pairs), instead of three v_dot2 products (hi hi, lo hi, hi lo) of four instructions each: the
+// kernel was held by its VALU stream (profiles/r06/zf_pmc_tail3_sedn.txt: 130 VALU instructions per loaded pixel-group pair), and the lo lo term comes with it.
+// LO: 0 fp16 operands, 1 hi + lo pairs, 2 hi + lo pairs with in1's low part as fp8 words (TailArgs::in1_lo8)
+template <int LO>
 __global__ __launch_bounds__(256) void tail3_kernel(TailArgs a)
 {
+    typedef float f2v __attribute__((ext_vector_type(2)));
     __shared__ float part[3][8][32][9];          // [dx][output row][column][channel group], padded: 27.6 KB
     const int cgi = threadIdx.x & 7, pc = threadIdx.x >> 3;
     const int nbx = (a.W + 29) / 30, nby = (a.H + 7) / 8;
@@ -218,48 +224,102 @@ __global__ __launch_bounds__(256) void tail3_kernel(TailArgs a)
     for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
         for (int o = 0; o < 8; ++o) S[dx][o] = 0.f;
-#pragma unroll 1
-    for (int which = 0; which < 2; ++which) {
-        const half_t* in = which ? a.in1 : a.in0;
-        if (!in) continue;
-        const half_t* wsrc = (which ? a.w1 : a.w0) + cgi * 8;
-        const half_t* wlo_src = (which ? a.w1_lo : a.w0_lo);
-        const half_t* in_lo = which ? a.in1_lo : a.in0_lo;
-        half8_t w[9], wl[9];
+    if constexpr (LO != 0) {
+        f2v S2[3][8];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            w[t] = *(const half8_t*)(wsrc + t * 64);
-            wl[t] = in_lo ? *(const half8_t*)(wlo_src + cgi * 8 + t * 64) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
-        }
+        for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-        for (int r = 0; r < 10; ++r) {
-            const int yy = y0 + r - 1;
-            const bool ok = xin && yy >= 0 && yy < a.H;
-            const long long off = ((long long)(b * a.H + yy) * a.W + x) * 64 + cgi * 8;
-            half8_t v = {0, 0, 0, 0, 0, 0, 0, 0}, vl = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (ok) v = *(const half8_t*)(in + off);
-            if (ok && in_lo) {
-                if (which && a.in1_lo8) {      // the stem's low part as fp8 words of lo / 4 (bytes in channel order): every value * 4 is exact in fp16
-                    typedef float f2v __attribute__((ext_vector_type(2)));
-                    const uint2 q = *(const uint2*)((const unsigned char*)in_lo + off);
-                    const f2v f0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)q.x, false), f1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)q.x, true);
-                    const f2v f2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)q.y, false), f3 = __builtin_amdgcn_cvt_pk_f32_fp8((int)q.y, true);
-                    vl = half8_t{(half_t)(f0[0] * 4.f), (half_t)(f0[1] * 4.f), (half_t)(f1[0] * 4.f), (half_t)(f1[1] * 4.f),
-                                 (half_t)(f2[0] * 4.f), (half_t)(f2[1] * 4.f), (half_t)(f3[0] * 4.f), (half_t)(f3[1] * 4.f)};
-                } else vl = *(const half8_t*)(in_lo + off);
+            for (int o = 0; o < 8; ++o) S2[dx][o] = f2v{0.f, 0.f};
+        const int xc = min(max(x, 0), a.W - 1);
+        auto branch = [&](auto which_c) {
+            constexpr int which = decltype(which_c)::value;
+            constexpr bool lo8 = which == 1 && LO == 2;
+            const half_t* in = which ? a.in1 : a.in0;
+            if (!in) return;
+            const half_t* wsrc = (which ? a.w1 : a.w0) + cgi * 8;
+            const half_t* wlo_src = (which ? a.w1_lo : a.w0_lo) + cgi * 8;
+            const half_t* in_lo = which ? a.in1_lo : a.in0_lo;
+            f2v w[9][4];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const half8_t wh = *(const half8_t*)(wsrc + t * 64), wl = *(const half8_t*)(wlo_src + t * 64);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    w[t][e] = f2v{(float)wh[2 * e] + (float)wl[2 * e] * 0.00048828125f, (float)wh[2 * e + 1] + (float)wl[2 * e + 1] * 0.00048828125f};
             }
+            // rows are fetched two ahead of their use into a ring of three, from clamped addresses (no branch around a load: the values of a pixel outside the image are
+            // zeroed at their use); the scheduler left to itself hoists all twenty loads: 256 VGPRs, one wave per SIMD
+            half8_t vh[3];
+            uint4 vq[3];
+            auto fetch = [&](int r, half8_t& h, uint4& q) {
+                const int yy = min(max(y0 + r - 1, 0), a.H - 1);
+                const long long off = ((long long)(b * a.H + yy) * a.W + xc) * 64 + cgi * 8;
+                h = *(const half8_t*)(in + off);
+                if constexpr (lo8) { const uint2 t = *(const uint2*)((const unsigned char*)in_lo + off); q = make_uint4(t.x, t.y, 0, 0); }
+                else q = *(const uint4*)(in_lo + off);
+            };
+            fetch(0, vh[0], vq[0]);
+            fetch(1, vh[1], vq[1]);
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                const int o = r - dy;
-                if (o < 0 || o >= 8) continue;
+            for (int r = 0; r < 10; ++r) {
+                if (r + 2 < 10) fetch(r + 2, vh[(r + 2) % 3], vq[(r + 2) % 3]);
+                __builtin_amdgcn_sched_barrier(0);
+                const int yy = y0 + r - 1;
+                const float keep = (xin && yy >= 0 && yy < a.H) ? 1.f : 0.f;
+                const half8_t v = vh[r % 3];
+                const uint4 q = vq[r % 3];
+                f2v xv[4];
+                if constexpr (lo8) {      // the stem's low part as fp8 words of lo / 4 (bytes in channel order)
+                    const f2v l0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)q.x, false), l1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)q.x, true);
+                    const f2v l2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)q.y, false), l3 = __builtin_amdgcn_cvt_pk_f32_fp8((int)q.y, true);
+                    const f2v ll[4] = {l0, l1, l2, l3};
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    S[dx][o] = dot8(v, w[dy * 3 + dx], S[dx][o]);
-                    if (in_lo) {   // FP16X3: (a_hi + a_lo/2048) * (w_hi + w_lo/2048), cross terms kept
-                        float c = dot8(vl, w[dy * 3 + dx], 0.f);
-                        c = dot8(v, wl[dy * 3 + dx], c);
-                        S[dx][o] += c * 0.00048828125f;
-                    }
+                    for (int e = 0; e < 4; ++e) xv[e] = f2v{(float)v[2 * e] + ll[e][0] * 0.001953125f, (float)v[2 * e + 1] + ll[e][1] * 0.001953125f} * keep;
+                } else {
+                    const half8_t vl = __builtin_bit_cast(half8_t, q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xv[e] = f2v{(float)v[2 * e] + (float)vl[2 * e] * 0.00048828125f, (float)v[2 * e + 1] + (float)vl[2 * e + 1] * 0.00048828125f} * keep;
+                }
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int o = r - dy;
+                    if (o < 0 || o >= 8) continue;
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) S2[dx][o] = __builtin_elementwise_fma(xv[e], w[dy * 3 + dx][e], S2[dx][o]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        branch(std::integral_constant<int, 0>{});
+        branch(std::integral_constant<int, 1>{});
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int o = 0; o < 8; ++o) S[dx][o] = S2[dx][o][0] + S2[dx][o][1];
+    } else {
+#pragma unroll 1
+        for (int which = 0; which < 2; ++which) {
+            const half_t* in = which ? a.in1 : a.in0;
+            if (!in) continue;
+            const half_t* wsrc = (which ? a.w1 : a.w0) + cgi * 8;
+            half8_t w[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) w[t] = *(const half8_t*)(wsrc + t * 64);
+#pragma unroll
+            for (int r = 0; r < 10; ++r) {
+                const int yy = y0 + r - 1;
+                const bool ok = xin && yy >= 0 && yy < a.H;
+                const long long off = ((long long)(b * a.H + yy) * a.W + x) * 64 + cgi * 8;
+                half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (ok) v = *(const half8_t*)(in + off);
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int o = r - dy;
+                    if (o < 0 || o >= 8) continue;
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) S[dx][o] = dot8(v, w[dy * 3 + dx], S[dx][o]);
                 }
             }
         }
@@ -1094,7 +1154,12 @@ void launch_tail(const TailArgs& a, hipStream_t s)
 {
     static const bool old9 = [] { const char* e = getenv("MOE_TAIL_V1"); return e && !strcmp(e, "1"); }();
     const int blocks = ((a.W + 31) / 32) * ((a.H + 7) / 8) * a.B;
-    if (a.taps == 9 && (!old9 || a.in1_lo8)) hipLaunchKernelGGL(tail3_kernel, dim3(((a.W + 29) / 30) * ((a.H + 7) / 8) * a.B), dim3(256), 0, s, a);
+    if (a.taps == 9 && (!old9 || a.in1_lo8)) {
+        const dim3 g(((a.W + 29) / 30) * ((a.H + 7) / 8) * a.B);
+        if (a.in0_lo && a.in1_lo8) hipLaunchKernelGGL(tail3_kernel<2>, g, dim3(256), 0, s, a);
+        else if (a.in0_lo) hipLaunchKernelGGL(tail3_kernel<1>, g, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(tail3_kernel<0>, g, dim3(256), 0, s, a);
+    }
     else if (a.taps == 9) hipLaunchKernelGGL((tail_kernel<9>), dim3(blocks), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((tail_kernel<1>), dim3(blocks), dim3(256), 0, s, a);
 }
