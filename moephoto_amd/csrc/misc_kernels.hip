@@ -705,13 +705,50 @@ __global__ __launch_bounds__(256) void sedn_fmean_kernel(SednFuseArgs a)
             sums[0][t] = u;
         }
     }
-    for (int i = t; i < 5 * 64; i += 256) {
-        const int c = i >> 6, ch = i & 63;
-        if (c == 0 && a.pooled) continue;
-        float v = 0.f;
+    if (a.pooled) {
+        // round 6: with the totals formed by the producing conv only the border is left of sedn_xsum's work -- 2 W + 2 H pixels, visited HERE (by each of the plane's four
+        // blocks) instead of by a launch of its own: index i in [0, 2W + 2H) = first row, last row, first column, last column (corner pixels appear in a row list and in a
+        // column list, as they must); thread = (pixel lane t / 8 of 32, channel group t % 8), then a fixed-order sum over the 32 lanes
+        __shared__ float bred[4][32][64];
+        const int cg = t & 7, pl = t >> 3;
+        float acc[4][8];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[c][e] = 0.f;
+        const int nb = 2 * a.W + 2 * a.H;
+#pragma unroll 4
+        for (int i = pl; i < nb; i += 32) {
+            int y, x, c;
+            if (i < 2 * a.W) { c = i < a.W ? 0 : 1; y = c ? a.H - 1 : 0; x = c ? i - a.W : i; }
+            else { const int k = i - 2 * a.W; c = k < a.H ? 2 : 3; x = c == 3 ? a.W - 1 : 0; y = c == 3 ? k - a.H : k; }
+            const half8_t v = *(const half8_t*)(a.x + ((long long)b * HW + (long long)y * a.W + x) * 64 + cg * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float u = (float)v[e];
+                acc[0][e] += c == 0 ? u : 0.f; acc[1][e] += c == 1 ? u : 0.f; acc[2][e] += c == 2 ? u : 0.f; acc[3][e] += c == 3 ? u : 0.f;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bred[c][pl][cg * 8 + e] = acc[c][e];
+        __syncthreads();
+        {
+            const int c = t >> 6, ch = t & 63;
+            float v = 0.f;
 #pragma unroll 8
-        for (int k = 0; k < a.nslab; ++k) v += a.partial[(((long long)b * a.nslab + k) * 5 + c) * 64 + ch];
-        sums[c][ch] = v;
+            for (int k = 0; k < 32; ++k) v += bred[c][k][ch];
+            sums[1 + c][ch] = v;
+        }
+    } else {
+        for (int i = t; i < 5 * 64; i += 256) {
+            const int c = i >> 6, ch = i & 63;
+            float v = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < a.nslab; ++k) v += a.partial[(((long long)b * a.nslab + k) * 5 + c) * 64 + ch];
+            sums[c][ch] = v;
+        }
     }
     {
         const int q = t >> 6, ch = t & 63;
@@ -747,16 +784,14 @@ __global__ __launch_bounds__(256) void sedn_fmean_kernel(SednFuseArgs a)
     if (t < 64) a.gate[b * 256 + blockIdx.y * 64 + t] = ((red[0][t] + red[1][t]) + (red[2][t] + red[3][t])) / (float)HW;   // (the MEAN; the gate is formed in sedn_weff)
 }
 
-// W_eff[b][co][k] = sum_m (W_t[co][m] g[b][m]) W_256[m][k]: 64 x 576 x 256 per plane.  Block = all 64 co x 64 k (one tap), 4 x 4 per thread: two 16-byte LDS reads per
-// 16 FMAs (round 4: 32 co x 64 k, 2 x 4 per thread, 24 bytes per 8 FMAs -- LDS-bound at 36 us a launch); grid 9 x B.
+// W_eff[b][co][k] = sum_m (W_t[co][m] g[b][m]) W_256[m][k]: 64 x 576 x 256 per plane.  Block = all 64 co x 64 k (one tap); grid 9 x B.  (Round 4: 32 co x 64 k, 2 x 4 per
+// thread on VALU FMAs, LDS-bound at 36 us a launch; round 5: 4 x 4 per thread, 27 us.)
 __global__ __launch_bounds__(256) void sedn_weff_kernel(SednFuseArgs a)
 {
-    constexpr int MC = 64;               // m per stage
-    __shared__ __attribute__((aligned(16))) float As[MC][68];         // [m][co] (+4: rows stay 16-byte aligned, the transposing stores spread over the banks)
-    __shared__ __attribute__((aligned(16))) float Bs[MC][64];         // [m][k]
-    __shared__ float mean[256], part[256], hid[16], gate[256];
+    __shared__ __attribute__((aligned(16))) half_t Cs[64][72];        // the block's result [co][ci] (+8: rows stay 16-byte aligned)
+    __shared__ __attribute__((aligned(16))) float gate[256];
+    __shared__ float mean[256], part[256], hid[16];
     const int tap = blockIdx.x, b = blockIdx.y;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     {   // squeeze-excite gate of this plane from its channel means (16 KFLOP: every block redoes it rather than wait for a launch)
         const int t = threadIdx.x;
         mean[t] = a.gate[b * 256 + t];
@@ -782,36 +817,37 @@ __global__ __launch_bounds__(256) void sedn_weff_kernel(SednFuseArgs a)
         gate[t] = 1.f / (1.f + __expf(-u));
         __syncthreads();
     }
-    float acc[4][4] = {};
-    for (int m0 = 0; m0 < 256; m0 += MC) {
-        for (int i = threadIdx.x; i < MC * 64; i += 256) {
-            const int m = i % MC, co = i / MC;
-            As[m][co] = a.wt[co * 256 + m0 + m] * gate[m0 + m];
-        }
-        for (int i = threadIdx.x; i < MC * 16; i += 256) {      // 16-byte loads: 16 per row of 64 k
-            const int kq = i & 15, m = i >> 4;
-            *(float4*)&Bs[m][kq * 4] = *(const float4*)(a.w256 + (long long)(m0 + m) * 576 + tap * 64 + kq * 4);
-        }
-        __syncthreads();
+    // round 6: the 64 x 64 x 256 product of a block on fp32 MFMAs (v_mfma_f32_32x32x2_f32: wave (cob, cib) owns a 32 x 32 quadrant, 128 MFMAs), operands straight from
+    // global memory -- no staging, no barrier in the loop.  The k order of an MFMA is free as long as A and B agree: lane (ln, lk) takes the 16 bytes W_t[co][8 q + 4 lk ..]
+    // and the four W_256 rows 8 q + 4 lk + e; MFMA (q, e) multiplies the k pair (8 q + e, 8 q + 4 + e).  (The VALU form -- 4 x 4 outputs per thread, 16 FMAs per two 16-byte
+    // LDS reads, a barrier pair per 64 m -- ran 27 us a launch: profiles/r06/zf_pmc_tail3_sedn.txt.)
+    typedef float f16v __attribute__((ext_vector_type(16)));
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int cob = wave >> 1, cib = wave & 1, lk = lane >> 5, ln = lane & 31;
+    f16v acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float* wrow = a.wt + (cob * 32 + ln) * 256 + 4 * lk;
+    const float* brow = a.w256 + (long long)(4 * lk) * 576 + tap * 64 + cib * 32 + ln;
 #pragma unroll 8
-        for (int m = 0; m < MC; ++m) {      // (m ascending, one accumulator per output: the summation order of round 4's kernel -- the same bits)
-            const float4 bv = *(const float4*)&Bs[m][tx * 4];
-            const float4 av = *(const float4*)&As[m][ty * 4];
-            const float aa[4] = {av.x, av.y, av.z, av.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { acc[i][0] += aa[i] * bv.x; acc[i][1] += aa[i] * bv.y; acc[i][2] += aa[i] * bv.z; acc[i][3] += aa[i] * bv.w; }
-        }
-        __syncthreads();
+    for (int q = 0; q < 32; ++q) {
+        const float4 av = *(const float4*)(wrow + 8 * q);
+        const float4 gv = *(const float4*)&gate[8 * q + 4 * lk];
+        const float b0 = brow[(8 * q + 0) * 576], b1 = brow[(8 * q + 1) * 576], b2 = brow[(8 * q + 2) * 576], b3 = brow[(8 * q + 3) * 576];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x * gv.x, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y * gv.y, b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z * gv.z, b2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w * gv.w, b3, acc, 0, 0, 0);
     }
-    // fragment f = (tap*4 + ks)*2 + nblk, lane l = 32*(ci%16/8) + co%32, element e = ci%8   (pack_conv's order)
+    // through LDS as fp16 [co][ci], then 16-byte stores: the tap's eight fragments are 8 KB in a row.  fragment f = (tap*4 + ks)*2 + nblk, lane l = 32*(ci%16/8) + co%32,
+    // element e = ci%8 (pack_conv's order)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 16; ++r) Cs[cob * 32 + (r >> 2) * 8 + lk * 4 + (r & 3)][cib * 32 + ln] = (half_t)acc[r];      // (D: register r of lane -> row 8 (r / 4) + 4 lk + r % 4, column ln)
+    __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int co = ty * 4 + i, ci = tx * 4 + j;
-            const int f = (tap * 4 + (ci >> 4)) * 2 + (co >> 5), l = (((ci >> 3) & 1) << 5) + (co & 31), e = ci & 7;
-            a.weff[(((long long)b * 72 + f) * 64 + l) * 8 + e] = (half_t)acc[i][j];
-        }
+    for (int q = threadIdx.x; q < 512; q += 256) {
+        const int fl = q >> 6, l = q & 63;
+        const int ci8 = (fl >> 1) * 2 + (l >> 5), co = (fl & 1) * 32 + (l & 31);
+        *(half8_t*)(a.weff + ((long long)b * 72 + tap * 8) * 512 + q * 8) = *(const half8_t*)&Cs[co][ci8 * 8];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1198,7 +1234,7 @@ void launch_sedn_se(const SednSeArgs& a, hipStream_t s)
 
 void launch_sedn_fuse(const SednFuseArgs& a, hipStream_t s)
 {
-    hipLaunchKernelGGL(sedn_xsum_kernel, dim3(a.nslab, a.B), dim3(256), 0, s, a);
+    if (!a.pooled) hipLaunchKernelGGL(sedn_xsum_kernel, dim3(a.nslab, a.B), dim3(256), 0, s, a);      // (with the producing conv's totals sedn_fmean visits the border itself)
     hipLaunchKernelGGL(sedn_fmean_kernel, dim3(a.B, kMeanSplit), dim3(256), 0, s, a);
     hipLaunchKernelGGL(sedn_weff_kernel, dim3(9, a.B), dim3(256), 0, s, a);
 }

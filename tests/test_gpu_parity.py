@@ -161,6 +161,17 @@ def test_sedn_fused_block_tail_shapes(dev):
         want = onets.forward('sedn', sd, x).numpy()
         got = mf(torch.from_numpy(x).to(dev))[-1].cpu().numpy()
         assert np.abs(got - want).max() <= TOL, (bn, h, w, float(np.abs(got - want).max()))
+    # the gate's sums two ways: totals from rblock.2's epilogue + the border visited by sedn_fmean (default), and the full pass of sedn_xsum (pool_fuse = 0) -- the same
+    # fp32 sums in another order: the outputs agree far inside the tolerance, and both with the oracle
+    x = gd.natural_image(17, (3, 88, 72))[:, None]
+    xd = torch.from_numpy(x).to(dev)
+    want = onets.forward('sedn', sd, x).numpy()
+    try:
+        y0 = mf.set_option('pool_fuse', 0)(xd)[-1].cpu().numpy()
+    finally:
+        mf.set_option('pool_fuse', 1)
+    y1 = mf(xd)[-1].cpu().numpy()
+    assert np.abs(y0 - want).max() <= TOL and np.abs(y1 - want).max() <= TOL and np.abs(y0 - y1).max() <= 1e-4, (float(np.abs(y0 - want).max()), float(np.abs(y0 - y1).max()))
     mx = module_for('l25', 'fp16x3')
     x = gd.natural_image(13, (3, 24, 56))[:, None]
     assert np.abs(mx(torch.from_numpy(x).to(dev))[-1].cpu().numpy() - onets.forward('sedn', sd, x).numpy()).max() <= 2e-5
