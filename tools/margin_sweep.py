@@ -40,7 +40,7 @@ def main():
     for key in keys:
         arch = gd.MODELS[key][0]
         sd0 = gd.state_dict_for(key, load_state_dict_file)
-        ctor = {'net2x': models.Net2x, 'net4x': models.Net4x}[arch]
+        ctor = {'net2x': models.Net2x, 'net3x': models.Net3x, 'net4x': models.Net4x, 'netdn': models.NetDN}[arch]
         for name, sd in variants(sd0):
             m = ctor()
             m.load_state_dict({n: torch.from_numpy(np.ascontiguousarray(v)) for n, v in sd.items()})

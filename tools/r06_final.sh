@@ -25,7 +25,7 @@ find $OUT/stats -name '*kernel_stats.csv' -exec cp {} $OUT/bench_kernel_stats.cs
 rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_grbm
 head -14 $OUT/bench_kernel_stats.csv
 TM_PREC=auto timeout 600 python tools/time_models.py > $OUT/time_models.txt 2>&1; grep -v "^$" $OUT/time_models.txt | grep -v amdgpu | tail -9
-timeout 600 python tools/margin_sweep.py a4 a2 > $OUT/margin_sweep.txt 2>&1; grep -v amdgpu $OUT/margin_sweep.txt | tail -30
+timeout 900 python tools/margin_sweep.py a4 a2 dn_lite5 > $OUT/margin_sweep.txt 2>&1; grep -v amdgpu $OUT/margin_sweep.txt | tail -30
 FUZZ_N=16 FUZZ_KEYS=a2,a4,a3,dn_lite5,lite2,lite8,l25 FUZZ_SEED=29 FUZZ_CROPS=8 timeout 900 python tools/fuzz_gpu.py > $OUT/fuzz.txt 2>&1; echo "fuzz rc=$?"; grep -v amdgpu $OUT/fuzz.txt | tail -14
 timeout 200 python tools/kernel_power.py 4 > $OUT/kernel_power.txt 2>&1; grep -v amdgpu $OUT/kernel_power.txt
 timeout 200 python tools/prof_dropin.py 8 > $OUT/prof_dropin.txt 2>&1; grep prof_dropin $OUT/prof_dropin.txt
