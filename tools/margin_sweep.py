@@ -50,7 +50,8 @@ def main():
             cal = '{} / {} blocks'.format(m.resolved_precision(), m.exact_blocks())
             r = m.calibrate()
             if r is not None:
-                cal += ', calibrate() = ({}, predicted {:.3e} = measured {:.3e} x 1.10)'.format(r[0], r[1], r[1] / 1.10)
+                infl = 1.30 if arch == 'netdn' else 1.10      # (kCalibInflateDN / kCalibInflate of csrc/engine.cpp)
+                cal += ', calibrate() = ({}, predicted {:.3e} = measured {:.3e} x {:.2f})'.format(r[0], r[1], r[1] / infl, infl)
             worst = {}
             for kind in ('noise_u8', 'natural'):
                 w = 0.0
