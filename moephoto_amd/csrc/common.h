@@ -219,6 +219,8 @@ struct ConvX3Args {
     // optional (plain epilogue only): per-plane channel sums of the output, the global average pool of lite's FRM / LB (MoeNet_lite2.py:16-20,
     // models.py:274) without a second pass over the tensor: pool[b][workgroup][64], zeroed by the caller, pool_slabs >= workgroups
     float* pool; int pool_slabs;
+    // optional (with a residual, conv64_x3 only): out = gate[b][c] * conv + residual; gate = [2][B][64] fp32: g, then 1 / g (frm_pre_kernel)
+    const float* gate;
     // conv64_q8.hip only: w_hi as A fragments of v_mfma_f32_32x32x16_f16 (ConvLayer::w_hi, pack_conv order), w_hi 2^8 and w_lo 2^8 as fp8 e4m3
     // A fragments of v_mfma_scale_f32_32x32x64_f8f6f4: [tap 9][channel half 2][lane 64][32 bytes]
     const half_t* wq_hi16; const unsigned char* wq_hi8; const unsigned char* wq_lo8;
@@ -367,6 +369,20 @@ struct FrmArgs {     // FRM gate (models.py:270-287) then out = t*gate + x   (Mo
     int B;
 };
 void launch_frm(const FrmArgs& a, hipStream_t s);
+// The FRM gate of an LB BEFORE its conv_2 runs (round 6).  conv_2 has no bias and no activation, so the pooled mean the gate needs is linear in conv_2's INPUT m:
+//   mean_t[co] = 1/HW  sum_tap sum_ci W2[co][ci][tap] S_tap[ci],   S_tap = the sum of m over the plane shifted by the tap (total minus border rows / columns, zero padding)
+// (what sedn_fmean does for SEDN).  conv_1's epilogue forms the totals of m (conv64_x3 EPI 4), this kernel visits the border, applies W2 and the gate's two 1x1 layers
+// (models.py:270-287) and writes g and 1 / g; conv_2's epilogue then stores g * conv + x (conv64_x3 EPI 5) -- frm_apply's pass over six tensors is gone.
+struct FrmPreArgs {
+    const half_t* m; const half_t* m_lo;         // [B][H][W][64] conv_2's input (low part or nullptr)
+    const float* partial; int nslab;             // the totals of m: [B][nslab][64]
+    const float* c2t;                            // conv_2's weights, fp32, [tap*64 + ci][co 64]
+    const float* w0; const float* b0;            // [3][64], [3]
+    const float* w2; const float* b2;            // [64][3], [64]
+    float* gate;                                 // out: [2][B][64]: g, then 1 / g
+    int B, H, W;
+};
+void launch_frm_pre(const FrmPreArgs& a, hipStream_t s);
 
 struct StitchArgs {
     const float* tiles; const long long* tile_off;   // device

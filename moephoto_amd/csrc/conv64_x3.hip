@@ -12,7 +12,8 @@
 //   pass 1  streams the ten rows of the a_hi patch:  acc_hi += w_hi a_hi,  acc_lo += w_lo a_hi      (72 MFMAs per row)
 //   pass 2  streams the ten rows of the a_lo patch:  acc_lo += w_hi a_lo                             (36 MFMAs per row)
 //           and finishes each output row as soon as its third a_lo row is in: v = acc_hi + acc_lo 2^-11 in fp32, then
-//           EPI 0 plain | 1 PReLU (fp32, slope <= 1) | 2 + residual (hi + lo 2^-11); hi and lo parts stored, 16 bytes per lane.
+//           EPI 0 plain | 1 PReLU (fp32, slope <= 1) | 2 + residual (hi + lo 2^-11) | 3 plain + pooled channel sums | 4 PReLU + pooled | 5 gate[plane][channel] * conv +
+//           residual (lite's LB with the FRM gate known BEFORE conv_2 runs: engine.cpp, frm_pre_kernel); hi and lo parts stored, 16 bytes per lane.
 //
 // LDS: a_hi double buffered (its DMA for patch p+1 rides in pass 2 of patch p), a_lo single buffered: it is only live during pass 2,
 // so its DMA for patch p is issued behind the barrier that opens patch p and lands while pass 1 runs.  2 x 45,056 + 45,056 B.
@@ -122,7 +123,9 @@ __global__ __launch_bounds__(256) void conv64_x3_kernel(ConvX3Args a)
 
     // EPI 3 = plain + pooled: this lane's partial channel sums of the plane being processed; when the workgroup moves on to another
     // plane (and at the end) the 16 pixel lanes of a channel group are added up and lane n = 0 stores the workgroup's slab
-    constexpr bool POOL = EPI == 3;
+    constexpr bool POOL = EPI == 3 || EPI == 4, PRELU = EPI == 1 || EPI == 4, RES = EPI == 2 || EPI == 5, GATE = EPI == 5;
+    // GATE: out = g (conv) + x = g (conv + x / g): the residual words are added into the accumulators scaled by 1 / g (gate[B*64 + ..]), the finished row is multiplied by g
+    float4_t g4 = {1.f, 1.f, 1.f, 1.f}, rg4 = {1.f, 1.f, 1.f, 1.f}, rgl4 = {0.00048828125f, 0.00048828125f, 0.00048828125f, 0.00048828125f};
     float psum[4] = {0.f, 0.f, 0.f, 0.f};
     int pool_b = it_cur.b;
     auto pool_flush = [&](int b) {
@@ -153,6 +156,10 @@ __global__ __launch_bounds__(256) void conv64_x3_kernel(ConvX3Args a)
         else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         __builtin_amdgcn_s_barrier();                     // every wave is done with a_lo[p-1]
         asm volatile("" ::: "memory");
+        if (GATE) {      // this plane's gate, channels 16 w4 + 4 q ..: requested here, OLDER than every load of pass 1 -- the counted waits there cover it
+            g4 = *(const float4_t*)(a.gate + (long long)it.b * 64 + 16 * w4 + 4 * q);
+            rg4 = *(const float4_t*)(a.gate + ((long long)a.B + it.b) * 64 + 16 * w4 + 4 * q);
+        }
 
         half8_t fr[2][12];
         const char* pb[12];
@@ -179,8 +186,13 @@ __global__ __launch_bounds__(256) void conv64_x3_kernel(ConvX3Args a)
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
                 float t0 = h4[cb][0], t1 = h4[cb][1], t2 = h4[cb][2], t3 = h4[cb][3];
-                t0 = mix_lo(l0[cb], kc.lowscale, t0); t1 = mix_hi(l0[cb], kc.lowscale, t1); t2 = mix_lo(l1[cb], kc.lowscale, t2); t3 = mix_hi(l1[cb], kc.lowscale, t3);
-                t0 = mix_lo(r0[cb], kc.one, t0); t1 = mix_hi(r0[cb], kc.one, t1); t2 = mix_lo(r1[cb], kc.one, t2); t3 = mix_hi(r1[cb], kc.one, t3);
+                if (GATE) {
+                    t0 = mix_lo(l0[cb], rgl4[0], t0); t1 = mix_hi(l0[cb], rgl4[1], t1); t2 = mix_lo(l1[cb], rgl4[2], t2); t3 = mix_hi(l1[cb], rgl4[3], t3);
+                    t0 = mix_lo(r0[cb], rg4[0], t0); t1 = mix_hi(r0[cb], rg4[1], t1); t2 = mix_lo(r1[cb], rg4[2], t2); t3 = mix_hi(r1[cb], rg4[3], t3);
+                } else {
+                    t0 = mix_lo(l0[cb], kc.lowscale, t0); t1 = mix_hi(l0[cb], kc.lowscale, t1); t2 = mix_lo(l1[cb], kc.lowscale, t2); t3 = mix_hi(l1[cb], kc.lowscale, t3);
+                    t0 = mix_lo(r0[cb], kc.one, t0); t1 = mix_hi(r0[cb], kc.one, t1); t2 = mix_lo(r1[cb], kc.one, t2); t3 = mix_hi(r1[cb], kc.one, t3);
+                }
                 h4[cb] = float4_t{t0, t1, t2, t3};
             }
         };
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(256) void conv64_x3_kernel(ConvX3Args a)
             // words of output row xr-3, requested three row steps ago -- a COUNTED wait (younger: the DMA pieces and words of the two rows between),
             // placed here behind the previous row's sched_barrier: a wait in mid-row does not keep the scheduler from hoisting the words' first use
             // above it, and for a use it finds unprotected the compiler inserts vmcnt(0) while LDS-DMA pieces are in flight
-            if (EPI != 2 || xr < 3) __builtin_amdgcn_s_waitcnt(0xC07F);
+            if (!RES || xr < 3) __builtin_amdgcn_s_waitcnt(0xC07F);
             else if (xr <= 5) __builtin_amdgcn_s_waitcnt(0x0078);     // vmcnt(8) lgkmcnt(0)
             else if (xr == 6) __builtin_amdgcn_s_waitcnt(0x0077);     // 7
             else if (xr == 7) __builtin_amdgcn_s_waitcnt(0x0075);     // 5
@@ -228,13 +240,14 @@ __global__ __launch_bounds__(256) void conv64_x3_kernel(ConvX3Args a)
                             }
                         }
                     }
-            if (EPI == 2 && xr >= 3) {        // rows 0..6 (ah[o] is complete since row step o + 2)
+            if (RES && xr >= 3) {        // rows 0..6 (ah[o] is complete since row step o + 2)
+                if (GATE && xr == 3) rgl4 = rg4 * 0.00048828125f;
                 add_res(ah[xr - 3], sidew[(xr - 3) & 3], resw[(xr - 3) & 3]);
             }
             // a_lo of THIS patch (its buffer was freed by the barrier above): 11 pieces over the first six rows
             if (xr < 5) { issue_piece(a.in_lo, it, 2 * xr, lbuf, true); issue_piece(a.in_lo, it, 2 * xr + 1, lbuf, true); }
             if (xr == 5) issue_piece(a.in_lo, it, 10, lbuf, true);
-            if (EPI == 2 && xr < 8) {         // words of output row xr: their ring slot was released by the add above
+            if (RES && xr < 8) {         // words of output row xr: their ring slot was released by the add above
                 const unsigned off = row_off(xr);
                 resw[xr & 3] = *(const u4v_t*)((const char*)a.res_hi + off);
                 sidew[xr & 3] = *(const u4v_t*)((const char*)a.res_lo + off);
@@ -254,7 +267,13 @@ __global__ __launch_bounds__(256) void conv64_x3_kernel(ConvX3Args a)
                 for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[cb][e] = __builtin_fmaf(l4[cb][e], 0.00048828125f, h4[cb][e]);
-                if (EPI == 1) {
+                if (GATE) {
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[cb][e] *= g4[e];
+                }
+                if (PRELU) {
 #pragma unroll
                     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -276,7 +295,7 @@ __global__ __launch_bounds__(256) void conv64_x3_kernel(ConvX3Args a)
             };
             MOE_SET_BASE(lbuf)
             MOE_READ_ROW(0, 0)
-            if (EPI == 2) add_res(ah[7], sidew[3], resw[3]);
+            if (RES) add_res(ah[7], sidew[3], resw[3]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int xr = 0; xr < 10; ++xr) {
@@ -326,6 +345,8 @@ hipError_t conv64_x3_init()
     if ((e = set_limit<0>()) != hipSuccess) return e;
     if ((e = set_limit<1>()) != hipSuccess) return e;
     if ((e = set_limit<3>()) != hipSuccess) return e;
+    if ((e = set_limit<4>()) != hipSuccess) return e;
+    if ((e = set_limit<5>()) != hipSuccess) return e;
     return set_limit<2>();
 }
 
@@ -342,8 +363,11 @@ bool launch_conv64_x3(ConvX3Args a, int max_groups, hipStream_t s)
     const long long items = (long long)a.B * a.px * a.py;
     const int G = a.pool ? pooled_groups((long long)a.px * a.py, items, max_groups) : (int)std::min<long long>(items, max_groups);
     const dim3 grid(G), blk(256);
-    if (a.pool && (a.res_hi || a.slope != 1.f || a.pool_slabs < G)) return false;
-    if (a.pool) conv64_x3_kernel<3><<<grid, blk, LDS_BYTES, s>>>(a);
+    if (a.pool && (a.res_hi || a.pool_slabs < G)) return false;
+    if (a.gate && !a.res_hi) return false;
+    if (a.pool && a.slope != 1.f) conv64_x3_kernel<4><<<grid, blk, LDS_BYTES, s>>>(a);
+    else if (a.pool) conv64_x3_kernel<3><<<grid, blk, LDS_BYTES, s>>>(a);
+    else if (a.gate) conv64_x3_kernel<5><<<grid, blk, LDS_BYTES, s>>>(a);
     else if (a.res_hi) conv64_x3_kernel<2><<<grid, blk, LDS_BYTES, s>>>(a);
     else if (a.slope != 1.f) conv64_x3_kernel<1><<<grid, blk, LDS_BYTES, s>>>(a);
     else conv64_x3_kernel<0><<<grid, blk, LDS_BYTES, s>>>(a);

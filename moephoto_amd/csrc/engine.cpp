@@ -115,6 +115,7 @@ struct NetOptions {
     bool fuse_tail = true;    // fuse_tail   last upsampler conv + 64->1 / 48->1 tail conv in one kernel
     bool sedn_fuse = true;    // sedn_fuse   SEDN's fused block tail
     bool pool_fuse = true;    // pool_fuse   SE / FRM channel sums out of the producing conv's epilogue
+    bool frm_pre = true;      // frm_pre     lite (fp16x3): the FRM gate of an LB from conv_2's INPUT (frm_pre_kernel), conv_2 stores gate * conv + x -- no frm_apply pass | 0: gate from conv_2's output, frm_apply
     int overlap_calls = 1;    // overlap_calls  1 (default): consecutive small forwards that the CALLER marks as independent of each other (moe_net_forward_ex with MOE_FWD_INPUT_SINCE_PREV:
                               //             "my input was complete when the previous forward of this net was enqueued" -- true of the reference's tile loop, whose inputs are slices of
                               //             ONE padded image, python/imageProcess.py:164-170) alternate between two internal (stream, workspace) sets: forward k+1 starts beside forward k
@@ -177,6 +178,7 @@ struct NetOptions {
         if (key == "fuse_tail") return flag(fuse_tail);
         if (key == "sedn_fuse") return flag(sedn_fuse);
         if (key == "pool_fuse") return flag(pool_fuse);
+        if (key == "frm_pre") return flag(frm_pre);
         if (key == "dbg") { dbg = atoi(v); return true; }
         if (key == "tiles_per_batch") { tiles_per_batch = atoi(v); return tiles_per_batch >= 0; }
         if (key == "max_groups") { max_groups = atoi(v); return max_groups >= 0; }
@@ -201,7 +203,7 @@ struct NetOptions {
     {
         static const char* const names[][2] = {{"MOE_CONV_IMPL", "conv_impl"}, {"MOE_SP_IMPL", "sp_impl"}, {"MOE_TAIL_SPLIT", "tail_split"}, {"MOE_TAIL_FORM", "tail_form"}, {"MOE_UP_IMPL", "up_impl"}, {"MOE_UP_FUSE2", "up_fuse2"},
                                                {"MOE_CONV1X1", "conv1x1"}, {"MOE_Q8_IMPL", "q8_impl"}, {"MOE_EXACT_FUSE", "exact_fuse"}, {"MOE_BRANCH_STREAMS", "branch_streams"}, {"MOE_BRANCH_GROUPS", "branch_groups"}, {"MOE_AUTO_CALIBRATE", "auto_calibrate"}, {"MOE_OVERLAP_CALLS", "overlap_calls"}, {"MOE_OVERLAP_GROUPS", "overlap_groups"}, {"MOE_OVERLAP_FORK", "overlap_fork"}, {"MOE_S64", "s64"}, {"MOE_K48", "k48"}, {"MOE_X3_IMPL", "x3_impl"}, {"MOE_LO8", "lo8"}, {"MOE_X3_FUSE", "x3_fuse"}, {"MOE_ARSB_FUSE", "arsb_fuse"}, {"MOE_FUSE_TAIL", "fuse_tail"},
-                                               {"MOE_SEDN_FUSE", "sedn_fuse"}, {"MOE_POOL_FUSE", "pool_fuse"}, {"MOE_DBG", "dbg"}, {"MOE_TRACE_KEY", "trace_key"},
+                                               {"MOE_SEDN_FUSE", "sedn_fuse"}, {"MOE_POOL_FUSE", "pool_fuse"}, {"MOE_FRM_PRE", "frm_pre"}, {"MOE_DBG", "dbg"}, {"MOE_TRACE_KEY", "trace_key"},
                                                {"MOE_TILES_PER_BATCH", "tiles_per_batch"}, {"MOE_MAX_GROUPS", "max_groups"}};
         for (const auto& nv : names)
             if (const char* e = getenv(nv[0]))
@@ -659,6 +661,13 @@ static int build_device_weights(moe_net& n, int precision)
             f32table(key + ".b0", n.get(p + "se.conv_du.0.bias")->data);
             f32table(key + ".w2", w2);
             f32table(key + ".b2", b2);
+            // conv_2's weights once more, fp32 and transposed: [tap*64 + ci][co 64] -- the gate's pooled mean is this matrix applied to the window sums of conv_2's input (frm_pre)
+            std::vector<float> c2t((size_t)576 * 64, 0.f);
+            const Param& C2 = *n.get(p + "conv_2.weight");
+            for (int co = 0; co < 48; ++co)
+                for (int ci = 0; ci < 48; ++ci)
+                    for (int tap = 0; tap < 9; ++tap) c2t[(size_t)(tap * 64 + ci) * 64 + co] = C2.data[((size_t)co * 48 + ci) * 9 + tap];
+            f32table(key + ".c2t", c2t);
         }
         for (const char* br : {"ures", "uim"})
             for (int s = 0; s < n.stages; ++s) {
@@ -704,6 +713,9 @@ struct Fwd {
     float* pool_out = nullptr;   // set around a conv() call: let the conv pool its output per plane (conv64_x3's pooled epilogue), [B][pool_slabs][64]
     int pool_slabs = 0;
     bool pool_done = false;      // the conv did
+    bool pool_act = false;       // ... with pool_out: the conv may pool BEHIND its PReLU (conv64_x3 EPI 4: lite's conv_1, whose output's sums make the FRM gate -- frm_pre)
+    const float* gate_in = nullptr;   // set around a conv() call with a residual: out = gate[plane][channel] * conv + residual (conv64_x3 EPI 5), [2][B][64]
+    bool gate_done = false;      // the conv did
 
     Act act(long long pixels, int ch = 64, bool want_lo = false)
     {
@@ -910,10 +922,11 @@ struct Fwd {
                 q.res_hi = res ? res->hi : nullptr; q.res_lo = res ? res->lo : nullptr;
                 q.w_hi = blob<half_t>(L.w_arsb); q.w_lo = blob<half_t>(L.w_arsb_lo); q.zero = small<half_t>("zero");
                 q.slope = L.slope; q.B = B; q.H = H; q.W = W;
-                if (pool_out && !res && L.slope == 1.f && pooled_groups_ok((long long)((W + kTileW - 1) / kTileW) * ((H + kTileH - 1) / kTileH),
+                if (pool_out && !res && (L.slope == 1.f || pool_act) && pooled_groups_ok((long long)((W + kTileW - 1) / kTileW) * ((H + kTileH - 1) / kTileH),
                                                                             (long long)B * ((W + kTileW - 1) / kTileW) * ((H + kTileH - 1) / kTileH), n.max_groups)) {
                     q.pool = pool_out; q.pool_slabs = pool_slabs;      // (conv64_x3's patches are 8 x 32 outputs, as the launcher counts them)
                 }
+                if (gate_in && res && !use_q8()) q.gate = gate_in;
                 const int rec = prof_begin(key, 3 * 2.0 * (double)B * H * W * L.cout * L.cin * L.taps);
                 bool ok = false;
                 // The two correction products on fp8 operands (conv64_q8.hip): 'mixed' only -- 'fp16x3' promises 2e-5, fp8 corrections deliver ~15 bits.
@@ -929,7 +942,7 @@ struct Fwd {
                 if (!ok && any8) { prof_end(rec); return false; }
                 if (!ok) ok = launch_conv64_x3(q, n.max_groups, s);
                 prof_end(rec);
-                if (ok) { pool_done = q.pool != nullptr; return true; }
+                if (ok) { pool_done = q.pool != nullptr; gate_done = q.gate != nullptr; return true; }
             }
         }
         if (fast && L.nchunks <= 16) {
@@ -1474,9 +1487,38 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         f.tap("stem", A, h, w, 64, 48);
         f.conv("input2", A, Bb, nullptr, h, w);
         f.tap("input2", Bb, h, w, 64, 48);
+        float* gate2 = (float*)f.ar.take((size_t)2 * B * 64 * 4);
         for (int k = 1; k <= 3; ++k) {
             const std::string key = "lb" + std::to_string(k);
-            f.conv(key + ".c1", Bb, Cc, nullptr, h, w);
+            // round 6: conv_2 has no bias and no activation, so the mean the gate pools is linear in conv_2's INPUT: conv_1's epilogue forms the totals of its own output m,
+            // frm_pre visits m's border, applies conv_2's weights to the nine shifted-window sums and the gate's two layers; conv_2 then stores gate * conv + x itself
+            // (FrmPreArgs in common.h).  frm_apply's pass over six tensors (2.7 ms of a 1080p frame, at 6 TB/s) is gone.
+            if (n.opt.frm_pre && poolfuse && f.x3 && !f.use_q8() && !n.debug && !f.direct && Bb.lo && Cc.lo && Dd.lo) {
+                f.pool_done = false;
+                if (!f.dry()) {
+                    (void)hipMemsetAsync(partial, 0, (size_t)B * pslabs * 64 * 4, s);      // (workgroups without a patch in a plane leave their slab untouched)
+                    f.pool_out = partial; f.pool_slabs = pslabs; f.pool_act = true;
+                }
+                f.conv(key + ".c1", Bb, Cc, nullptr, h, w);
+                f.pool_out = nullptr; f.pool_act = false;
+                if (f.dry()) { f.conv(key + ".c2", Cc, Dd, &Bb, h, w); continue; }
+                if (f.pool_done) {
+                    FrmPreArgs a{};
+                    a.m = Cc.hi; a.m_lo = Cc.lo; a.partial = partial; a.nslab = pslabs; a.c2t = f.small<float>(key + ".c2t");
+                    a.w0 = f.small<float>(key + ".w0"); a.b0 = f.small<float>(key + ".b0"); a.w2 = f.small<float>(key + ".w2"); a.b2 = f.small<float>(key + ".b2");
+                    a.gate = gate2; a.B = B; a.H = h; a.W = w;
+                    launch_frm_pre(a, s);
+                    f.gate_in = gate2; f.gate_done = false;
+                    f.conv(key + ".c2", Cc, Dd, &Bb, h, w);
+                    f.gate_in = nullptr;
+                    if (!f.gate_done) return fail(MOE_EINVAL, "layer %s: the gated form of conv64_x3 refused a shape its pooled form took", key.c_str());
+                    std::swap(Bb, Dd);
+                    f.tap(key, Bb, h, w, 64, 48);
+                    continue;
+                }
+                // (conv_1 ran without the pooled epilogue: the shape is outside pooled_groups_ok -- the form below, from conv_2 on)
+            } else
+                f.conv(key + ".c1", Bb, Cc, nullptr, h, w);
             f.pool_done = false;
             if (!f.dry() && poolfuse && f.x3) {
                 (void)hipMemsetAsync(partial, 0, (size_t)B * pslabs * 64 * 4, s);      // (workgroups without a patch in a plane leave their slab untouched)

@@ -879,6 +879,111 @@ __global__ __launch_bounds__(256) void frm_gate_kernel(FrmArgs a)
     }
 }
 
+// the gate from conv_2's INPUT (FrmPreArgs in common.h): one block per plane
+__global__ __launch_bounds__(256) void frm_pre_kernel(FrmPreArgs a)
+{
+    __shared__ float sums[5][64];        // total, first row, last row, first column, last column
+    __shared__ float corner[4][64];      // m[0][0], m[0][W-1], m[H-1][0], m[H-1][W-1]
+    __shared__ float sh[576];            // shifted-window sums, k = tap*64 + ci
+    __shared__ float red[4][64];
+    __shared__ float bred[4][32][64];
+    __shared__ float mean[64];
+    __shared__ float hid[3];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const long long HW = (long long)a.H * a.W;
+    {   // totals: the slabs of conv_1's epilogue, four parts in a fixed order
+        const int ch = t & 63, part = t >> 6;
+        float s = 0.f;
+        for (int k = part; k < a.nslab; k += 4) s += a.partial[((long long)b * a.nslab + k) * 64 + ch];
+        red[part][ch] = s;
+    }
+    {   // border: index i in [0, 2W + 2H) = first row, last row, first column, last column; thread = (pixel lane t / 8 of 32, channel group t % 8)
+        const int cg = t & 7, pl = t >> 3;
+        float acc[4][8];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[c][e] = 0.f;
+        const int nb = 2 * a.W + 2 * a.H;
+#pragma unroll 2
+        for (int i = pl; i < nb; i += 32) {
+            int y, x, c;
+            if (i < 2 * a.W) { c = i < a.W ? 0 : 1; y = c ? a.H - 1 : 0; x = c ? i - a.W : i; }
+            else { const int k = i - 2 * a.W; c = k < a.H ? 2 : 3; x = c == 3 ? a.W - 1 : 0; y = c == 3 ? k - a.H : k; }
+            const long long off = ((long long)b * HW + (long long)y * a.W + x) * 64 + cg * 8;
+            const half8_t v = *(const half8_t*)(a.m + off);
+            half8_t vl = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (a.m_lo) vl = *(const half8_t*)(a.m_lo + off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float u = (float)v[e] + (float)vl[e] * 0.00048828125f;
+                acc[0][e] += c == 0 ? u : 0.f; acc[1][e] += c == 1 ? u : 0.f; acc[2][e] += c == 2 ? u : 0.f; acc[3][e] += c == 3 ? u : 0.f;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bred[c][pl][cg * 8 + e] = acc[c][e];
+    }
+    {
+        const int q = t >> 6, ch = t & 63;
+        const long long p = (q & 2 ? (long long)(a.H - 1) * a.W : 0) + (q & 1 ? a.W - 1 : 0);
+        const long long off = ((long long)b * HW + p) * 64 + ch;
+        corner[q][ch] = (float)a.m[off] + (a.m_lo ? (float)a.m_lo[off] * 0.00048828125f : 0.f);
+    }
+    __syncthreads();
+    {
+        const int c = t >> 6, ch = t & 63;
+        float v = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) v += bred[c][k][ch];
+        sums[1 + c][ch] = v;
+        if (c == 0) sums[0][ch] = (red[0][ch] + red[1][ch]) + (red[2][ch] + red[3][ch]);
+    }
+    __syncthreads();
+    for (int k = t; k < 576; k += 256) {
+        const int tap = k >> 6, ci = k & 63, dy = tap / 3, dx = tap % 3;
+        float v = sums[0][ci];
+        if (dy == 0) v -= sums[2][ci];           // rows y-1: the last row never contributes
+        if (dy == 2) v -= sums[1][ci];           // rows y+1: the first row never contributes
+        if (dx == 0) v -= sums[4][ci];
+        if (dx == 2) v -= sums[3][ci];
+        if (dy == 0 && dx == 0) v += corner[3][ci];
+        if (dy == 0 && dx == 2) v += corner[2][ci];
+        if (dy == 2 && dx == 0) v += corner[1][ci];
+        if (dy == 2 && dx == 2) v += corner[0][ci];
+        sh[k] = v;
+    }
+    __syncthreads();
+    {   // thread (part q of 4, channel co): 144 of the 576 terms, then a fixed-order sum of the four parts
+        const int q = t >> 6, co = t & 63;
+        float m0 = 0.f, m1 = 0.f;
+#pragma unroll 8
+        for (int k = q * 144; k < q * 144 + 144; k += 2) {
+            m0 += a.c2t[(k + 0) * 64 + co] * sh[k + 0];
+            m1 += a.c2t[(k + 1) * 64 + co] * sh[k + 1];
+        }
+        red[q][co] = m0 + m1;
+    }
+    __syncthreads();
+    if (t < 64) mean[t] = ((red[0][t] + red[1][t]) + (red[2][t] + red[3][t])) / (float)HW;
+    __syncthreads();
+    if (t < 3) {
+        float h = a.b0[t];
+        for (int c = 0; c < 64; ++c) h += a.w0[t * 64 + c] * mean[c];
+        hid[t] = h > 0.f ? h : 0.f;
+    }
+    __syncthreads();
+    if (t < 64) {
+        float u = a.b2[t];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) u += a.w2[t * 3 + k] * hid[k];
+        const float g = fmaxf(1.f / (1.f + __expf(-u)), 1e-12f);      // (a gate that small contributes nothing; its reciprocal must stay finite: the residual is added as x / g)
+        a.gate[b * 64 + t] = g;
+        a.gate[((long long)a.B + b) * 64 + t] = 1.f / g;
+    }
+}
+
 __global__ __launch_bounds__(256) void frm_apply_kernel(FrmArgs a)
 {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // one 16-B group each
@@ -1244,6 +1349,11 @@ void launch_frm(const FrmArgs& a, hipStream_t s)
     hipLaunchKernelGGL(frm_gate_kernel, dim3(a.B), dim3(256), 0, s, a);
     const long long total = (long long)a.B * a.HW * 8;
     hipLaunchKernelGGL(frm_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+}
+
+void launch_frm_pre(const FrmPreArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(frm_pre_kernel, dim3(a.B), dim3(256), 0, s, a);
 }
 
 void launch_stitch(const StitchArgs& a, hipStream_t s)

@@ -1163,6 +1163,32 @@ def test_lite_last_two_upsampler_stages_in_one_launch(key, dev):
         m.set_option('up_fuse2', 1)
 
 
+@pytest.mark.parametrize('key', ['lite2', 'lite4'])
+def test_lite_frm_gate_from_conv2_input(key, dev):
+    """Option frm_pre (default on; MoeNet_lite2.py:16-20, models.py:270-287): an LB's conv_2 has no bias and no activation, so the mean the FRM gate pools is linear in conv_2's
+    INPUT -- conv_1's epilogue forms its totals, frm_pre_kernel the border sums, the product with conv_2's weights and the gate; conv_2 stores gate * conv + x and frm_apply's
+    pass is gone.  Against the form that pools conv_2's output (frm_pre = 0): another summation order for the mean and g (conv + x / g) for g conv + x, i.e. fp32-rounding
+    apart; both within 2e-5 of the oracle; ragged, tiny (one patch, one row) and multi-plane shapes; a repeated launch gives the same bits."""
+    arch = gd.MODELS[key][0]
+    sd = gd.state_dict_for(key, load_state_dict_file)
+    m = module_for(key)
+    try:
+        for shape in ((3, 24, 40), (2, 16, 72), (1, 9, 35), (3, 8, 8), (5, 40, 33), (2, 64, 96), (1, 1, 7), (2, 3, 1)):
+            for kind in ('natural', 'noise'):
+                x = (gd.natural_image(71, shape) if kind == 'natural' else gd.noise_image(71, shape))[:, None]
+                xd = torch.from_numpy(x).to(dev)
+                y0 = m.set_option('frm_pre', 0)(xd)[-1].cpu().numpy()
+                y1 = m.set_option('frm_pre', 1)(xd)[-1].cpu().numpy()
+                y2 = m(xd)[-1].cpu().numpy()
+                assert np.isfinite(y1).all(), (key, shape, kind)
+                assert np.array_equal(y1, y2), (key, shape, kind)
+                want = onets.forward(arch, sd, x).numpy()
+                assert np.abs(y1 - want).max() <= 2e-5 and np.abs(y0 - want).max() <= 2e-5, (key, shape, kind, float(np.abs(y1 - want).max()), float(np.abs(y0 - want).max()))
+                assert np.abs(y1 - y0).max() <= 1e-5, (key, shape, kind, float(np.abs(y1 - y0).max()))
+    finally:
+        m.set_option('frm_pre', 1)
+
+
 def test_integration_md_stub_drives_every_family(dev):
     """INTEGRATION.md section 1 is the binding a MoePhoto maintainer would add (a ctypes stub over include/moephoto_amd.h).  This test EXECUTES that text --
     the first python block of the file, with the library path filled in -- and drives one SR key, one NetDN key, one SEDN key and one lite key through the

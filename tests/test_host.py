@@ -286,6 +286,8 @@ NOT_IN_THE_TABLE = {
     # reached by the defaults on other shapes than the table's small cases (profiles/r05/h_kernel_census_defaults.txt: the 1080p frame)
     'conv3x3_ps4_kernel<0, true>': 'store form of the x2 stages: launches with >= 32 four-row blocks per workgroup (a 1080p frame of a4)',
     # option forms the form-vs-form GPU tests compare, and fallbacks for shapes the fast kernels refuse (profiles/r05/h_kernel_census_gpu_test_suite.txt: all launched by the GPU suite)
+    'conv64_x3_kernel<3>': 'plain + pooled epilogue: lite with the gate pooled from conv_2\'s OUTPUT (option frm_pre = 0: test_lite_frm_gate_from_conv2_input compares the forms)',
+    'frm_gate_kernel': 'the FRM gate from pooled sums of conv_2\'s output: frm_pre = 0, and lite under fp16 / mixed',
     'sedn_xsum_kernel': 'the pass over x when the producing conv did not form the channel totals (option pool_fuse = 0: test_sedn_fused_block_tail_shapes compares the forms); since round 6 sedn_fmean visits the border itself when it did',
     'conv3x3_rw_kernel<3, false>': 'phase-class-sums fused tail on patch-aligned images: option up_impl = rw (A/B of conv3x3_ps4)',
     'conv3x3_rw_kernel<7, false>': 'the same with split tail activations',
