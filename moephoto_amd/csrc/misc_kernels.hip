@@ -717,7 +717,7 @@ __global__ __launch_bounds__(256) void sedn_fmean_kernel(SednFuseArgs a)
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[c][e] = 0.f;
         const int nb = 2 * a.W + 2 * a.H;
-#pragma unroll 4
+#pragma unroll 8
         for (int i = pl; i < nb; i += 32) {
             int y, x, c;
             if (i < 2 * a.W) { c = i < a.W ? 0 : 1; y = c ? a.H - 1 : 0; x = c ? i - a.W : i; }
@@ -894,7 +894,8 @@ __global__ __launch_bounds__(256) void frm_pre_kernel(FrmPreArgs a)
     {   // totals: the slabs of conv_1's epilogue, four parts in a fixed order
         const int ch = t & 63, part = t >> 6;
         float s = 0.f;
-        for (int k = part; k < a.nslab; k += 4) s += a.partial[((long long)b * a.nslab + k) * 64 + ch];
+#pragma unroll 16
+        for (int k = part; k < a.nslab; k += 4) s += a.partial[((long long)b * a.nslab + k) * 64 + ch];      // (unrolled: sixteen loads in flight -- one load per wait made this loop 2/3 of the kernel)
         red[part][ch] = s;
     }
     {   // border: index i in [0, 2W + 2H) = first row, last row, first column, last column; thread = (pixel lane t / 8 of 32, channel group t % 8)
@@ -905,7 +906,7 @@ __global__ __launch_bounds__(256) void frm_pre_kernel(FrmPreArgs a)
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[c][e] = 0.f;
         const int nb = 2 * a.W + 2 * a.H;
-#pragma unroll 2
+#pragma unroll 8
         for (int i = pl; i < nb; i += 32) {
             int y, x, c;
             if (i < 2 * a.W) { c = i < a.W ? 0 : 1; y = c ? a.H - 1 : 0; x = c ? i - a.W : i; }
