@@ -291,6 +291,9 @@ struct StemArgs {
     half_t* out_lo;                  // FP16X3 low part or nullptr
     int B, H, W, taps;
     int out_lo8;                     // the low part as fp8 e4m3 words of lo / 4, one byte a channel (what conv64_q8 with in8 reads: ConvX3Args)
+    // lite (taps == 1; MoeNet_lite2.py:40-41): conv_input2(PReLU(conv_input(x))) is x times a fixed vector -- P for x >= 0, Q for x < 0 (engine.cpp: "stem.p2") -- so the stem
+    // writes that tensor as well and the 48 -> 48 1x1 conv is never launched.  w2 = [2][64] fp32 (P, Q) or nullptr; out2 / out2_lo as out / out_lo (out2_lo may be nullptr)
+    const float* w2; half_t* out2; half_t* out2_lo;
 };
 void launch_stem(const StemArgs& a, hipStream_t s);
 

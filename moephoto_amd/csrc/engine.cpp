@@ -115,6 +115,7 @@ struct NetOptions {
     bool fuse_tail = true;    // fuse_tail   last upsampler conv + 64->1 / 48->1 tail conv in one kernel
     bool sedn_fuse = true;    // sedn_fuse   SEDN's fused block tail
     bool pool_fuse = true;    // pool_fuse   SE / FRM channel sums out of the producing conv's epilogue
+    bool stem2 = true;        // stem2       lite: conv_input2's output written by the stem in closed form (x times a fixed vector: StemArgs::w2), the 48 -> 48 1x1 conv not launched | 0: launched
     bool frm_pre = true;      // frm_pre     lite (fp16x3): the FRM gate of an LB from conv_2's INPUT (frm_pre_kernel), conv_2 stores gate * conv + x -- no frm_apply pass | 0: gate from conv_2's output, frm_apply
     int overlap_calls = 1;    // overlap_calls  1 (default): consecutive small forwards that the CALLER marks as independent of each other (moe_net_forward_ex with MOE_FWD_INPUT_SINCE_PREV:
                               //             "my input was complete when the previous forward of this net was enqueued" -- true of the reference's tile loop, whose inputs are slices of
@@ -179,6 +180,7 @@ struct NetOptions {
         if (key == "sedn_fuse") return flag(sedn_fuse);
         if (key == "pool_fuse") return flag(pool_fuse);
         if (key == "frm_pre") return flag(frm_pre);
+        if (key == "stem2") return flag(stem2);
         if (key == "dbg") { dbg = atoi(v); return true; }
         if (key == "tiles_per_batch") { tiles_per_batch = atoi(v); return tiles_per_batch >= 0; }
         if (key == "max_groups") { max_groups = atoi(v); return max_groups >= 0; }
@@ -203,7 +205,7 @@ struct NetOptions {
     {
         static const char* const names[][2] = {{"MOE_CONV_IMPL", "conv_impl"}, {"MOE_SP_IMPL", "sp_impl"}, {"MOE_TAIL_SPLIT", "tail_split"}, {"MOE_TAIL_FORM", "tail_form"}, {"MOE_UP_IMPL", "up_impl"}, {"MOE_UP_FUSE2", "up_fuse2"},
                                                {"MOE_CONV1X1", "conv1x1"}, {"MOE_Q8_IMPL", "q8_impl"}, {"MOE_EXACT_FUSE", "exact_fuse"}, {"MOE_BRANCH_STREAMS", "branch_streams"}, {"MOE_BRANCH_GROUPS", "branch_groups"}, {"MOE_AUTO_CALIBRATE", "auto_calibrate"}, {"MOE_OVERLAP_CALLS", "overlap_calls"}, {"MOE_OVERLAP_GROUPS", "overlap_groups"}, {"MOE_OVERLAP_FORK", "overlap_fork"}, {"MOE_S64", "s64"}, {"MOE_K48", "k48"}, {"MOE_X3_IMPL", "x3_impl"}, {"MOE_LO8", "lo8"}, {"MOE_X3_FUSE", "x3_fuse"}, {"MOE_ARSB_FUSE", "arsb_fuse"}, {"MOE_FUSE_TAIL", "fuse_tail"},
-                                               {"MOE_SEDN_FUSE", "sedn_fuse"}, {"MOE_POOL_FUSE", "pool_fuse"}, {"MOE_FRM_PRE", "frm_pre"}, {"MOE_DBG", "dbg"}, {"MOE_TRACE_KEY", "trace_key"},
+                                               {"MOE_SEDN_FUSE", "sedn_fuse"}, {"MOE_POOL_FUSE", "pool_fuse"}, {"MOE_FRM_PRE", "frm_pre"}, {"MOE_STEM2", "stem2"}, {"MOE_DBG", "dbg"}, {"MOE_TRACE_KEY", "trace_key"},
                                                {"MOE_TILES_PER_BATCH", "tiles_per_batch"}, {"MOE_MAX_GROUPS", "max_groups"}};
         for (const auto& nv : names)
             if (const char* e = getenv(nv[0]))
@@ -647,6 +649,23 @@ static int build_device_weights(moe_net& n, int precision)
         stem("conv_input.weight");
         n.scalars["stem_slope"] = scalar_of(n, "relu.weight");
         conv("input2", "conv_input2.weight", nullptr, 1, 1.f, 1.f);
+        {   // conv_input2(PReLU(conv_input(x))) in closed form (MoeNet_lite2.py:40-41: one input channel, 1x1 kernels, no bias): PReLU(w_s[c] x) = x p[c] for x >= 0 and
+            // x q[c] for x < 0 (p, q = w_s[c] or slope w_s[c] by the sign of w_s[c]), so conv_input2's output is x P / x Q with P = W2 p, Q = W2 q, summed in double here
+            const Param& Ws = *n.get("conv_input.weight");
+            const Param& W2 = *n.get("conv_input2.weight");
+            const double sl = (double)scalar_of(n, "relu.weight");
+            std::vector<float> pq(2 * 64, 0.f);
+            for (int co = 0; co < 48; ++co) {
+                double P = 0.0, Q = 0.0;
+                for (int c = 0; c < 48; ++c) {
+                    const double w = (double)Ws.data[c], w2 = (double)W2.data[(size_t)co * 48 + c];
+                    P += w2 * (w >= 0.0 ? w : sl * w);
+                    Q += w2 * (w <= 0.0 ? w : sl * w);
+                }
+                pq[co] = (float)P; pq[64 + co] = (float)Q;
+            }
+            f32table("stem.p2", pq);
+        }
         for (int k = 1; k <= 3; ++k) {
             const std::string p = "convt_F1" + std::to_string(k) + ".", key = "lb" + std::to_string(k);
             conv(key + ".c1", p + "conv_1.weight", nullptr, 1, scalar_of(n, p + "relu.weight"), 1.f);
@@ -1073,9 +1092,10 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         if (steep) { f.acc32_elems = (size_t)P * 64; f.acc32 = (float*)f.ar.take(f.acc32_elems * 4); }
     }
 
-    auto stem = [&](const Act& out) {
+    auto stem = [&](const Act& out, const Act* out2 = nullptr) {
         if (f.dry()) return;
         StemArgs a{};
+        if (out2) { a.w2 = f.small<float>("stem.p2"); a.out2 = out2->hi; a.out2_lo = out2->lo; }
         a.x = x; a.x_dtype = x_dtype; a.x_off = x_off_dev; a.sB = sB; a.sH = sH; a.sW = sW;
         a.w = f.small<float>("stem"); a.slope = n.scalars.at("stem_slope");
         a.out = out.hi; a.out_lo = out.lo; a.out_lo8 = out.lo8; a.B = B; a.H = h; a.W = w; a.taps = (int)n.scalars.at("stem_taps");
@@ -1483,10 +1503,15 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         const bool poolfuse = n.opt.pool_fuse;
         float* partial = (float*)f.ar.take((size_t)B * std::max(nslab, pslabs) * 64 * 4);
         float* gate = (float*)f.ar.take((size_t)B * 64 * 4);
-        stem(A);
-        f.tap("stem", A, h, w, 64, 48);
-        f.conv("input2", A, Bb, nullptr, h, w);
-        f.tap("input2", Bb, h, w, 64, 48);
+        // conv_input2's output is x times a fixed vector (see "stem.p2"): the stem writes it beside its own output, the 48 -> 48 1x1 conv is not launched (round 6)
+        const bool stem2 = n.opt.stem2 && !n.debug && !f.direct && (int)n.scalars.at("stem_taps") == 1;
+        if (stem2) stem(A, &Bb);
+        else {
+            stem(A);
+            f.tap("stem", A, h, w, 64, 48);
+            f.conv("input2", A, Bb, nullptr, h, w);
+            f.tap("input2", Bb, h, w, 64, 48);
+        }
         float* gate2 = (float*)f.ar.take((size_t)2 * B * 64 * 4);
         for (int k = 1; k <= 3; ++k) {
             const std::string key = "lb" + std::to_string(k);

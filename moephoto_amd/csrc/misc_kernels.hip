@@ -97,6 +97,17 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
                 *(uint2*)((unsigned char*)a.out_lo + p * 64 + cg) = make_uint2(p0, p1);
             }
         }
+        if (TAPS == 1 && a.w2) {      // conv_input2 of this pixel in closed form: x * P (x >= 0) or x * Q (StemArgs::w2)
+            const float xv = v[0][e4];
+            const float* pq = a.w2 + (xv < 0.f ? 64 : 0) + cg;
+            const float4 q0 = *(const float4*)pq, q1 = *(const float4*)(pq + 4);
+            const float t[8] = {xv * q0.x, xv * q0.y, xv * q0.z, xv * q0.w, xv * q1.x, xv * q1.y, xv * q1.z, xv * q1.w};
+            half8_t o2, l2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { o2[e] = (half_t)t[e]; l2[e] = (half_t)((t[e] - (float)o2[e]) * 2048.f); }
+            *(half8_t*)(a.out2 + p * 64 + cg) = o2;
+            if (a.out2_lo) *(half8_t*)(a.out2_lo + p * 64 + cg) = l2;
+        }
     }
 }
 

@@ -232,12 +232,12 @@ def test_perturbed_checkpoints_hold_the_contract_against_the_oracle(dev):
 
 # ---- timing floors: a regression of a family's frame time fails a test instead of waiting for a census (lite8's 3x slow-down shipped with green tests) ----
 # ms per 1080p frame (256-px tiles, fp16 I/O, default arithmetic) measured on the round's boxes, x 1.5: boxes differ by 5-8 %, the kernels run at the package power cap
-FRAME_MS_CEILING = {'SR a2': 13.8 * 1.5, 'SR a3': 18.2 * 1.5, 'SR a4': 24.6 * 1.5, 'SR lite2': 10.6 * 1.5, 'SR lite4': 14.8 * 1.5, 'SR lite8': 36.5 * 1.5, 'DN lite5': 8.2 * 1.5, 'DN lite10': 8.2 * 1.5,
+FRAME_MS_CEILING = {'SR a2': 13.8 * 1.5, 'SR a3': 18.2 * 1.5, 'SR a4': 24.6 * 1.5, 'SR lite2': 10.2 * 1.5, 'SR lite4': 14.4 * 1.5, 'SR lite8': 36.5 * 1.5, 'DN lite5': 8.2 * 1.5, 'DN lite10': 8.2 * 1.5,
                     'DN l25': 31.4 * 1.5}
 
 
 def test_frame_time_floors_per_family(dev):
-    """One 1080p frame per model family through doCrop (the plugin tables, 256-px tiles, fp16 I/O, default arithmetic), timed: at most 1.5x the round's measured figure.
+    """One 1080p frame per model family through doCrop (the plugin tables, 256-px tiles, fp16 I/O, default arithmetic), timed (the fastest of five frames): at most 1.5x the round's measured figure.
     Generous on purpose -- it is there to catch a family falling onto a fallback kernel (round 5: lite8's last stages on the generic 64-bit kernel, 27 ms a launch)."""
     from moephoto_amd import imageProcess as ip, runDN, runSR
     from moephoto_amd.config import config
@@ -263,11 +263,13 @@ def test_frame_time_floors_per_family(dev):
             for _ in range(2):
                 ip.doCrop(opt, x)
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(3):
+            best = float('inf')
+            for _ in range(5):      # the FASTEST of five frames, each timed by itself: a stall of the box (one 28-ms mean of three a3 frames among dozens of 17.5-ms runs in round 6)
+                t0 = time.perf_counter()      # must not fail the suite -- a family on a fallback kernel is slow on every frame
                 ip.doCrop(opt, x)
-            torch.cuda.synchronize()
-            got[name] = (time.perf_counter() - t0) / 3 * 1e3
+                torch.cuda.synchronize()
+                best = min(best, (time.perf_counter() - t0) * 1e3)
+            got[name] = best
             del opt
             torch.cuda.empty_cache()
     finally:

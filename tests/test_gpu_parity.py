@@ -1189,6 +1189,41 @@ def test_lite_frm_gate_from_conv2_input(key, dev):
         m.set_option('frm_pre', 1)
 
 
+@pytest.mark.parametrize('key', ['lite2', 'lite8'])
+def test_lite_conv_input2_in_closed_form(key, dev):
+    """Option stem2 (default on; MoeNet_lite2.py:40-41): conv_input2(PReLU(conv_input(x))) has ONE input channel and 1x1 kernels, so it is x times a fixed 48-vector (one for
+    x >= 0, one for x < 0) -- the stem writes that tensor beside its own output and the 48 -> 48 conv is not launched.  Against the launched form (stem2 = 0): fp32-rounding
+    apart, both within 2e-5 of the oracle; inputs of both signs (the nets are only ever fed [0, 1], the identity holds for any x)."""
+    arch = gd.MODELS[key][0]
+    sd = gd.state_dict_for(key, load_state_dict_file)
+    m = module_for(key)
+    try:
+        for shape in ((3, 24, 40), (1, 9, 35), (2, 64, 96), (1, 1, 7)):
+            for kind in ('natural', 'noise', 'signed'):
+                x = (gd.natural_image(73, shape) if kind == 'natural' else gd.noise_image(73, shape))[:, None]
+                if kind == 'signed':
+                    x = (x - np.float32(0.5)) * np.float32(1.5)
+                xd = torch.from_numpy(x).to(dev)
+                y0 = m.set_option('stem2', 0)(xd)[-1].cpu().numpy()
+                y1 = m.set_option('stem2', 1)(xd)[-1].cpu().numpy()
+                want = onets.forward(arch, sd, x).numpy()
+                assert np.abs(y1 - want).max() <= 2e-5 and np.abs(y0 - want).max() <= 2e-5, (key, shape, kind, float(np.abs(y1 - want).max()), float(np.abs(y0 - want).max()))
+                assert np.abs(y1 - y0).max() <= 1e-5, (key, shape, kind, float(np.abs(y1 - y0).max()))
+        # plain fp16 operands (not lite's default: every layer of it is error-critical): the launched conv rounds its operands to fp16, the closed form does not -- the two
+        # agree at that level
+        mh = module_for(key, 'fp16')
+        x = gd.natural_image(73, (2, 40, 56))[:, None]
+        xd = torch.from_numpy(x).to(dev)
+        try:
+            h0 = mh.set_option('stem2', 0)(xd)[-1].cpu().numpy()
+        finally:
+            mh.set_option('stem2', 1)
+        h1 = mh(xd)[-1].cpu().numpy()
+        assert np.isfinite(h0).all() and np.isfinite(h1).all() and np.abs(h1 - h0).max() <= 2e-2, (key, float(np.abs(h1 - h0).max()))
+    finally:
+        m.set_option('stem2', 1)
+
+
 def test_integration_md_stub_drives_every_family(dev):
     """INTEGRATION.md section 1 is the binding a MoePhoto maintainer would add (a ctypes stub over include/moephoto_amd.h).  This test EXECUTES that text --
     the first python block of the file, with the library path filled in -- and drives one SR key, one NetDN key, one SEDN key and one lite key through the

@@ -288,6 +288,8 @@ NOT_IN_THE_TABLE = {
     # option forms the form-vs-form GPU tests compare, and fallbacks for shapes the fast kernels refuse (profiles/r05/h_kernel_census_gpu_test_suite.txt: all launched by the GPU suite)
     'conv64_x3_kernel<3>': 'plain + pooled epilogue: lite with the gate pooled from conv_2\'s OUTPUT (option frm_pre = 0: test_lite_frm_gate_from_conv2_input compares the forms)',
     'frm_gate_kernel': 'the FRM gate from pooled sums of conv_2\'s output: frm_pre = 0, and lite under fp16 / mixed',
+    'conv1x1_kernel<true, 1, false, 4>': 'lite\'s conv_input2 as a launched 1x1 conv (option stem2 = 0: test_lite_conv_input2_in_closed_form compares it with the stem\'s closed form)',
+    'conv1x1_kernel<false, 1, false, 4>': 'the same layer on plain fp16 operands (precision fp16, stem2 = 0: the same test)',
     'sedn_xsum_kernel': 'the pass over x when the producing conv did not form the channel totals (option pool_fuse = 0: test_sedn_fused_block_tail_shapes compares the forms); since round 6 sedn_fmean visits the border itself when it did',
     'conv3x3_rw_kernel<3, false>': 'phase-class-sums fused tail on patch-aligned images: option up_impl = rw (A/B of conv3x3_ps4)',
     'conv3x3_rw_kernel<7, false>': 'the same with split tail activations',
