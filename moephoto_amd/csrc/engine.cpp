@@ -115,6 +115,7 @@ struct NetOptions {
     bool fuse_tail = true;    // fuse_tail   last upsampler conv + 64->1 / 48->1 tail conv in one kernel
     bool sedn_fuse = true;    // sedn_fuse   SEDN's fused block tail
     bool pool_fuse = true;    // pool_fuse   SE / FRM channel sums out of the producing conv's epilogue
+    bool lite_lut = true;     // lite_lut    lite, fp16 inputs: the U branch as a table lookup inside the final sum (see moe_net::lut) | 0: computed
     bool stem2 = true;        // stem2       lite: conv_input2's output written by the stem in closed form (x times a fixed vector: StemArgs::w2), the 48 -> 48 1x1 conv not launched | 0: launched
     bool frm_pre = true;      // frm_pre     lite (fp16x3): the FRM gate of an LB from conv_2's INPUT (frm_pre_kernel), conv_2 stores gate * conv + x -- no frm_apply pass | 0: gate from conv_2's output, frm_apply
     int overlap_calls = 1;    // overlap_calls  1 (default): consecutive small forwards that the CALLER marks as independent of each other (moe_net_forward_ex with MOE_FWD_INPUT_SINCE_PREV:
@@ -181,6 +182,7 @@ struct NetOptions {
         if (key == "pool_fuse") return flag(pool_fuse);
         if (key == "frm_pre") return flag(frm_pre);
         if (key == "stem2") return flag(stem2);
+        if (key == "lite_lut") return flag(lite_lut);
         if (key == "dbg") { dbg = atoi(v); return true; }
         if (key == "tiles_per_batch") { tiles_per_batch = atoi(v); return tiles_per_batch >= 0; }
         if (key == "max_groups") { max_groups = atoi(v); return max_groups >= 0; }
@@ -205,7 +207,7 @@ struct NetOptions {
     {
         static const char* const names[][2] = {{"MOE_CONV_IMPL", "conv_impl"}, {"MOE_SP_IMPL", "sp_impl"}, {"MOE_TAIL_SPLIT", "tail_split"}, {"MOE_TAIL_FORM", "tail_form"}, {"MOE_UP_IMPL", "up_impl"}, {"MOE_UP_FUSE2", "up_fuse2"},
                                                {"MOE_CONV1X1", "conv1x1"}, {"MOE_Q8_IMPL", "q8_impl"}, {"MOE_EXACT_FUSE", "exact_fuse"}, {"MOE_BRANCH_STREAMS", "branch_streams"}, {"MOE_BRANCH_GROUPS", "branch_groups"}, {"MOE_AUTO_CALIBRATE", "auto_calibrate"}, {"MOE_OVERLAP_CALLS", "overlap_calls"}, {"MOE_OVERLAP_GROUPS", "overlap_groups"}, {"MOE_OVERLAP_FORK", "overlap_fork"}, {"MOE_S64", "s64"}, {"MOE_K48", "k48"}, {"MOE_X3_IMPL", "x3_impl"}, {"MOE_LO8", "lo8"}, {"MOE_X3_FUSE", "x3_fuse"}, {"MOE_ARSB_FUSE", "arsb_fuse"}, {"MOE_FUSE_TAIL", "fuse_tail"},
-                                               {"MOE_SEDN_FUSE", "sedn_fuse"}, {"MOE_POOL_FUSE", "pool_fuse"}, {"MOE_FRM_PRE", "frm_pre"}, {"MOE_STEM2", "stem2"}, {"MOE_DBG", "dbg"}, {"MOE_TRACE_KEY", "trace_key"},
+                                               {"MOE_SEDN_FUSE", "sedn_fuse"}, {"MOE_POOL_FUSE", "pool_fuse"}, {"MOE_FRM_PRE", "frm_pre"}, {"MOE_STEM2", "stem2"}, {"MOE_LITE_LUT", "lite_lut"}, {"MOE_DBG", "dbg"}, {"MOE_TRACE_KEY", "trace_key"},
                                                {"MOE_TILES_PER_BATCH", "tiles_per_batch"}, {"MOE_MAX_GROUPS", "max_groups"}};
         for (const auto& nv : names)
             if (const char* e = getenv(nv[0]))
@@ -228,6 +230,10 @@ struct moe_net {
     int exact_blocks = -1;       // MOE_PREC_MIXED: leading ARSBs computed with split operands (-1: the calibrated count if there is one, else the per-architecture default)
     // calibration of THESE weights (moe_net_calibrate; run by moe_net_finalize(MOE_PREC_AUTO) on the ARSB nets): valid until a parameter changes
     bool calib_valid = false;
+    // lite, fp16 inputs (round 6): the U branch (MoeNet_lite2.py:47,50: conv_input, uim, convt_I1) is POINTWISE -- 1x1 convs, pixel shuffles, PReLUs on a one-channel input -- so its
+    // output at an HR pixel is a function of ONE input value and the pixel's phase: a table over the 65,536 fp16 bit patterns, filled once per checkpoint by the U branch's own
+    // kernels run on an image of all patterns (bit-identical to computing it), [256 r][256 r] fp32.  lut_state: 0 not tried, 1 ready, -1 not available, 2 being built
+    float* lut = nullptr; half_t* lut_in = nullptr; int lut_state = 0;
     int calib_blocks = -1;       // smallest count of split-operand ARSBs whose worst noise-tile error against the exact mode is within the target (-1: none is -> FP16X3)
     double calib_err = 0.0;      // that error
     int auto_resolved = -1;      // what MOE_PREC_AUTO resolved to at the last finalize with it (-1: not finalized that way since the parameters changed)
@@ -515,8 +521,18 @@ static void pack_q8(const Param& W, ConvLayer& L, BlobBuilder& bb, float fold)
 
 static float scalar_of(const moe_net& n, const std::string& name) { return n.get(name)->data[0]; }
 
+static void drop_lut(moe_net& n)
+{
+    if (n.lut || n.lut_in) (void)hipDeviceSynchronize();      // (a forward reading the table may be in flight; rare: weights or options changed)
+    if (n.lut) (void)hipFree(n.lut);
+    if (n.lut_in) (void)hipFree(n.lut_in);
+    n.lut = nullptr; n.lut_in = nullptr; n.lut_state = 0;
+}
+
 static int build_device_weights(moe_net& n, int precision)
 {
+    drop_lut(n);      // (the table holds the U branch of the weights packed before)
+
     BlobBuilder bb;
     n.convs.clear(); n.conv_index.clear(); n.small.clear(); n.scalars.clear();
     const bool mixed = precision == MOE_PREC_MIXED, plain = precision == MOE_PREC_DEBUG_DIRECT;
@@ -727,6 +743,7 @@ struct Fwd {
     size_t acc32_elems = 0;
     half_t* side16 = nullptr;    // fp16 sum of the two low-order products of a 3x3 conv (split precision), output layout
     bool dry() const { return ar.base == nullptr; }
+    float* lut_capture = nullptr;     // lite: this forward fills the U-branch table -- its input is the image of all fp16 patterns; part[1] is copied here instead of summed
     int tail1_parts = 2;         // partial planes per branch the fused 1x1 tail wrote (conv_mfma_kernel: 2, conv1x1.hip: 1)
     int tail_form = 0;           // fused tail of this forward: 0 nine tap planes (conv3x3_sp), 1 phase-class sums (conv3x3_rw + tapsum4)
     float* pool_out = nullptr;   // set around a conv() call: let the conv pool its output per plane (conv64_x3's pooled epilogue), [B][pool_slabs][64]
@@ -1569,7 +1586,10 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         // and read back per branch, never exists): the conv's epilogue dots its fp32 activations with the tail weights.
         const bool fuse1 = n.opt.fuse_tail && !f.direct && !n.debug && n.stages >= 1;
         float* part[2] = {nullptr, nullptr};
+        // fp16 input and the table of this checkpoint's U branch at hand (moe_net::lut): the U branch is not run, the final sum looks its value up
+        const bool use_lut = !f.dry() && !f.lut_capture && fuse1 && x_dtype == MOE_F16 && n.lut_state == 1 && n.lut && n.opt.lite_lut;
         for (int br = 0; br < 2; ++br) {
+            if (br == 1 && use_lut) { H = h * n.scale; W = w * n.scale; break; }
             Act cur = br == 0 ? Bb : A;
             H = h; W = w;
             for (int st = 0; st < n.stages; ++st) {
@@ -1616,12 +1636,20 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
         }
         if (fuse1) {
             if (!f.dry()) {
+                if (f.lut_capture) {      // (B = 1, the 256 x 256 image of all patterns: part[1] IS the table)
+                    if (f.tail1_parts != 1 || !part[1]) return MOE_EINVAL;
+                    HIP_TRY(hipMemcpyAsync(f.lut_capture, part[1], (size_t)H * W * 4, hipMemcpyDeviceToDevice, s));
+                    return MOE_OK;
+                }
+                if (use_lut && f.tail1_parts != 1) return fail(MOE_EINVAL, "lite: the U-branch table needs the one-part form of the fused tail");
                 Tail1SumArgs t{};
-                t.p0 = part[0]; t.p1 = part[1]; t.nparts = f.tail1_parts; t.y = y; t.y_dtype = y_dtype; t.y_off = y_off_dev; t.B = B; t.H = H; t.W = W;
+                t.p0 = part[0]; t.p1 = use_lut ? nullptr : part[1]; t.nparts = f.tail1_parts; t.y = y; t.y_dtype = y_dtype; t.y_off = y_off_dev; t.B = B; t.H = H; t.W = W;
+                if (use_lut) { t.lut = n.lut; t.r = n.scale; t.x = x; t.x_off = x_off_dev; t.sB = sB; t.sH = sH; t.sW = sW; }
                 launch_tail1sum(t, s);
             }
             return MOE_OK;
         }
+        if (f.lut_capture) return MOE_EINVAL;      // (no fused tail: no table -- build_lite_lut marks it unavailable)
         tail(&fin[0], &fin[1], H, W, false);
     }
     return MOE_OK;
@@ -1638,10 +1666,35 @@ size_t workspace_need(moe_net& n, int B, int h, int w)
 int forward_dev_chunk(moe_net& n, const void* x, int x_dtype, int B, int h, int w, long long sB, long long sH, long long sW,
                       const long long* x_off_dev, void* y, int y_dtype, const long long* y_off_dev, hipStream_t s, bool y_off_mult8);
 
+// The table of lite's U branch (moe_net::lut), filled on the first fp16 forward of a checkpoint: one ordinary forward of the net on a 256 x 256 one-plane image whose pixel
+// (i, j) holds the fp16 bit pattern 256 i + j; run_forward copies the U branch's plane (part[1]) instead of summing.  Not during stream capture (it allocates), not for
+// precisions / options whose fused tail is not the one-part form (then the table stays unavailable and the branch is computed as before).
+static void build_lite_lut(moe_net& n, hipStream_t s)
+{
+    n.lut_state = -1;
+    if (n.arch != MOE_ARCH_LITE || !n.opt.lite_lut || n.debug || !n.opt.fuse_tail || n.precision == MOE_PREC_DEBUG_DIRECT) return;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); n.lut_state = 0; return; }      // (another forward may try)
+    const int r = n.scale;
+    std::vector<unsigned short> pat(65536);
+    for (int i = 0; i < 65536; ++i) pat[(size_t)i] = (unsigned short)i;
+    if (hipMalloc((void**)&n.lut_in, 65536 * 2) != hipSuccess || hipMalloc((void**)&n.lut, (size_t)65536 * r * r * 4) != hipSuccess) { (void)hipGetLastError(); drop_lut(n); n.lut_state = -1; return; }
+    if (hipMemcpyAsync(n.lut_in, pat.data(), 65536 * 2, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); drop_lut(n); n.lut_state = -1; return; }
+    float* scratch = nullptr;
+    if (hipMalloc((void**)&scratch, (size_t)65536 * r * r * 4) != hipSuccess) { (void)hipGetLastError(); drop_lut(n); n.lut_state = -1; return; }
+    n.lut_state = 2;
+    const int rc = forward_dev_chunk(n, n.lut_in, MOE_F16, 1, 256, 256, 65536, 256, 1, nullptr, scratch, MOE_F32, nullptr, s, true);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(scratch);
+    if (rc != MOE_OK) { (void)hipGetLastError(); drop_lut(n); n.lut_state = -1; return; }
+    n.lut_state = 1;
+}
+
 int forward_dev(moe_net& n, const void* x, int x_dtype, int B, int h, int w, long long sB, long long sH, long long sW,
                 const long long* x_off_dev, void* y, int y_dtype, const long long* y_off_dev, hipStream_t s, bool y_off_mult8 = true)
 {
     if (!n.finalized) return fail(MOE_ESTATE, "moe_net_forward: net is not finalized (load_state_dict + to(device) first)");
+    if (n.arch == MOE_ARCH_LITE && x_dtype == MOE_F16 && n.lut_state == 0 && n.opt.lite_lut) build_lite_lut(n, s);
     if (B < 1 || h < 1 || w < 1) return fail(MOE_EINVAL, "moe_net_forward: bad shape B=%d h=%d w=%d", B, h, w);
     if ((x_dtype != MOE_F32 && x_dtype != MOE_F16) || (y_dtype != MOE_F32 && y_dtype != MOE_F16))
         return fail(MOE_EINVAL, "moe_net_forward: x/y dtype must be MOE_F32 or MOE_F16");
@@ -1682,6 +1735,7 @@ int forward_dev_chunk(moe_net& n, const void* x, int x_dtype, int B, int h, int 
     Fwd f{n, s, B, h, w, Arena{n.ws, 0}, n.precision == MOE_PREC_FP16X3, n.precision == MOE_PREC_DEBUG_DIRECT};
     f.mixed = n.precision == MOE_PREC_MIXED;
     f.y_vec = y_off_mult8 && ((uintptr_t)y % 16 == 0);   // every output plane starts 16-byte aligned: wide stores allowed
+    if (n.lut_state == 2 && x == (const void*)n.lut_in) f.lut_capture = n.lut;      // (build_lite_lut's own forward)
     int rc = run_forward(n, f, x, x_dtype, sB, sH, sW, x_off_dev, y, y_dtype, y_off_dev);
     if (rc) return rc;
     hipError_t e = hipGetLastError();
@@ -1904,6 +1958,7 @@ static void pipe_destroy(moe_net& n);
 void moe_net_destroy(moe_net* n)
 {
     if (!n) return;
+    drop_lut(*n);
     if (n->blob) (void)hipFree(n->blob);
     if (n->ws) (void)hipFree(n->ws);
     for (auto& t : n->taps) if (t.second.dev) (void)hipFree(t.second.dev);
@@ -2195,6 +2250,7 @@ int moe_net_set_option(moe_net* n, const char* key, const char* value)
 {
     if (!n || !key || !value) return fail(MOE_EINVAL, "moe_net_set_option: NULL argument");
     if (!n->opt.set(key, value)) return fail(MOE_EINVAL, "moe_net_set_option: unknown option or value \"%s\" = \"%s\"", key, value);
+    if (n->lut_state != 2) drop_lut(*n);      // (a kernel-form switch may change the U branch's bits: the table is refilled by the next fp16 forward)
     if (!strcmp(key, "max_groups") && n->finalized) n->max_groups = n->opt.max_groups > 0 ? n->opt.max_groups : conv_mfma_max_groups();
     return MOE_OK;
 }

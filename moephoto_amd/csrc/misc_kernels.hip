@@ -527,6 +527,11 @@ __global__ __launch_bounds__(256) void tail1sum_kernel(Tail1SumArgs a)
     if (a.p1) {
         v += a.p1[idx];
         if (a.nparts == 2) v += a.p1[plane + idx];
+    } else if (a.lut) {      // the U branch of a pointwise net is a function of the input pixel's value and the HR pixel's phase
+        const int Y = (int)(p / a.W), X = (int)(p - (long long)Y * a.W);
+        const int ly = Y / a.r, lx = X / a.r;
+        const unsigned bits = ((const unsigned short*)a.x)[(a.x_off ? a.x_off[b] : (long long)b * a.sB) + (long long)ly * a.sH + (long long)lx * a.sW];
+        v += a.lut[((long long)(bits >> 8) * a.r + (Y - ly * a.r)) * (256 * a.r) + (bits & 255) * a.r + (X - lx * a.r)];
     }
     const long long yo = (a.y_off ? a.y_off[b] : (long long)b * hw) + p;
     if (a.y_dtype == MOE_F16) ((half_t*)a.y)[yo] = (half_t)v;

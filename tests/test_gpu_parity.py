@@ -1224,6 +1224,39 @@ def test_lite_conv_input2_in_closed_form(key, dev):
         m.set_option('stem2', 1)
 
 
+@pytest.mark.parametrize('key', ['lite2', 'lite4', 'lite8'])
+def test_lite_u_branch_as_a_table_for_fp16_inputs(key, dev):
+    """Option lite_lut (default on; MoeNet_lite2.py:47,50): the U branch -- conv_input, PReLU, the uim stages, convt_I1 -- is pointwise on a ONE-channel input, so its value at an
+    HR pixel depends on one input value and the pixel's phase.  For fp16 inputs the engine fills a table over the 65,536 bit patterns with the branch's own kernels (once per
+    checkpoint, on the first fp16 forward) and the final sum looks the value up: BIT-IDENTICAL to computing the branch (lite_lut = 0), within 2e-5 (+ half an fp16 ulp of the
+    output) of the oracle on the fp16-rounded input; fp32 inputs keep computing; a changed option or reloaded weights drop the table."""
+    arch = gd.MODELS[key][0]
+    sd = gd.state_dict_for(key, load_state_dict_file)
+    m = module_for(key)
+    try:
+        for shape in ((3, 24, 40), (1, 9, 35), (2, 64, 96), (1, 1, 7), (4, 33, 17)):
+            for kind in ('natural', 'noise'):
+                x = (gd.natural_image(79, shape) if kind == 'natural' else gd.noise_image(79, shape))[:, None]
+                xh = torch.from_numpy(x).to(dev).half()
+                y0 = m.set_option('lite_lut', 0)(xh)[-1]
+                y1 = m.set_option('lite_lut', 1)(xh)[-1]
+                y2 = m(xh)[-1]
+                assert torch.equal(y1, y0), (key, shape, kind, float((y1.float() - y0.float()).abs().max()))
+                assert torch.equal(y1, y2), (key, shape, kind)
+                want = onets.forward(arch, sd, xh.float().cpu().numpy()).numpy()
+                got = y1.float().cpu().numpy()
+                assert np.abs(got - want).max() <= 2e-5 + HALF_OUT * (y1.dtype == torch.float16), (key, shape, kind, float(np.abs(got - want).max()))
+        # a strided view (what doCrop's per-tile calls pass) and an fp32 input right behind an fp16 one
+        big = torch.from_numpy(gd.natural_image(83, (3, 70, 90))[:, None]).to(dev).half()
+        view = big[:, :, 5:53, 11:75]
+        assert torch.equal(m(view)[-1], m(view.contiguous())[-1])
+        x32 = view.float()
+        want = onets.forward(arch, sd, x32.cpu().numpy()).numpy()
+        assert np.abs(m(x32)[-1].float().cpu().numpy() - want).max() <= 2e-5 + HALF_OUT
+    finally:
+        m.set_option('lite_lut', 1)
+
+
 def test_integration_md_stub_drives_every_family(dev):
     """INTEGRATION.md section 1 is the binding a MoePhoto maintainer would add (a ctypes stub over include/moephoto_amd.h).  This test EXECUTES that text --
     the first python block of the file, with the library path filled in -- and drives one SR key, one NetDN key, one SEDN key and one lite key through the
