@@ -331,6 +331,7 @@ struct Tail1SumArgs {
     // lite, fp16 input: the U branch's value from the table of the net (engine.cpp, moe_net::lut: [256 r][256 r] fp32, the entry of input pattern v and phase (py, px) at
     // ((v >> 8) r + py) 256 r + (v & 255) r + px) instead of p1 (nullptr then); x = the forward's fp16 input (strides in elements, x_off = device [B] offsets or nullptr: b sB)
     const float* lut; int r; const void* x; const long long* x_off; long long sB, sH, sW;
+    int vec_ok;                            // every output plane starts 16-byte aligned (the four-outputs-per-thread table kernel)
 };
 void launch_tail1sum(const Tail1SumArgs& a, hipStream_t s);
 

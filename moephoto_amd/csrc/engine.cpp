@@ -1644,7 +1644,7 @@ int run_forward(moe_net& n, Fwd& f, const void* x, int x_dtype, long long sB, lo
                 if (use_lut && f.tail1_parts != 1) return fail(MOE_EINVAL, "lite: the U-branch table needs the one-part form of the fused tail");
                 Tail1SumArgs t{};
                 t.p0 = part[0]; t.p1 = use_lut ? nullptr : part[1]; t.nparts = f.tail1_parts; t.y = y; t.y_dtype = y_dtype; t.y_off = y_off_dev; t.B = B; t.H = H; t.W = W;
-                if (use_lut) { t.lut = n.lut; t.r = n.scale; t.x = x; t.x_off = x_off_dev; t.sB = sB; t.sH = sH; t.sW = sW; }
+                if (use_lut) { t.lut = n.lut; t.r = n.scale; t.x = x; t.x_off = x_off_dev; t.sB = sB; t.sH = sH; t.sW = sW; t.vec_ok = f.y_vec; }
                 launch_tail1sum(t, s);
             }
             return MOE_OK;

@@ -538,6 +538,42 @@ __global__ __launch_bounds__(256) void tail1sum_kernel(Tail1SumArgs a)
     else ((float*)a.y)[yo] = v;
 }
 
+// the table form (Tail1SumArgs::lut), four consecutive outputs of a row per thread (W % 4 == 0, one part per branch, output rows 8- / 16-byte aligned): r = 4, 8 -- the four
+// lie in ONE input pixel, their table entries are 16 contiguous bytes; r = 2 -- two input pixels, 8 bytes each.  The same additions as tail1sum_kernel: the same bits.
+__global__ __launch_bounds__(256) void tail1sum_lut4_kernel(Tail1SumArgs a)
+{
+    const int wq = a.W >> 2;
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= (long long)a.B * a.H * wq) return;
+    const int xq = (int)(q % wq);
+    const long long t = q / wq;
+    const int Y = (int)(t % a.H), b = (int)(t / a.H);
+    const int X0 = xq * 4, ly = Y / a.r, py = Y - ly * a.r;
+    const long long p = (long long)Y * a.W + X0, idx = (long long)b * a.H * a.W + p;
+    const float4 pv = *(const float4*)(a.p0 + idx);
+    const unsigned short* xrow = (const unsigned short*)a.x + (a.x_off ? a.x_off[b] : (long long)b * a.sB) + (long long)ly * a.sH;
+    float v[4] = {pv.x, pv.y, pv.z, pv.w};
+    if (a.r >= 4) {
+        const int lx = X0 / a.r, px = X0 - lx * a.r;
+        const unsigned bits = xrow[(long long)lx * a.sW];
+        const float4 u = *(const float4*)(a.lut + ((long long)(bits >> 8) * a.r + py) * (256 * a.r) + (bits & 255) * a.r + px);
+        v[0] += u.x; v[1] += u.y; v[2] += u.z; v[3] += u.w;
+    } else {
+        const int lx = X0 >> 1;
+        const unsigned b0 = xrow[(long long)lx * a.sW], b1 = xrow[(long long)(lx + 1) * a.sW];
+        const float2 u0 = *(const float2*)(a.lut + ((long long)(b0 >> 8) * 2 + py) * 512 + (b0 & 255) * 2);
+        const float2 u1 = *(const float2*)(a.lut + ((long long)(b1 >> 8) * 2 + py) * 512 + (b1 & 255) * 2);
+        v[0] += u0.x; v[1] += u0.y; v[2] += u1.x; v[3] += u1.y;
+    }
+    const long long yo = (a.y_off ? a.y_off[b] : (long long)b * a.H * a.W) + p;
+    if (a.y_dtype == MOE_F16) {
+        half4_t h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = (half_t)v[e];
+        *(half4_t*)((half_t*)a.y + yo) = h;
+    } else *(float4*)((float*)a.y + yo) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Global average pool partial sums (AdaptiveAvgPool2d(1): models.py:190,274): in [B][HW][C] -> [B][nslab][C].
 // Deterministic two-stage reduction (the second stage lives in the gate kernels).
@@ -1340,6 +1376,11 @@ void launch_tapsum(const TapSumArgs& a, hipStream_t s)
 
 void launch_tail1sum(const Tail1SumArgs& a, hipStream_t s)
 {
+    if (a.lut && !a.p1 && a.nparts == 1 && a.vec_ok && a.W % 4 == 0 && (a.r == 2 || a.r == 4 || a.r == 8) && ((uintptr_t)a.p0 & 15) == 0) {
+        const long long nq = (long long)a.B * a.H * (a.W / 4);
+        hipLaunchKernelGGL(tail1sum_lut4_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, a);
+        return;
+    }
     const long long n = (long long)a.B * a.H * a.W;
     hipLaunchKernelGGL(tail1sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
 }
