@@ -290,7 +290,6 @@ NOT_IN_THE_TABLE = {
     'frm_gate_kernel': 'the FRM gate from pooled sums of conv_2\'s output: frm_pre = 0, and lite under fp16 / mixed',
     'conv1x1_kernel<true, 1, false, 4>': 'lite\'s conv_input2 as a launched 1x1 conv (option stem2 = 0: test_lite_conv_input2_in_closed_form compares it with the stem\'s closed form)',
     'conv1x1_kernel<false, 1, false, 4>': 'the same layer on plain fp16 operands (precision fp16, stem2 = 0: the same test)',
-    'tail1sum_lut4_kernel': 'lite with fp16 inputs: the final sum with the U branch from the table, four outputs per thread (test_lite_u_branch_as_a_table_for_fp16_inputs; in the table once it is regenerated)',
     'sedn_xsum_kernel': 'the pass over x when the producing conv did not form the channel totals (option pool_fuse = 0: test_sedn_fused_block_tail_shapes compares the forms); since round 6 sedn_fmean visits the border itself when it did',
     'conv3x3_rw_kernel<3, false>': 'phase-class-sums fused tail on patch-aligned images: option up_impl = rw (A/B of conv3x3_ps4)',
     'conv3x3_rw_kernel<7, false>': 'the same with split tail activations',
