@@ -157,9 +157,7 @@ int moe_net_set_exact_blocks(moe_net* net, int blocks);
  * ("sp_impl" = "auto" | "rw" | "sp", "arsb_fuse" / "x3_fuse" / "conv1x1" / "fuse_tail" / "sedn_fuse" / "pool_fuse" = "0" | "1",
  * "tail_split" = "0" | "r" | "ru", "tail_form" = "sums" | "planes", "conv_impl" = "sp" | "v1", "tiles_per_batch", "max_groups",
  * "k48" = "0" | "1", "repeat" = "<layer key>:<n>" (measurement: the matching bracketed launches are issued n times -- tools/kernel_power.py), "x3_impl" = "auto" | "x3" | "q8" (the split-operand layers' kernel: three fp16 products, or the two
- * corrections on fp8 operands; auto = q8 for the SR nets and NetDN), "lo8" = "on" | "off" (fp8 low parts between conv64_q8 layers);
- * lite (python/MoeNet_lite2.py:16-20,40-51): "frm_pre" (an LB's FRM gate from conv_2's input, conv_2 stores gate * conv + x), "stem2" (conv_input2 in closed form inside the
- * stem), "lite_lut" (fp16 inputs: the pointwise U branch as a table over the fp16 bit patterns, bit-identical to computing it) = "0" | "1").
+ * corrections on fp8 operands; auto = q8 for the SR nets), "lo8" = "on" | "off" (fp8 low parts between conv64_q8 layers)).
  * Defaults come from the MOE_* environment variables of the same names ONCE, at moe_net_create; the forward path itself reads no
  * environment.  The reference has no such switches: its forward is torch.nn (python/imageProcess.py:391-395). */
 int moe_net_set_option(moe_net* net, const char* key, const char* value);
